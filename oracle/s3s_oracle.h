@@ -1,0 +1,129 @@
+/*
+ * s3s_oracle.h — CPU restatement of the shuffle-block codec path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (spark-s3-shuffle_amd/)
+ * may include, link or call this.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py use it — as the checker, never as the thing shipped.
+ *
+ * What it restates (reference = IBM/spark-s3-shuffle @ /root/reference, plus the
+ * third-party code the reference reaches through Spark's CompressionCodec, whose
+ * sources are NOT under /root/reference):
+ *
+ *   - on-store layout .data/.index/.checksum
+ *       src/main/scala/org/apache/spark/shuffle/helper/S3ShuffleHelper.scala:44-59,105-121
+ *       src/main/scala/org/apache/spark/shuffle/S3ShuffleMapOutputWriter.scala:58,91-118,197-201
+ *   - per-partition checksum validation on the reduce side
+ *       src/main/scala/org/apache/spark/storage/S3ChecksumValidationStream.scala:54-86
+ *       src/main/scala/org/apache/spark/shuffle/helper/S3ShuffleHelper.scala:94-103
+ *   - block range semantics
+ *       src/main/scala/org/apache/spark/storage/S3ShuffleBlockIterator.scala:37-42
+ *       src/main/scala/org/apache/spark/storage/S3ShuffleBlockStream.scala:36-40
+ *   - [EXT] org.lz4:lz4-java 1.8.0  LZ4BlockOutputStream / LZ4BlockInputStream framing
+ *           (reached from S3ShuffleReader.scala:59,108 via Spark 3.5.5 LZ4CompressionCodec)
+ *   - [EXT] liblz4 1.9.3  LZ4_compress_default (byU16 table mode, inputs < 64 KiB)
+ *   - [EXT] xxHash32 (seed 0x9747b28c, masked to 28 bits by lz4-java's asChecksum())
+ *   - [EXT] java.util.zip.CRC32 / Adler32
+ *   - [EXT] org.xerial.snappy:snappy-java SnappyOutputStream framing + raw snappy
+ *           (restated after the locally available libsnappy 1.1.8 — "parity unpinned"
+ *            against the JVM's bundled snappy 1.1.10)
+ *
+ * Pinning: tests/test_oracle_pins.py checks every function here against the native
+ * libraries present in this image (liblz4.so.1.9.3 — the same C code lz4-java binds
+ * through JNI —, zlib, python-xxhash, libsnappy 1.1.8, pyarrow's lz4_raw / snappy
+ * decoders) and against the committed golden vectors in tests/golden/.
+ */
+#ifndef S3S_ORACLE_H
+#define S3S_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* codec / checksum selectors — same numeric values as include/s3shuffle_codec.h */
+enum { S3O_CODEC_NONE = 0, S3O_CODEC_LZ4 = 1, S3O_CODEC_SNAPPY = 2 };
+enum { S3O_CHECKSUM_NONE = 0, S3O_CHECKSUM_ADLER32 = 1, S3O_CHECKSUM_CRC32 = 2 };
+
+/* error codes — same numeric values as include/s3shuffle_codec.h */
+enum {
+  S3O_OK = 0,
+  S3O_E_INVALID = -1,
+  S3O_E_CAPACITY = -2,
+  S3O_E_BAD_FRAME = -3,
+  S3O_E_CHECKSUM = -4,
+  S3O_E_UNSUPPORTED = -6
+};
+
+/* ---- primitive hashes / checksums -------------------------------------------------- */
+uint32_t s3o_xxh32(const void* data, size_t len, uint32_t seed);
+/* zlib conventions: start value 0 for crc32, 1 for adler32; both incremental. */
+uint32_t s3o_crc32(uint32_t crc, const void* data, size_t len);
+uint32_t s3o_adler32(uint32_t adler, const void* data, size_t len);
+/* the value java.util.zip.{Adler32,CRC32}.getValue() would return over data[0,len) */
+int64_t s3o_checksum(int algo, const void* data, size_t len);
+
+/* ---- raw LZ4 block ------------------------------------------------------------------ */
+/* LZ4_compressBound */
+int s3o_lz4_compress_bound(int src_len);
+/* Restatement of liblz4 1.9.3 LZ4_compress_default for src_len < 65547 (byU16 table).
+ * Returns compressed size, 0 if dst_cap is too small or src_len out of range. */
+int s3o_lz4_compress_block(const uint8_t* src, int src_len, uint8_t* dst, int dst_cap);
+/* Safe decoder. Returns decoded size (must be <= dst_cap) or <0 on malformed input.
+ * *consumed (optional) receives the number of source bytes read. */
+int s3o_lz4_decompress_block(const uint8_t* src, int src_len, uint8_t* dst, int dst_cap,
+                             int* consumed);
+
+/* ---- lz4-java LZ4Block stream ------------------------------------------------------- */
+int64_t s3o_lz4block_max_stream_size(int64_t ulen, int block_size);
+/* One LZ4BlockOutputStream (write ulen bytes, close). ulen == 0 -> 0 bytes (stream never
+ * opened). Returns bytes written or S3O_E_*. */
+int64_t s3o_lz4block_compress_stream(const uint8_t* src, int64_t ulen, int block_size,
+                                     uint8_t* dst, int64_t dst_cap);
+/* LZ4BlockInputStream(stopOnEmptyBlock=false): decodes concatenated streams until EOF.
+ * Returns decoded bytes or S3O_E_BAD_FRAME / S3O_E_CAPACITY. */
+int64_t s3o_lz4block_decompress_stream(const uint8_t* src, int64_t clen, uint8_t* dst,
+                                       int64_t dst_cap);
+
+/* ---- raw snappy + snappy-java SnappyOutputStream ------------------------------------ */
+int s3o_snappy_max_compressed_length(int src_len);
+int s3o_snappy_compress_block(const uint8_t* src, int src_len, uint8_t* dst, int dst_cap);
+int s3o_snappy_decompress_block(const uint8_t* src, int src_len, uint8_t* dst, int dst_cap);
+int64_t s3o_snappy_max_stream_size(int64_t ulen, int block_size);
+int64_t s3o_snappy_compress_stream(const uint8_t* src, int64_t ulen, int block_size,
+                                   uint8_t* dst, int64_t dst_cap);
+int64_t s3o_snappy_decompress_stream(const uint8_t* src, int64_t clen, uint8_t* dst,
+                                     int64_t dst_cap);
+
+/* ---- whole map output (the drop-in boundary) ---------------------------- */
+int64_t s3o_max_compressed_size(int codec, int block_size, const int64_t* src_offsets,
+                                int32_t num_partitions);
+/* Builds the exact .data image for one map task: partition p's uncompressed serialized
+ * bytes are src[src_offsets[p], src_offsets[p+1]); each non-empty partition becomes one
+ * codec stream; streams are concatenated.  out_index[N+1] is the cumulative index
+ * (host-endian; S3ShuffleHelper.writePartitionLengths semantics), out_checksums[N] the
+ * per-partition checksum over the COMPRESSED bytes (may be NULL iff checksum==NONE). */
+int s3o_compress_map_output(int codec, int checksum_algo, int block_size,
+                            const uint8_t* src, const int64_t* src_offsets,
+                            int32_t num_partitions, uint8_t* dst, int64_t dst_capacity,
+                            int64_t* out_index, int64_t* out_checksums, int64_t* out_total);
+/* Reduce side: comp[0,comp_len) holds partitions r0..r1-1 of one map output (a
+ * ShuffleBlockId or ShuffleBlockBatchId range); part_offsets[nparts+1] are the index
+ * entries relative to the range start.  Validates each partition's checksum exactly like
+ * S3ChecksumValidationStream (zero-length partitions compare the checksum of no bytes),
+ * then decodes the concatenated codec streams.  *out_bad_partition = first failing partition
+ * (relative) on S3O_E_CHECKSUM, else -1. */
+int s3o_decompress_range(int codec, int checksum_algo, const uint8_t* comp, int64_t comp_len,
+                         const int64_t* part_offsets, const int64_t* ref_checksums,
+                         int32_t nparts, uint8_t* dst, int64_t dst_capacity, int64_t* out_len,
+                         int32_t* out_bad_partition);
+
+/* .index / .checksum file images: big-endian longs (S3ShuffleHelper.writeArrayAsBlock). */
+void s3o_longs_to_be(const int64_t* v, int64_t n, uint8_t* out);
+int s3o_longs_from_be(const uint8_t* in, int64_t nbytes, int64_t* v); /* <0 if nbytes%8 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

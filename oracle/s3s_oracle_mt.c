@@ -1,0 +1,148 @@
+/*
+ * s3s_oracle_mt.c — multi-threaded CPU baseline driver (bench.py cpu_baseline leg only).
+ *
+ * TEST / BENCH INFRASTRUCTURE ONLY (see s3s_oracle.h).
+ *
+ * Mirrors how Spark runs the reference path: one map task per executor core, each task
+ * compressing + checksumming its own map output independently.  Each thread
+ * runs s3o_compress_map_output on its own task; when liblz4.so.1 (1.9.3 — the same native
+ * code lz4-java reaches through JNI) can be dlopen'ed, `use_liblz4=1` swaps the block
+ * compressor for the library's LZ4_compress_default so the baseline is not sandbagged by
+ * the restatement's plainer inner loops.
+ */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "s3s_oracle.h"
+
+typedef int (*lz4_fn)(const char*, char*, int, int);
+static lz4_fn g_lz4 = NULL;
+
+int s3o_mt_have_liblz4(void) {
+  if (g_lz4) return 1;
+  void* h = dlopen("liblz4.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return 0;
+  g_lz4 = (lz4_fn)dlsym(h, "LZ4_compress_default");
+  return g_lz4 != NULL;
+}
+
+/* LZ4Block stream using liblz4 for the block compressor (same framing as the oracle). */
+static void put_header(uint8_t* h, int token, uint32_t c, uint32_t o, uint32_t check) {
+  static const uint8_t magic[8] = {'L', 'Z', '4', 'B', 'l', 'o', 'c', 'k'};
+  memcpy(h, magic, 8);
+  h[8] = (uint8_t)token;
+  for (int i = 0; i < 4; i++) {
+    h[9 + i] = (uint8_t)(c >> (8 * i));
+    h[13 + i] = (uint8_t)(o >> (8 * i));
+    h[17 + i] = (uint8_t)(check >> (8 * i));
+  }
+}
+
+static int64_t stream_liblz4(const uint8_t* src, int64_t ulen, int bs, uint8_t* dst) {
+  int level = 0;
+  while ((1 << level) < bs) level++;
+  level = level > 10 ? level - 10 : 0;
+  int64_t op = 0;
+  if (ulen == 0) return 0;
+  for (int64_t pos = 0; pos < ulen; pos += bs) {
+    const int o = (int)(ulen - pos < bs ? ulen - pos : bs);
+    uint8_t* h = dst + op;
+    const uint32_t check = s3o_xxh32(src + pos, (size_t)o, 0x9747b28cu) & 0x0FFFFFFFu;
+    int r = g_lz4((const char*)src + pos, (char*)h + 21, o, o + o / 255 + 16);
+    int method = 0x20;
+    if (r >= o || r <= 0) {
+      memcpy(h + 21, src + pos, (size_t)o);
+      r = o;
+      method = 0x10;
+    }
+    put_header(h, method | level, (uint32_t)r, (uint32_t)o, check);
+    op += 21 + r;
+  }
+  put_header(dst + op, 0x10 | level, 0, 0, 0);
+  return op + 21;
+}
+
+typedef struct {
+  int codec, checksum, block_size, use_liblz4;
+  const uint8_t* src;
+  const int64_t* offs;
+  int32_t nparts;
+  uint8_t* dst;
+  int64_t cap;
+  int64_t* index;
+  int64_t* sums;
+  int64_t total;
+  int rc;
+  int reps;
+} task_t;
+
+static void* run_task(void* arg) {
+  task_t* t = (task_t*)arg;
+  for (int r = 0; r < t->reps; r++) {
+    if (t->use_liblz4 && t->codec == S3O_CODEC_LZ4 && g_lz4) {
+      int64_t op = 0;
+      t->index[0] = 0;
+      for (int32_t p = 0; p < t->nparts; p++) {
+        int64_t u = t->offs[p + 1] - t->offs[p];
+        int64_t w = stream_liblz4(t->src + t->offs[p], u, t->block_size, t->dst + op);
+        if (t->checksum != S3O_CHECKSUM_NONE)
+          t->sums[p] = s3o_checksum(t->checksum, t->dst + op, (size_t)w);
+        op += w;
+        t->index[p + 1] = op;
+      }
+      t->total = op;
+      t->rc = 0;
+    } else {
+      t->rc = s3o_compress_map_output(t->codec, t->checksum, t->block_size, t->src, t->offs,
+                                      t->nparts, t->dst, t->cap, t->index, t->sums, &t->total);
+    }
+  }
+  return NULL;
+}
+
+/* Runs `ntasks` identical-shape map tasks on `nthreads` threads (task i -> thread i %
+ * nthreads is NOT used: exactly one task per thread, ntasks == nthreads), `reps` times
+ * each, and returns wall seconds.  All tasks read the same src (read-only) but write
+ * private outputs.  out_total receives one task's compressed size. */
+double s3o_mt_compress_bench(int codec, int checksum, int block_size, int use_liblz4,
+                             const uint8_t* src, const int64_t* offs, int32_t nparts,
+                             int nthreads, int reps, int64_t* out_total) {
+  if (use_liblz4 && !s3o_mt_have_liblz4()) use_liblz4 = 0;
+  int64_t cap = s3o_max_compressed_size(codec, block_size, offs, nparts);
+  task_t* ts = (task_t*)calloc((size_t)nthreads, sizeof(task_t));
+  pthread_t* th = (pthread_t*)calloc((size_t)nthreads, sizeof(pthread_t));
+  for (int i = 0; i < nthreads; i++) {
+    ts[i] = (task_t){codec, checksum, block_size, use_liblz4, src, offs, nparts,
+                     (uint8_t*)malloc((size_t)cap + 64), cap,
+                     (int64_t*)malloc(sizeof(int64_t) * (size_t)(nparts + 1)),
+                     (int64_t*)malloc(sizeof(int64_t) * (size_t)(nparts + 1)), 0, 0, reps};
+    memset(ts[i].dst, 0, (size_t)cap); /* fault the pages in before timing */
+  }
+  struct timespec a, b;
+  clock_gettime(CLOCK_MONOTONIC, &a);
+  for (int i = 0; i < nthreads; i++) pthread_create(&th[i], NULL, run_task, &ts[i]);
+  for (int i = 0; i < nthreads; i++) pthread_join(th[i], NULL);
+  clock_gettime(CLOCK_MONOTONIC, &b);
+  if (out_total) *out_total = ts[0].total;
+  int rc = 0;
+  for (int i = 0; i < nthreads; i++) {
+    rc |= ts[i].rc;
+    free(ts[i].dst);
+    free(ts[i].index);
+    free(ts[i].sums);
+  }
+  free(ts);
+  free(th);
+  double s = (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
+  return rc ? -1.0 : s;
+}
+
+/* For tests: the liblz4-backed stream must equal the restatement byte for byte. */
+int64_t s3o_mt_stream_liblz4(const uint8_t* src, int64_t ulen, int block_size, uint8_t* dst) {
+  if (!s3o_mt_have_liblz4()) return S3O_E_UNSUPPORTED;
+  return stream_liblz4(src, ulen, block_size, dst);
+}
