@@ -1,0 +1,177 @@
+/*
+ * s3shuffle_codec.h — C-ABI of the MI355X-native shuffle-block codec path.
+ *
+ * This is the drop-in boundary for ONE hot path of IBM/spark-s3-shuffle: the map-side
+ * compress + checksum of a map task's shuffle partitions and the reduce-side verify +
+ * decompress of a fetched block range.  Everything above it (ShuffleManager /
+ * ShuffleDataIO SPI, object-store I/O, lifecycle) stays on the JVM unchanged; a thin JNI
+ * shim binds exactly these entry points.  Plain pointers and sizes only.
+ *
+ * Reference interfaces each entry point replaces (paths relative to the reference repo,
+ * src/main/scala/org/apache/spark/...):
+ *
+ *   s3s_compress_map_output        the [EXT] LZ4BlockOutputStream / SnappyOutputStream +
+ *                                  MutableCheckedOutputStream stage that feeds
+ *                                  shuffle/S3ShuffleMapOutputWriter.scala:168-202
+ *                                  (S3ShuffleOutputStream.write) and whose per-partition
+ *                                  lengths / checksums are persisted by
+ *                                  shuffle/S3ShuffleMapOutputWriter.scala:91-118
+ *                                  (commitAllPartitions) through
+ *                                  shuffle/helper/S3ShuffleHelper.scala:44-59
+ *                                  (writePartitionLengths / writeChecksum); also the
+ *                                  pre-built spill file + lengths + checksums handed to
+ *                                  shuffle/S3SingleSpillShuffleMapOutputWriter.scala:24-64.
+ *   s3s_checksum_ranges            shuffle/helper/S3ShuffleHelper.scala:94-103
+ *                                  (createChecksumAlgorithm) as used by
+ *                                  storage/S3ChecksumValidationStream.scala:54-66.
+ *   s3s_decompress_range           storage/S3ChecksumValidationStream.scala:17-92 (verify)
+ *                                  + the [EXT] serializerManager.wrapStream decompression
+ *                                  at storage/S3ShuffleReader.scala:98-110, over the byte
+ *                                  range storage/S3ShuffleBlockIterator.scala:37-42 /
+ *                                  storage/S3ShuffleBlockStream.scala:36-40 define.
+ *   s3s_decompressed_size          (no reference counterpart: sizing helper for the shim;
+ *                                  the JVM path grows its buffers while streaming)
+ *   s3s_max_compressed_size        (sizing helper; LZ4BlockOutputStream allocates
+ *                                  HEADER_LENGTH + maxCompressedLength(blockSize) per block)
+ *   s3s_create / s3s_destroy       shuffle/helper/S3ShuffleDispatcher.scala:240-255 (the
+ *                                  process-wide lazily built state); the device is chosen
+ *                                  by the caller as mapId % nGPU, mirroring
+ *                                  mapId % folderPrefixes at S3ShuffleDispatcher.scala:142.
+ *
+ * Byte formats produced / consumed (bit-exact with the JVM path):
+ *   LZ4    one lz4-java LZ4BlockOutputStream per non-empty partition: frames of
+ *          "LZ4Block" | token | compressedLen LE | originalLen LE | xxh32&0x0FFFFFFF LE |
+ *          payload (LZ4_compress_default of a block_size chunk, or the raw chunk when that
+ *          is not smaller), then a 21-byte end frame.  Empty partition = 0 bytes.
+ *   SNAPPY one snappy-java SnappyOutputStream per non-empty partition: 16-byte header,
+ *          then compressedLen BE | raw snappy per block_size chunk.
+ *   NONE   the partition bytes unchanged (spark.shuffle.compress=false).
+ *   out_index     cumulative offsets [0, L0, L0+L1, ...] (host-endian int64; the caller
+ *                 serialises big-endian exactly like S3ShuffleHelper.writeArrayAsBlock).
+ *   out_checksums java.util.zip.Adler32 / CRC32 getValue() over each partition's
+ *                 COMPRESSED bytes, i.e. over data[index[p], index[p+1]).
+ *
+ * Threading: an s3s_ctx is NOT thread-safe; use one per task thread.  Calls on distinct
+ * contexts are fully concurrent (each owns its HIP stream and device workspace).
+ * Ownership: the caller owns every buffer passed in; the library owns only the ctx.
+ * Errors: 0 on success, negative S3S_E_* otherwise; never aborts; s3s_last_error() gives
+ * a message.  There is NO CPU fallback: without a usable HIP device s3s_create() fails.
+ */
+#ifndef S3SHUFFLE_CODEC_H
+#define S3SHUFFLE_CODEC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S3S_ABI_VERSION 1
+
+/* spark.io.compression.codec (only when spark.shuffle.compress=true) */
+enum { S3S_CODEC_NONE = 0, S3S_CODEC_LZ4 = 1, S3S_CODEC_SNAPPY = 2 };
+/* spark.shuffle.checksum.algorithm (NONE when spark.shuffle.checksum.enabled=false) */
+enum { S3S_CHECKSUM_NONE = 0, S3S_CHECKSUM_ADLER32 = 1, S3S_CHECKSUM_CRC32 = 2 };
+
+enum {
+  S3S_OK = 0,
+  S3S_E_INVALID = -1,     /* bad argument (RuntimeException("Precondition: ...") on the JVM) */
+  S3S_E_CAPACITY = -2,    /* dst_capacity too small */
+  S3S_E_BAD_FRAME = -3,   /* IOException("Stream is corrupted") */
+  S3S_E_CHECKSUM = -4,    /* SparkException("Invalid checksum detected for ...") */
+  S3S_E_HIP = -5,         /* HIP runtime / device failure */
+  S3S_E_UNSUPPORTED = -6, /* e.g. block size outside the supported range */
+  S3S_E_NOMEM = -7
+};
+
+/* option keys for s3s_set_option / s3s_get_option */
+enum {
+  S3S_OPT_LZ4_BLOCK_SIZE = 1,    /* spark.io.compression.lz4.blockSize, default 32768;
+                                    supported 64..32768 */
+  S3S_OPT_SNAPPY_BLOCK_SIZE = 2, /* spark.io.compression.snappy.blockSize, default 32768;
+                                    supported 1024..32768 (snappy-java raises smaller values
+                                    to 1024) */
+  S3S_OPT_PROFILE = 3            /* 1: record per-stage HIP-event timings (s3s_stage_ms) */
+};
+
+/* stages reported by s3s_stage_ms (valid after a call made with S3S_OPT_PROFILE=1) */
+enum {
+  S3S_STAGE_TOTAL = 0,      /* first kernel start -> last kernel end of the last call */
+  S3S_STAGE_CODEC = 1,      /* the block compress (or decompress) kernel — the dominant one */
+  S3S_STAGE_ASSEMBLE = 2,   /* offset scan + frame gather */
+  S3S_STAGE_CHECKSUM = 3,   /* per-partition Adler32 / CRC32 */
+  S3S_STAGE_DISCOVER = 4,   /* reduce side: frame discovery */
+  S3S_STAGE_COUNT = 5
+};
+
+typedef struct s3s_ctx s3s_ctx;
+
+/* ---- lifecycle ------------------------------------------------------------------------ */
+const char* s3s_version(void);
+int s3s_abi_version(void);
+/* Number of visible HIP devices (0 when there is none; never fails). */
+int s3s_device_count(void);
+/* Creates a context bound to `device_ordinal`; `scratch_bytes` pre-sizes the device
+ * workspace (0 = grow on demand).  Returns NULL on failure (s3s_last_error(NULL) tells why). */
+s3s_ctx* s3s_create(int device_ordinal, int64_t scratch_bytes);
+void s3s_destroy(s3s_ctx* ctx);
+const char* s3s_last_error(const s3s_ctx* ctx);
+int s3s_set_option(s3s_ctx* ctx, int key, int64_t value);
+int64_t s3s_get_option(const s3s_ctx* ctx, int key);
+/* The HIP stream (hipStream_t) the context launches on, for callers that time with events. */
+void* s3s_stream(const s3s_ctx* ctx);
+double s3s_stage_ms(const s3s_ctx* ctx, int stage);
+
+/* ---- sizing ---------------------------------------------------------------------------- */
+/* Upper bound of the .data image for these partition ranges. ctx may be NULL (defaults). */
+int64_t s3s_max_compressed_size(const s3s_ctx* ctx, int codec, const int64_t* src_offsets,
+                                int32_t num_partitions);
+
+/* ---- map side: compress + checksum one map task's output ------------------------------- */
+/* Partition p's serialized (uncompressed) bytes are src[src_offsets[p], src_offsets[p+1]).
+ * Writes the exact .data byte image into dst, out_index[num_partitions+1],
+ * out_checksums[num_partitions] (may be NULL iff checksum_algo == NONE), *out_total.
+ * Host-buffer variant: src/dst are host memory (H2D/D2H inside the call).               */
+int s3s_compress_map_output(s3s_ctx* ctx, int codec, int checksum_algo, const uint8_t* src,
+                            const int64_t* src_offsets, int32_t num_partitions, uint8_t* dst,
+                            int64_t dst_capacity, int64_t* out_index, int64_t* out_checksums,
+                            int64_t* out_total);
+/* Device-buffer variant: src/dst are device memory on ctx's device (offsets/index/checksums
+ * stay host arrays).  This is the form the roofline metric is measured on. */
+int s3s_compress_map_output_device(s3s_ctx* ctx, int codec, int checksum_algo,
+                                   const uint8_t* d_src, const int64_t* src_offsets,
+                                   int32_t num_partitions, uint8_t* d_dst, int64_t dst_capacity,
+                                   int64_t* out_index, int64_t* out_checksums,
+                                   int64_t* out_total);
+
+/* ---- checksum only ---------------------------------------------------------------------- */
+/* out[i] = checksum(data[offsets[i], offsets[i+1])) for i in [0, n). */
+int s3s_checksum_ranges(s3s_ctx* ctx, int checksum_algo, const uint8_t* data,
+                        const int64_t* offsets, int32_t n, int64_t* out);
+int s3s_checksum_ranges_device(s3s_ctx* ctx, int checksum_algo, const uint8_t* d_data,
+                               const int64_t* offsets, int32_t n, int64_t* out);
+
+/* ---- reduce side: verify + decompress one fetched block range --------------------------- */
+/* comp[0, comp_len) holds partitions r0..r1-1 of one map output (a ShuffleBlockId or a
+ * ShuffleBlockBatchId range); part_offsets[nparts+1] are the .index entries relative to the
+ * range start (part_offsets[0] == 0, part_offsets[nparts] == comp_len).  When
+ * checksum_algo != NONE every partition is validated against ref_checksums first
+ * (S3S_E_CHECKSUM, *out_bad_partition = first failing one); then the concatenated codec
+ * streams are decoded into dst (frame hashes verified; S3S_E_BAD_FRAME on corruption). */
+int s3s_decompress_range(s3s_ctx* ctx, int codec, int checksum_algo, const uint8_t* comp,
+                         int64_t comp_len, const int64_t* part_offsets,
+                         const int64_t* ref_checksums, int32_t nparts, uint8_t* dst,
+                         int64_t dst_capacity, int64_t* out_len, int32_t* out_bad_partition);
+int s3s_decompress_range_device(s3s_ctx* ctx, int codec, int checksum_algo,
+                                const uint8_t* d_comp, int64_t comp_len,
+                                const int64_t* part_offsets, const int64_t* ref_checksums,
+                                int32_t nparts, uint8_t* d_dst, int64_t dst_capacity,
+                                int64_t* out_len, int32_t* out_bad_partition);
+/* Decoded size of the codec streams in comp[0, comp_len) (host memory). */
+int s3s_decompressed_size(s3s_ctx* ctx, int codec, const uint8_t* comp, int64_t comp_len,
+                          int64_t* out_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,143 @@
+// assemble.hip — turn per-chunk codec output into the exact .data byte image.
+//
+// The reference writes partitions strictly in ascending order into ONE object and records
+// each partition's byte count (S3ShuffleMapOutputWriter.scala:67-83, :197-201); the index is
+// the running sum with a leading zero (S3ShuffleHelper.scala:44-47).  Here every frame of
+// every partition was produced independently into a fixed-stride slot, so the layout step is
+// an exclusive scan over item sizes followed by a gather:
+//   scan_items    item_off[i] = sum_{j<i} size_j ; index[p] = item_off[first item of p]
+//   gather_items  dst[item_off[i] ...] = header | payload   (payload from the slot, or from the
+//                 uncompressed source for LZ4 frames stored RAW)
+// Both are pure HBM streaming: (compressed bytes) read + written once.
+#include "s3s_internal.h"
+
+namespace s3s {
+namespace {
+
+constexpr int kScanThreads = 1024;
+
+__global__ __launch_bounds__(kScanThreads) void scan_items_kernel(
+    const uint32_t* __restrict__ item_size, int32_t n_items, int64_t* __restrict__ item_off,
+    const int32_t* __restrict__ part_first, int32_t n_parts, int64_t* __restrict__ index) {
+  __shared__ int64_t wave_sum[kScanThreads / kWave];
+  __shared__ int64_t carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  // tiles of kScanThreads items, carried sequentially (n_items is ~1 per 32 KiB of input)
+  for (int32_t tile = 0; tile < n_items; tile += kScanThreads) {
+    const int32_t i = tile + tid;
+    const int64_t x = i < n_items ? (int64_t)(item_size[i] & ~kRawFlag) : 0;
+    int64_t inc = x;  // inclusive scan within the wave
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+      const int64_t y = __shfl_up(inc, d);
+      if (lane >= d) inc += y;
+    }
+    if (lane == kWave - 1) wave_sum[wave] = inc;
+    __syncthreads();
+    int64_t before = carry;
+    for (int wv = 0; wv < wave; wv++) before += wave_sum[wv];
+    if (i < n_items) item_off[i] = before + inc - x;
+    __syncthreads();
+    if (tid == kScanThreads - 1) carry = before + inc;
+    __syncthreads();
+  }
+  if (tid == 0) item_off[n_items] = carry;
+  __syncthreads();
+  // partition index: offset of the partition's first item (== total for trailing empties)
+  for (int32_t p = tid; p <= n_parts; p += kScanThreads) index[p] = item_off[part_first[p]];
+}
+
+constexpr int kGatherThreads = 256;
+
+// n bytes global -> global; 16-byte stores on the destination's alignment.
+__device__ __forceinline__ void copy_bytes(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src,
+                                           int n, int tid) {
+  int head = (int)((16u - (uint32_t)(uintptr_t)dst) & 15u);
+  head = head < n ? head : n;
+  if (tid < head) dst[tid] = src[tid];
+  const int nvec = (n - head) >> 4;
+  uint4* d16 = reinterpret_cast<uint4*>(dst + head);
+  const uint8_t* s = src + head;
+  for (int v = tid; v < nvec; v += kGatherThreads) {
+    uint4 x;
+    __builtin_memcpy(&x, s + 16 * v, 16);  // source alignment is arbitrary
+    d16[v] = x;
+  }
+  const int done = head + 16 * nvec;
+  if (tid < n - done) dst[done + tid] = src[done + tid];
+}
+
+__global__ __launch_bounds__(kGatherThreads) void gather_items_kernel(
+    const uint8_t* __restrict__ src, const Item* __restrict__ items, int32_t n_items,
+    const uint8_t* __restrict__ slots, const uint32_t* __restrict__ item_size,
+    const int64_t* __restrict__ item_off, uint8_t* __restrict__ dst, int64_t dst_capacity,
+    int32_t* __restrict__ status) {
+  const int it = blockIdx.x;
+  if (it >= n_items) return;
+  const Item item = items[it];
+  const uint32_t sz = item_size[it];
+  const int n = (int)(sz & ~kRawFlag);
+  const int64_t off = item_off[it];
+  const int tid = threadIdx.x;
+  if (off + n > dst_capacity) {
+    if (tid == 0) atomicExch(status, S3S_E_CAPACITY);
+    return;
+  }
+  uint8_t* d = dst + off;
+  const int kind = item.kind & 0xff;
+  if (kind == kItemLz4End) {
+    // LZ4BlockOutputStream.finish(): magic | RAW|level | 0 | 0 | 0
+    if (tid < kLz4FrameHeader) {
+      const uint64_t magic = 0x6b636f6c42345a4cull;
+      uint32_t b = 0;
+      if (tid < 8) b = (uint32_t)(magic >> (8 * tid));
+      else if (tid == 8) b = 0x10u | ((uint32_t)(item.kind >> 8) & 0x0Fu);
+      d[tid] = (uint8_t)b;
+    }
+    return;
+  }
+  if (kind == kItemSnappyHeader) {
+    if (tid < kSnappyStreamHeader) {
+      const uint64_t lo = 0x00595050414e5382ull;  // 0x82 'S' 'N' 'A' 'P' 'P' 'Y' 0x00
+      uint32_t b;
+      if (tid < 8) b = (uint32_t)(lo >> (8 * tid));
+      else b = (tid == 11 || tid == 15) ? 1u : 0u;  // version = 1, compatible version = 1 (BE)
+      d[tid] = (uint8_t)b;
+    }
+    return;
+  }
+  const uint8_t* slot = slots + (size_t)item.chunk * kSlotBytes;
+  if (kind == kItemLz4Chunk) {
+    if (sz & kRawFlag) {
+      copy_bytes(d, slot + (kSlotHeader - kLz4FrameHeader), kLz4FrameHeader, tid);
+      copy_bytes(d + kLz4FrameHeader, src + item.src_off, n - kLz4FrameHeader, tid);
+    } else {
+      copy_bytes(d, slot + (kSlotHeader - kLz4FrameHeader), n, tid);
+    }
+  } else {  // kItemSnappyChunk: i32 BE length right-aligned in the slot header, then payload
+    copy_bytes(d, slot + (kSlotHeader - 4), n, tid);
+  }
+}
+
+}  // namespace
+
+void launch_scan_items(const Item*, const uint32_t* d_item_size, int32_t n_items,
+                       int64_t* d_item_off, const int32_t* d_part_first, int32_t n_parts,
+                       int64_t* d_index, hipStream_t st) {
+  hipLaunchKernelGGL(scan_items_kernel, dim3(1), dim3(kScanThreads), 0, st, d_item_size, n_items,
+                     d_item_off, d_part_first, n_parts, d_index);
+}
+
+void launch_gather_items(const uint8_t* d_src, const Item* d_items, int32_t n_items,
+                         const uint8_t* d_slots, const uint32_t* d_item_size,
+                         const int64_t* d_item_off, uint8_t* d_dst, int64_t dst_capacity,
+                         int32_t* d_status, hipStream_t st) {
+  if (n_items <= 0) return;
+  hipLaunchKernelGGL(gather_items_kernel, dim3((unsigned)n_items), dim3(kGatherThreads), 0, st,
+                     d_src, d_items, n_items, d_slots, d_item_size, d_item_off, d_dst,
+                     dst_capacity, d_status);
+}
+
+}  // namespace s3s

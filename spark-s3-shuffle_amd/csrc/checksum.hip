@@ -1,0 +1,271 @@
+// checksum.hip — per-partition Adler32 / CRC32 over byte ranges of the .data image.
+//
+// Replaces java.util.zip.{Adler32,CRC32} as the reference uses them:
+//   write side  [EXT] MutableCheckedOutputStream -> checksums(p) delivered to
+//               S3ShuffleMapOutputWriter.scala:91 / S3SingleSpillShuffleMapOutputWriter.scala:27
+//   read side   S3ShuffleHelper.scala:94-103 (createChecksumAlgorithm) driven by
+//               S3ChecksumValidationStream.scala:54-86 (update per read, compare at the
+//               partition boundary).
+// Both are defined over a partition's COMPRESSED bytes data[index[p], index[p+1]).
+//
+// A sequential checksum becomes a two-level reduction because both functions combine:
+//   Adler32  a = 1 + sum d_j,  b = L + sum d_j * (L - j)      (all mod 65521)
+//   CRC32    crc(X||Y) = crc(X) * x^(8|Y|) mod P  xor  crc(Y)  (zlib crc32_combine identity)
+// Level 1: one workgroup per 16 KiB segment of a range; every thread owns a 64-byte piece,
+//          right-aligned in the segment so each piece's distance to the segment end is a
+//          multiple of 64 (=> the CRC shift operator comes from a 256-entry table).
+// Level 2: one workgroup per range folds its segment partials.
+// Roofline: HBM read of the range bytes, 1 B/B.
+#include "s3s_internal.h"
+
+namespace s3s {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kPiece = 64;
+static_assert(kChecksumSegBytes == kThreads * kPiece, "segment = one piece per thread");
+constexpr uint32_t kAdlerMod = 65521u;
+
+struct Tables {             // built on the host once per context (codec_api.hip)
+  uint32_t slice[4][256];   // CRC-32 slice-by-4 tables (reflected 0xEDB88320)
+  uint32_t pow_piece[256];  // x^(8*64*k) mod P
+  uint32_t x2n[32];         // x^(2^k) mod P
+};
+
+// a(x) * b(x) mod P in the reflected representation (zlib multmodp), branch-free
+__device__ __forceinline__ uint32_t multmodp(uint32_t a, uint32_t b) {
+  uint32_t p = 0;
+#pragma unroll
+  for (int i = 0; i < 32; i++) {
+    p ^= (a & (0x80000000u >> i)) ? b : 0u;
+    b = (b >> 1) ^ (0xEDB88320u & (0u - (b & 1u)));
+  }
+  return p;
+}
+
+// x^(8n) mod P
+__device__ __forceinline__ uint32_t x8n(const uint32_t* x2n, uint64_t n) {
+  uint32_t p = 0x80000000u;
+  for (int k = 3; n; n >>= 1, k++)
+    if (n & 1) p = multmodp(x2n[k & 31], p);
+  return p;
+}
+
+__device__ __forceinline__ uint32_t block_reduce_xor(uint32_t v, uint32_t* scratch) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v ^= __shfl_xor(v, d);
+  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+  __syncthreads();
+  uint32_t r = 0;
+  for (int w = 0; w < kThreads / kWave; w++) r ^= scratch[w];
+  __syncthreads();
+  return r;
+}
+__device__ __forceinline__ uint32_t block_reduce_add(uint32_t v, uint32_t* scratch) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+  __syncthreads();
+  uint32_t r = 0;
+  for (int w = 0; w < kThreads / kWave; w++) r += scratch[w];
+  __syncthreads();
+  return r;
+}
+
+// partial[seg] = { A|crc, B, seg_len, 0 }
+template <int ALGO>
+__global__ __launch_bounds__(kThreads) void checksum_segments_kernel(
+    const uint8_t* __restrict__ data, const int64_t* __restrict__ offsets, int32_t n,
+    const int32_t* __restrict__ seg_start, const Tables* __restrict__ tabs,
+    uint32_t* __restrict__ partial) {
+  __shared__ uint32_t lds_slice[4 * 256];
+  __shared__ uint32_t scratch[kThreads / kWave];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  // which range owns worst-case segment slot b
+  int lo = 0, hi = n;  // seg_start[lo] <= b < seg_start[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (seg_start[mid] <= b) lo = mid; else hi = mid;
+  }
+  const int p = lo;
+  const int s = b - seg_start[p];
+  const int64_t pstart = offsets[p], plen = offsets[p + 1] - pstart;
+  const int64_t soff = (int64_t)s * kChecksumSegBytes;
+  if (soff >= plen) return;  // slot beyond the actual (compressed) length
+  const int seg_len = (int)((plen - soff) < kChecksumSegBytes ? (plen - soff) : kChecksumSegBytes);
+  const uint8_t* g = data + pstart + soff;
+
+  if (ALGO == S3S_CHECKSUM_CRC32) {
+    for (int i = tid; i < 4 * 256; i += kThreads) lds_slice[i] = (&tabs->slice[0][0])[i];
+    __syncthreads();
+  }
+  // pieces are right-aligned: thread t of T owns [seg_len - 64*(T-t), seg_len - 64*(T-1-t))
+  const int T = (seg_len + kPiece - 1) / kPiece;
+  uint32_t v0 = 0, v1 = 0;
+  if (tid < T) {
+    const int end = seg_len - kPiece * (T - 1 - tid);
+    const int beg = end - kPiece > 0 ? end - kPiece : 0;
+    const int pl = end - beg;
+    if (ALGO == S3S_CHECKSUM_ADLER32) {
+      uint32_t s1 = 0, s2 = 0;  // s2 = sum d_k * (pl - k)
+      if (pl == kPiece) {
+        uint4 q[4];
+        __builtin_memcpy(q, g + beg, 64);
+        const uint32_t* wds = reinterpret_cast<const uint32_t*>(q);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+          const uint32_t x = wds[j];
+          const uint32_t b0 = x & 0xff, b1 = (x >> 8) & 0xff, b2 = (x >> 16) & 0xff, b3 = x >> 24;
+          s1 += b0 + b1 + b2 + b3;
+          s2 += b0 * (uint32_t)(64 - 4 * j) + b1 * (uint32_t)(63 - 4 * j) +
+                b2 * (uint32_t)(62 - 4 * j) + b3 * (uint32_t)(61 - 4 * j);
+        }
+      } else {
+        for (int k = 0; k < pl; k++) {
+          const uint32_t d = g[beg + k];
+          s1 += d;
+          s2 += d * (uint32_t)(pl - k);
+        }
+      }
+      const uint32_t after = (uint32_t)(seg_len - end);  // < 16384
+      v0 = s1;                              // <= 16320
+      v1 = (s2 + s1 * after) % kAdlerMod;   // < 2^32 before the mod
+    } else {
+      uint32_t c = 0xFFFFFFFFu;
+      if (pl == kPiece) {
+        uint4 q[4];
+        __builtin_memcpy(q, g + beg, 64);
+        const uint32_t* wds = reinterpret_cast<const uint32_t*>(q);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+          c ^= wds[j];
+          c = lds_slice[768 + (c & 0xff)] ^ lds_slice[512 + ((c >> 8) & 0xff)] ^
+              lds_slice[256 + ((c >> 16) & 0xff)] ^ lds_slice[c >> 24];
+        }
+      } else {
+        for (int k = 0; k < pl; k++) c = lds_slice[(c ^ g[beg + k]) & 0xff] ^ (c >> 8);
+      }
+      c = ~c;
+      v0 = multmodp(tabs->pow_piece[T - 1 - tid], c);  // shift by the bytes after this piece
+    }
+  }
+  uint32_t* out = partial + 4 * (size_t)b;
+  if (ALGO == S3S_CHECKSUM_ADLER32) {
+    const uint32_t A = block_reduce_add(v0, scratch);  // <= 255*16384, no overflow
+    const uint32_t B = block_reduce_add(v1, scratch);  // <= 256*65520
+    if (tid == 0) {
+      out[0] = A % kAdlerMod;
+      out[1] = B % kAdlerMod;
+      out[2] = (uint32_t)seg_len;
+    }
+  } else {
+    const uint32_t c = block_reduce_xor(v0, scratch);
+    if (tid == 0) {
+      out[0] = c;
+      out[2] = (uint32_t)seg_len;
+    }
+  }
+}
+
+template <int ALGO>
+__global__ __launch_bounds__(kThreads) void checksum_combine_kernel(
+    const int64_t* __restrict__ offsets, int32_t n, const int32_t* __restrict__ seg_start,
+    const Tables* __restrict__ tabs, const uint32_t* __restrict__ partial,
+    int64_t* __restrict__ out) {
+  __shared__ uint32_t scratch[kThreads / kWave];
+  __shared__ uint32_t lds_x2n[32];
+  const int p = blockIdx.x, tid = threadIdx.x;
+  if (p >= n) return;
+  const int64_t plen = offsets[p + 1] - offsets[p];
+  const int64_t nseg = (plen + kChecksumSegBytes - 1) / kChecksumSegBytes;
+  const uint32_t* part = partial + 4 * (size_t)seg_start[p];
+  if (ALGO == S3S_CHECKSUM_ADLER32) {
+    uint32_t sa = 0, sb = 0;
+    for (int64_t s = tid; s < nseg; s += kThreads) {
+      const uint32_t A = part[4 * s], B = part[4 * s + 1], len = part[4 * s + 2];
+      const int64_t after = plen - (s * kChecksumSegBytes + len);
+      sa = (sa + A) % kAdlerMod;
+      sb = (uint32_t)((sb + B + (uint64_t)A * (uint64_t)(after % kAdlerMod)) % kAdlerMod);
+    }
+    const uint32_t a = block_reduce_add(sa, scratch);
+    const uint32_t b = block_reduce_add(sb, scratch);
+    if (tid == 0) {
+      const uint32_t fa = (1u + a) % kAdlerMod;
+      const uint32_t fb = (uint32_t)(((uint64_t)(plen % kAdlerMod) + b) % kAdlerMod);
+      out[p] = (int64_t)(((uint64_t)fb << 16) | fa);
+    }
+  } else {
+    if (tid < 32) lds_x2n[tid] = tabs->x2n[tid];
+    __syncthreads();
+    // thread j folds a contiguous run of segments Horner-style, then shifts the run to the end
+    const int64_t run = (nseg + kThreads - 1) / kThreads;
+    const int64_t s0 = (int64_t)tid * run, s1 = (s0 + run) < nseg ? (s0 + run) : nseg;
+    uint32_t c = 0;
+    int64_t end = 0;
+    if (s0 < s1) {
+      const uint32_t xseg = x8n(lds_x2n, kChecksumSegBytes);
+      for (int64_t s = s0; s < s1; s++) {
+        const uint32_t len = part[4 * s + 2];
+        c = multmodp(c, len == (uint32_t)kChecksumSegBytes ? xseg : x8n(lds_x2n, len)) ^ part[4 * s];
+        end = s * kChecksumSegBytes + len;
+      }
+      c = multmodp(c, x8n(lds_x2n, (uint64_t)(plen - end)));
+    }
+    const uint32_t r = block_reduce_xor(c, scratch);
+    if (tid == 0) out[p] = (int64_t)(uint64_t)r;
+  }
+}
+
+}  // namespace
+
+size_t checksum_tables_bytes() { return sizeof(Tables); }
+
+// host-side construction of the constant tables (uploaded once per context)
+void checksum_tables_build(void* host_buf) {
+  Tables* t = static_cast<Tables*>(host_buf);
+  for (uint32_t i = 0; i < 256; i++) {
+    uint32_t c = i;
+    for (int k = 0; k < 8; k++) c = (c & 1) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
+    t->slice[0][i] = c;
+  }
+  for (uint32_t i = 0; i < 256; i++)
+    for (int s = 1; s < 4; s++)
+      t->slice[s][i] = (t->slice[s - 1][i] >> 8) ^ t->slice[0][t->slice[s - 1][i] & 0xff];
+  auto mul = [](uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+    for (int i = 0; i < 32; i++) {
+      if (a & (0x80000000u >> i)) p ^= b;
+      b = (b >> 1) ^ (0xEDB88320u & (0u - (b & 1u)));
+    }
+    return p;
+  };
+  t->x2n[0] = 0x40000000u;  // x^1
+  for (int k = 1; k < 32; k++) t->x2n[k] = mul(t->x2n[k - 1], t->x2n[k - 1]);
+  // x^(8*64) = x^(2^9)
+  const uint32_t xp = t->x2n[9];
+  t->pow_piece[0] = 0x80000000u;  // 1
+  for (int k = 1; k < 256; k++) t->pow_piece[k] = mul(t->pow_piece[k - 1], xp);
+}
+
+void launch_checksum_with_tables(int algo, const uint8_t* d_data, const int64_t* d_offsets,
+                                 int32_t n, const int32_t* d_seg_start, int32_t total_segs,
+                                 const void* d_tables, uint32_t* d_partial, int64_t* d_out,
+                                 hipStream_t st) {
+  if (n <= 0) return;
+  const Tables* tabs = static_cast<const Tables*>(d_tables);
+  if (algo == S3S_CHECKSUM_ADLER32) {
+    if (total_segs > 0)
+      hipLaunchKernelGGL(checksum_segments_kernel<S3S_CHECKSUM_ADLER32>, dim3((unsigned)total_segs),
+                         dim3(kThreads), 0, st, d_data, d_offsets, n, d_seg_start, tabs, d_partial);
+    hipLaunchKernelGGL(checksum_combine_kernel<S3S_CHECKSUM_ADLER32>, dim3((unsigned)n),
+                       dim3(kThreads), 0, st, d_offsets, n, d_seg_start, tabs, d_partial, d_out);
+  } else {
+    if (total_segs > 0)
+      hipLaunchKernelGGL(checksum_segments_kernel<S3S_CHECKSUM_CRC32>, dim3((unsigned)total_segs),
+                         dim3(kThreads), 0, st, d_data, d_offsets, n, d_seg_start, tabs, d_partial);
+    hipLaunchKernelGGL(checksum_combine_kernel<S3S_CHECKSUM_CRC32>, dim3((unsigned)n),
+                       dim3(kThreads), 0, st, d_offsets, n, d_seg_start, tabs, d_partial, d_out);
+  }
+}
+
+}  // namespace s3s

@@ -1,0 +1,533 @@
+// codec_api.hip — the C-ABI of include/s3shuffle_codec.h: context, planning, orchestration.
+//
+// One s3s_ctx = one HIP stream + one growable device workspace + one pinned staging area, used
+// by exactly one task thread (the reference creates one writer object per map task used by one
+// task thread, S3ShuffleDataIO.scala:34-43).  Every call enqueues its kernels on the context's
+// stream and synchronises once at the end to hand index / checksums back to the caller.
+//
+// There is NO CPU fallback anywhere in this file: without a HIP device s3s_create() fails and
+// every entry point needs a context.
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "s3s_internal.h"
+
+using namespace s3s;
+
+namespace {
+
+thread_local char g_create_error[512] = "";
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+enum BufId {
+  B_ITEMS, B_PART_FIRST, B_SLOTS, B_ITEM_SIZE, B_ITEM_OFF, B_INDEX, B_SUMS, B_SEG_START,
+  B_PARTIAL, B_STATUS, B_TABLES, B_SRC, B_DST, B_OFFSETS, B_FRAMES, B_PART_NFRAMES,
+  B_FRAME_OUT, B_REF_SUMS, B_COUNT
+};
+
+}  // namespace
+
+struct s3s_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  char err[512] = "";
+  int64_t lz4_block = 32768;
+  int64_t snappy_block = 32768;
+  int profile = 0;
+  DevBuf buf[B_COUNT];
+  void* h_stage = nullptr;  // pinned
+  size_t h_stage_cap = 0;
+  hipEvent_t ev[S3S_STAGE_COUNT + 1] = {};
+  double stage_ms[S3S_STAGE_COUNT] = {};
+};
+
+namespace {
+
+int fail(s3s_ctx* ctx, int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  if (ctx) vsnprintf(ctx->err, sizeof ctx->err, fmt, ap);
+  else vsnprintf(g_create_error, sizeof g_create_error, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                  \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(ctx, S3S_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),    \
+                  __FILE__, __LINE__);                                                      \
+  } while (0)
+
+int ensure(s3s_ctx* ctx, BufId id, size_t bytes) {
+  DevBuf& b = ctx->buf[id];
+  if (bytes <= b.cap) return S3S_OK;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (b.p) HIP_TRY(ctx, hipFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+  size_t want = bytes + bytes / 4 + 4096;
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) {
+    want = bytes;
+    e = hipMalloc(&b.p, want);
+  }
+  if (e != hipSuccess) return fail(ctx, S3S_E_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+  b.cap = want;
+  return S3S_OK;
+}
+
+int ensure_stage(s3s_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->h_stage_cap) return S3S_OK;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->h_stage) HIP_TRY(ctx, hipHostFree(ctx->h_stage));
+  ctx->h_stage = nullptr;
+  ctx->h_stage_cap = 0;
+  const size_t want = bytes + bytes / 4 + 4096;
+  HIP_TRY(ctx, hipHostMalloc(&ctx->h_stage, want, hipHostMallocDefault));
+  ctx->h_stage_cap = want;
+  return S3S_OK;
+}
+
+template <typename T>
+T* dev(s3s_ctx* ctx, BufId id) {
+  return static_cast<T*>(ctx->buf[id].p);
+}
+
+int lz4_level(int64_t block_size) {
+  int level = 0;
+  while ((1ll << level) < block_size) level++;
+  level -= 10;
+  return level < 0 ? 0 : level;
+}
+
+int64_t snappy_max_len(int64_t n) { return 32 + n + n / 6; }
+
+int64_t effective_block(const s3s_ctx* ctx, int codec) {
+  if (codec == S3S_CODEC_LZ4) return ctx ? ctx->lz4_block : 32768;
+  if (codec == S3S_CODEC_SNAPPY) {
+    const int64_t b = ctx ? ctx->snappy_block : 32768;
+    return b < 1024 ? 1024 : b;  // snappy-java: Math.max(MIN_BLOCK_SIZE, blockSize)
+  }
+  return 0;
+}
+
+int64_t max_partition_size(int codec, int64_t bs, int64_t u) {
+  if (u <= 0) return 0;
+  switch (codec) {
+    case S3S_CODEC_NONE:
+      return u;
+    case S3S_CODEC_LZ4: {
+      const int64_t chunks = (u + bs - 1) / bs;
+      return u + chunks * kLz4FrameHeader + kLz4FrameHeader;  // RAW fallback caps the payload
+    }
+    case S3S_CODEC_SNAPPY: {
+      const int64_t full = u / bs, rem = u % bs;
+      return kSnappyStreamHeader + full * (4 + snappy_max_len(bs)) + (rem ? 4 + snappy_max_len(rem) : 0);
+    }
+  }
+  return -1;
+}
+
+void record(s3s_ctx* ctx, int slot) {
+  if (ctx->profile) hipEventRecord(ctx->ev[slot], ctx->stream);
+}
+
+// worst-case 16 KiB checksum segments of a range that is at most `bytes` long
+int32_t worst_segs(int64_t bytes) { return (int32_t)((bytes + kChecksumSegBytes - 1) / kChecksumSegBytes); }
+
+int run_checksum(s3s_ctx* ctx, int algo, const uint8_t* d_data, const int64_t* d_offsets,
+                 int32_t n, const int32_t* h_seg_start /* n+1, in pinned stage */,
+                 int64_t* d_out) {
+  const int32_t total = h_seg_start[n];
+  int rc;
+  if ((rc = ensure(ctx, B_SEG_START, sizeof(int32_t) * (size_t)(n + 1)))) return rc;
+  if ((rc = ensure(ctx, B_PARTIAL, sizeof(uint32_t) * 4 * (size_t)(total > 0 ? total : 1)))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(dev<int32_t>(ctx, B_SEG_START), h_seg_start,
+                              sizeof(int32_t) * (size_t)(n + 1), hipMemcpyHostToDevice, ctx->stream));
+  launch_checksum_with_tables(algo, d_data, d_offsets, n, dev<int32_t>(ctx, B_SEG_START), total,
+                              ctx->buf[B_TABLES].p, dev<uint32_t>(ctx, B_PARTIAL), d_out,
+                              ctx->stream);
+  HIP_TRY(ctx, hipGetLastError());
+  return S3S_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* s3s_version(void) { return "s3shuffle-codec-mi355x 0.1.0 (gfx950)"; }
+int s3s_abi_version(void) { return S3S_ABI_VERSION; }
+
+int s3s_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+s3s_ctx* s3s_create(int device_ordinal, int64_t scratch_bytes) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    fail(nullptr, S3S_E_HIP, "no HIP device available (%s); this library has no CPU fallback",
+         e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    return nullptr;
+  }
+  if (device_ordinal < 0 || device_ordinal >= n) {
+    fail(nullptr, S3S_E_INVALID, "device ordinal %d out of range [0,%d)", device_ordinal, n);
+    return nullptr;
+  }
+  s3s_ctx* ctx = new s3s_ctx();
+  ctx->device = device_ordinal;
+  auto bail = [&](const char* what, hipError_t err) -> s3s_ctx* {
+    fail(nullptr, S3S_E_HIP, "%s failed: %s", what, hipGetErrorString(err));
+    delete ctx;
+    return nullptr;
+  };
+  if ((e = hipSetDevice(device_ordinal)) != hipSuccess) return bail("hipSetDevice", e);
+  if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
+    return bail("hipStreamCreate", e);
+  for (auto& ev : ctx->ev)
+    if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+  // constant tables for the checksum kernels
+  const size_t tb = checksum_tables_bytes();
+  std::vector<uint8_t> host_tabs(tb);
+  checksum_tables_build(host_tabs.data());
+  if (ensure(ctx, B_TABLES, tb) != S3S_OK ||
+      hipMemcpy(ctx->buf[B_TABLES].p, host_tabs.data(), tb, hipMemcpyHostToDevice) != hipSuccess) {
+    fail(nullptr, S3S_E_HIP, "table upload failed: %s", ctx->err);
+    s3s_destroy(ctx);
+    return nullptr;
+  }
+  if (scratch_bytes > 0) (void)ensure(ctx, B_SLOTS, (size_t)scratch_bytes);
+  return ctx;
+}
+
+void s3s_destroy(s3s_ctx* ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  if (ctx->stream) hipStreamSynchronize(ctx->stream);
+  for (auto& b : ctx->buf)
+    if (b.p) hipFree(b.p);
+  if (ctx->h_stage) hipHostFree(ctx->h_stage);
+  for (auto& ev : ctx->ev)
+    if (ev) hipEventDestroy(ev);
+  if (ctx->stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* s3s_last_error(const s3s_ctx* ctx) { return ctx ? ctx->err : g_create_error; }
+
+int s3s_set_option(s3s_ctx* ctx, int key, int64_t value) {
+  if (!ctx) return S3S_E_INVALID;
+  switch (key) {
+    case S3S_OPT_LZ4_BLOCK_SIZE:
+      // LZ4BlockOutputStream accepts 64 .. 32 MiB; the LDS-resident kernel takes <= 32 KiB
+      if (value < 64) return fail(ctx, S3S_E_INVALID, "lz4 blockSize must be >= 64, got %lld", (long long)value);
+      if (value > kMaxBlock)
+        return fail(ctx, S3S_E_UNSUPPORTED, "lz4 blockSize %lld > %d not supported", (long long)value, kMaxBlock);
+      ctx->lz4_block = value;
+      return S3S_OK;
+    case S3S_OPT_SNAPPY_BLOCK_SIZE:
+      if (value <= 0) return fail(ctx, S3S_E_INVALID, "snappy blockSize must be > 0");
+      if (value > kMaxBlock)
+        return fail(ctx, S3S_E_UNSUPPORTED, "snappy blockSize %lld > %d not supported", (long long)value, kMaxBlock);
+      ctx->snappy_block = value;
+      return S3S_OK;
+    case S3S_OPT_PROFILE:
+      ctx->profile = value != 0;
+      return S3S_OK;
+  }
+  return fail(ctx, S3S_E_INVALID, "unknown option %d", key);
+}
+
+int64_t s3s_get_option(const s3s_ctx* ctx, int key) {
+  if (!ctx) return S3S_E_INVALID;
+  switch (key) {
+    case S3S_OPT_LZ4_BLOCK_SIZE: return ctx->lz4_block;
+    case S3S_OPT_SNAPPY_BLOCK_SIZE: return ctx->snappy_block;
+    case S3S_OPT_PROFILE: return ctx->profile;
+  }
+  return S3S_E_INVALID;
+}
+
+void* s3s_stream(const s3s_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+double s3s_stage_ms(const s3s_ctx* ctx, int stage) {
+  if (!ctx || stage < 0 || stage >= S3S_STAGE_COUNT) return -1.0;
+  return ctx->stage_ms[stage];
+}
+
+int64_t s3s_max_compressed_size(const s3s_ctx* ctx, int codec, const int64_t* src_offsets,
+                                int32_t n) {
+  if (!src_offsets || n < 0) return S3S_E_INVALID;
+  if (codec != S3S_CODEC_NONE && codec != S3S_CODEC_LZ4 && codec != S3S_CODEC_SNAPPY) return S3S_E_INVALID;
+  const int64_t bs = effective_block(ctx, codec);
+  int64_t total = 0;
+  for (int32_t p = 0; p < n; p++) {
+    const int64_t u = src_offsets[p + 1] - src_offsets[p];
+    if (u < 0) return S3S_E_INVALID;
+    total += max_partition_size(codec, bs, u);
+  }
+  return total;
+}
+
+int s3s_compress_map_output_device(s3s_ctx* ctx, int codec, int checksum_algo,
+                                   const uint8_t* d_src, const int64_t* src_offsets, int32_t n,
+                                   uint8_t* d_dst, int64_t dst_capacity, int64_t* out_index,
+                                   int64_t* out_checksums, int64_t* out_total) {
+  if (!ctx) return S3S_E_INVALID;
+  ctx->err[0] = 0;
+  if (n < 0 || !src_offsets || !out_index) return fail(ctx, S3S_E_INVALID, "null offsets/index or negative partition count");
+  if (codec != S3S_CODEC_NONE && codec != S3S_CODEC_LZ4 && codec != S3S_CODEC_SNAPPY)
+    return fail(ctx, S3S_E_INVALID, "unknown codec %d", codec);
+  if (checksum_algo != S3S_CHECKSUM_NONE && checksum_algo != S3S_CHECKSUM_ADLER32 &&
+      checksum_algo != S3S_CHECKSUM_CRC32)
+    return fail(ctx, S3S_E_INVALID, "unknown checksum algorithm %d", checksum_algo);
+  if (checksum_algo != S3S_CHECKSUM_NONE && !out_checksums)
+    return fail(ctx, S3S_E_INVALID, "out_checksums is null but a checksum algorithm is selected");
+  for (int32_t p = 0; p < n; p++)
+    if (src_offsets[p + 1] < src_offsets[p]) return fail(ctx, S3S_E_INVALID, "src_offsets not monotonic at %d", p);
+  if (dst_capacity < 0) return fail(ctx, S3S_E_INVALID, "negative dst_capacity");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+  const int64_t bs = effective_block(ctx, codec);
+  const int64_t total_u = n > 0 ? src_offsets[n] - src_offsets[0] : 0;
+  if ((total_u > 0 && !d_src) || (!d_dst && dst_capacity > 0)) return fail(ctx, S3S_E_INVALID, "null data pointer");
+  const int level = codec == S3S_CODEC_LZ4 ? lz4_level(bs) : 0;
+
+  // ---- plan (host): items in .data order, first item per partition, checksum segment slots ---
+  int64_t n_items64 = 0, n_chunks64 = 0;
+  if (codec != S3S_CODEC_NONE) {
+    for (int32_t p = 0; p < n; p++) {
+      const int64_t u = src_offsets[p + 1] - src_offsets[p];
+      if (u > 0) {
+        const int64_t ch = (u + bs - 1) / bs;
+        n_chunks64 += ch;
+        n_items64 += ch + 1;  // + LZ4 end frame / snappy stream header
+      }
+    }
+  }
+  if (n_items64 > 0x7fffff00ll) return fail(ctx, S3S_E_UNSUPPORTED, "too many codec blocks in one call");
+  const int32_t n_items = (int32_t)n_items64, n_chunks = (int32_t)n_chunks64;
+
+  const size_t items_bytes = sizeof(Item) * (size_t)n_items;
+  const size_t pf_bytes = sizeof(int32_t) * (size_t)(n + 1);
+  const size_t seg_bytes = sizeof(int32_t) * (size_t)(n + 1);
+  const size_t idx_bytes = sizeof(int64_t) * (size_t)(n + 1);
+  const size_t sums_bytes = sizeof(int64_t) * (size_t)(n > 0 ? n : 1);
+  // pinned staging layout: [items][part_first][seg_start][index out][sums out][status out]
+  size_t o_items = 0, o_pf = (o_items + items_bytes + 15) & ~size_t(15),
+         o_seg = (o_pf + pf_bytes + 15) & ~size_t(15), o_idx = (o_seg + seg_bytes + 15) & ~size_t(15),
+         o_sums = (o_idx + idx_bytes + 15) & ~size_t(15), o_status = (o_sums + sums_bytes + 15) & ~size_t(15),
+         stage_total = o_status + 16;
+  int rc;
+  if ((rc = ensure_stage(ctx, stage_total))) return rc;
+  uint8_t* hs = static_cast<uint8_t*>(ctx->h_stage);
+  Item* h_items = reinterpret_cast<Item*>(hs + o_items);
+  int32_t* h_pf = reinterpret_cast<int32_t*>(hs + o_pf);
+  int32_t* h_seg = reinterpret_cast<int32_t*>(hs + o_seg);
+  int64_t* h_idx = reinterpret_cast<int64_t*>(hs + o_idx);
+  int64_t* h_sums = reinterpret_cast<int64_t*>(hs + o_sums);
+  int32_t* h_status = reinterpret_cast<int32_t*>(hs + o_status);
+
+  {
+    int32_t it = 0, ch = 0, seg = 0;
+    const int64_t base = n > 0 ? src_offsets[0] : 0;
+    (void)base;
+    for (int32_t p = 0; p < n; p++) {
+      const int64_t u = src_offsets[p + 1] - src_offsets[p];
+      h_pf[p] = it;
+      h_seg[p] = seg;
+      seg += worst_segs(max_partition_size(codec, bs, u));
+      if (codec == S3S_CODEC_NONE || u <= 0) continue;
+      if (codec == S3S_CODEC_SNAPPY) h_items[it++] = Item{0, 0, kItemSnappyHeader, -1, p};
+      for (int64_t pos = 0; pos < u; pos += bs) {
+        const int32_t len = (int32_t)((u - pos) < bs ? (u - pos) : bs);
+        const int32_t kind = codec == S3S_CODEC_LZ4 ? (kItemLz4Chunk | (level << 8)) : kItemSnappyChunk;
+        h_items[it++] = Item{src_offsets[p] + pos, len, kind, ch++, p};
+      }
+      if (codec == S3S_CODEC_LZ4) h_items[it++] = Item{0, 0, kItemLz4End | (level << 8), -1, p};
+    }
+    h_pf[n] = it;
+    h_seg[n] = seg;
+  }
+
+  if ((rc = ensure(ctx, B_INDEX, idx_bytes))) return rc;
+  if ((rc = ensure(ctx, B_SUMS, sums_bytes))) return rc;
+  if ((rc = ensure(ctx, B_STATUS, 16))) return rc;
+  HIP_TRY(ctx, hipMemsetAsync(ctx->buf[B_STATUS].p, 0, 16, ctx->stream));
+  record(ctx, 0);
+
+  if (codec == S3S_CODEC_NONE) {
+    // spark.shuffle.compress=false: the partition bytes are the stream
+    if (total_u > dst_capacity) return fail(ctx, S3S_E_CAPACITY, "dst_capacity %lld < %lld", (long long)dst_capacity, (long long)total_u);
+    if (total_u > 0)
+      HIP_TRY(ctx, hipMemcpyAsync(d_dst, d_src + src_offsets[0], (size_t)total_u, hipMemcpyDeviceToDevice, ctx->stream));
+    for (int32_t p = 0; p <= n; p++) h_idx[p] = n > 0 ? src_offsets[p] - src_offsets[0] : 0;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_INDEX].p, h_idx, idx_bytes, hipMemcpyHostToDevice, ctx->stream));
+    record(ctx, 1);
+    record(ctx, 2);
+  } else {
+    if ((rc = ensure(ctx, B_ITEMS, items_bytes + 16))) return rc;
+    if ((rc = ensure(ctx, B_PART_FIRST, pf_bytes))) return rc;
+    if ((rc = ensure(ctx, B_SLOTS, (size_t)kSlotBytes * (size_t)(n_chunks > 0 ? n_chunks : 1)))) return rc;
+    if ((rc = ensure(ctx, B_ITEM_SIZE, sizeof(uint32_t) * (size_t)(n_items + 1)))) return rc;
+    if ((rc = ensure(ctx, B_ITEM_OFF, sizeof(int64_t) * (size_t)(n_items + 1)))) return rc;
+    if (n_items > 0)
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_ITEMS].p, h_items, items_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_PART_FIRST].p, h_pf, pf_bytes, hipMemcpyHostToDevice, ctx->stream));
+    // the snappy stream header has a constant size; seed item_size for every item kind the
+    // codec kernel does not write
+    if (codec == S3S_CODEC_LZ4)
+      launch_lz4_compress(d_src, dev<Item>(ctx, B_ITEMS), n_items, dev<uint8_t>(ctx, B_SLOTS),
+                          dev<uint32_t>(ctx, B_ITEM_SIZE), ctx->stream);
+    else
+      launch_snappy_compress(d_src, dev<Item>(ctx, B_ITEMS), n_items, dev<uint8_t>(ctx, B_SLOTS),
+                             dev<uint32_t>(ctx, B_ITEM_SIZE), ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    record(ctx, 1);
+    launch_scan_items(dev<Item>(ctx, B_ITEMS), dev<uint32_t>(ctx, B_ITEM_SIZE), n_items,
+                      dev<int64_t>(ctx, B_ITEM_OFF), dev<int32_t>(ctx, B_PART_FIRST), n,
+                      dev<int64_t>(ctx, B_INDEX), ctx->stream);
+    launch_gather_items(d_src, dev<Item>(ctx, B_ITEMS), n_items, dev<uint8_t>(ctx, B_SLOTS),
+                        dev<uint32_t>(ctx, B_ITEM_SIZE), dev<int64_t>(ctx, B_ITEM_OFF), d_dst,
+                        dst_capacity, dev<int32_t>(ctx, B_STATUS), ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    record(ctx, 2);
+  }
+  if (checksum_algo != S3S_CHECKSUM_NONE && n > 0) {
+    if ((rc = run_checksum(ctx, checksum_algo, d_dst, dev<int64_t>(ctx, B_INDEX), n, h_seg,
+                           dev<int64_t>(ctx, B_SUMS))))
+      return rc;
+  }
+  record(ctx, 3);
+  HIP_TRY(ctx, hipMemcpyAsync(h_idx, ctx->buf[B_INDEX].p, idx_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  if (checksum_algo != S3S_CHECKSUM_NONE && n > 0)
+    HIP_TRY(ctx, hipMemcpyAsync(h_sums, ctx->buf[B_SUMS].p, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(h_status, ctx->buf[B_STATUS].p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->profile) {
+    float ms = 0;
+    hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]); ctx->stage_ms[S3S_STAGE_TOTAL] = ms;
+    hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); ctx->stage_ms[S3S_STAGE_CODEC] = ms;
+    hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]); ctx->stage_ms[S3S_STAGE_ASSEMBLE] = ms;
+    hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); ctx->stage_ms[S3S_STAGE_CHECKSUM] = ms;
+    ctx->stage_ms[S3S_STAGE_DISCOVER] = 0;
+  }
+  memcpy(out_index, h_idx, idx_bytes);
+  if (out_total) *out_total = h_idx[n];
+  if (*h_status != 0 || h_idx[n] > dst_capacity)
+    return fail(ctx, S3S_E_CAPACITY, "dst_capacity %lld too small for %lld output bytes",
+                (long long)dst_capacity, (long long)h_idx[n]);
+  if (checksum_algo != S3S_CHECKSUM_NONE && n > 0) memcpy(out_checksums, h_sums, sizeof(int64_t) * (size_t)n);
+  return S3S_OK;
+}
+
+int s3s_compress_map_output(s3s_ctx* ctx, int codec, int checksum_algo, const uint8_t* src,
+                            const int64_t* src_offsets, int32_t n, uint8_t* dst,
+                            int64_t dst_capacity, int64_t* out_index, int64_t* out_checksums,
+                            int64_t* out_total) {
+  if (!ctx) return S3S_E_INVALID;
+  ctx->err[0] = 0;
+  if (n < 0 || !src_offsets) return fail(ctx, S3S_E_INVALID, "null offsets or negative partition count");
+  for (int32_t p = 0; p < n; p++)
+    if (src_offsets[p + 1] < src_offsets[p]) return fail(ctx, S3S_E_INVALID, "src_offsets not monotonic at %d", p);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int64_t first = n > 0 ? src_offsets[0] : 0;
+  const int64_t total_u = n > 0 ? src_offsets[n] - first : 0;
+  const int64_t bound = s3s_max_compressed_size(ctx, codec, src_offsets, n);
+  if (bound < 0) return fail(ctx, S3S_E_INVALID, "invalid codec or offsets");
+  if ((total_u > 0 && !src) || (dst_capacity > 0 && !dst) || dst_capacity < 0) return fail(ctx, S3S_E_INVALID, "null/invalid host buffer");
+  const int64_t dcap = dst_capacity < bound ? dst_capacity : bound;
+  int rc;
+  if ((rc = ensure(ctx, B_SRC, (size_t)total_u + 64))) return rc;
+  if ((rc = ensure(ctx, B_DST, (size_t)dcap + 64))) return rc;
+  if (total_u > 0)
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_SRC].p, src + first, (size_t)total_u, hipMemcpyHostToDevice, ctx->stream));
+  // rebase the offsets so partition 0 starts at device offset 0
+  std::vector<int64_t> rebased((size_t)n + 1);
+  for (int32_t p = 0; p <= n; p++) rebased[(size_t)p] = src_offsets[p] - first;
+  int64_t total = 0;
+  rc = s3s_compress_map_output_device(ctx, codec, checksum_algo, dev<uint8_t>(ctx, B_SRC), rebased.data(), n,
+                                      dev<uint8_t>(ctx, B_DST), dcap, out_index, out_checksums, &total);
+  if (out_total) *out_total = total;
+  if (rc != S3S_OK) return rc;
+  if (total > 0) HIP_TRY(ctx, hipMemcpy(dst, ctx->buf[B_DST].p, (size_t)total, hipMemcpyDeviceToHost));
+  return S3S_OK;
+}
+
+int s3s_checksum_ranges_device(s3s_ctx* ctx, int algo, const uint8_t* d_data,
+                               const int64_t* offsets, int32_t n, int64_t* out) {
+  if (!ctx) return S3S_E_INVALID;
+  ctx->err[0] = 0;
+  if (n < 0 || !offsets || (n > 0 && !out)) return fail(ctx, S3S_E_INVALID, "null offsets/out or negative count");
+  if (algo != S3S_CHECKSUM_ADLER32 && algo != S3S_CHECKSUM_CRC32)
+    return fail(ctx, S3S_E_INVALID, "Unsupported shuffle checksum algorithm: %d", algo);
+  if (n == 0) return S3S_OK;
+  for (int32_t p = 0; p < n; p++)
+    if (offsets[p + 1] < offsets[p]) return fail(ctx, S3S_E_INVALID, "offsets not monotonic at %d", p);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t off_bytes = sizeof(int64_t) * (size_t)(n + 1), seg_bytes = sizeof(int32_t) * (size_t)(n + 1);
+  const size_t o_seg = (off_bytes + 15) & ~size_t(15), o_out = (o_seg + seg_bytes + 15) & ~size_t(15);
+  int rc;
+  if ((rc = ensure_stage(ctx, o_out + sizeof(int64_t) * (size_t)n))) return rc;
+  uint8_t* hs = static_cast<uint8_t*>(ctx->h_stage);
+  int64_t* h_off = reinterpret_cast<int64_t*>(hs);
+  int32_t* h_seg = reinterpret_cast<int32_t*>(hs + o_seg);
+  int64_t* h_out = reinterpret_cast<int64_t*>(hs + o_out);
+  int64_t segs = 0;
+  for (int32_t p = 0; p < n; p++) {
+    h_off[p] = offsets[p];
+    h_seg[p] = (int32_t)segs;
+    segs += worst_segs(offsets[p + 1] - offsets[p]);
+    if (segs > 0x7fffff00ll) return fail(ctx, S3S_E_UNSUPPORTED, "range too large for one call");
+  }
+  h_off[n] = offsets[n];
+  h_seg[n] = (int32_t)segs;
+  if ((rc = ensure(ctx, B_OFFSETS, off_bytes))) return rc;
+  if ((rc = ensure(ctx, B_SUMS, sizeof(int64_t) * (size_t)n))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_OFFSETS].p, h_off, off_bytes, hipMemcpyHostToDevice, ctx->stream));
+  record(ctx, 0);
+  if ((rc = run_checksum(ctx, algo, d_data, dev<int64_t>(ctx, B_OFFSETS), n, h_seg, dev<int64_t>(ctx, B_SUMS)))) return rc;
+  record(ctx, 3);
+  HIP_TRY(ctx, hipMemcpyAsync(h_out, ctx->buf[B_SUMS].p, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->profile) {
+    float ms = 0;
+    hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]);
+    for (auto& v : ctx->stage_ms) v = 0;
+    ctx->stage_ms[S3S_STAGE_TOTAL] = ctx->stage_ms[S3S_STAGE_CHECKSUM] = ms;
+  }
+  memcpy(out, h_out, sizeof(int64_t) * (size_t)n);
+  return S3S_OK;
+}
+
+int s3s_checksum_ranges(s3s_ctx* ctx, int algo, const uint8_t* data, const int64_t* offsets,
+                        int32_t n, int64_t* out) {
+  if (!ctx) return S3S_E_INVALID;
+  ctx->err[0] = 0;
+  if (n < 0 || !offsets) return fail(ctx, S3S_E_INVALID, "null offsets or negative count");
+  if (n == 0) return S3S_OK;
+  const int64_t first = offsets[0], total = offsets[n] - first;
+  if (total < 0 || (total > 0 && !data)) return fail(ctx, S3S_E_INVALID, "invalid range");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure(ctx, B_SRC, (size_t)total + 64))) return rc;
+  if (total > 0)
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_SRC].p, data + first, (size_t)total, hipMemcpyHostToDevice, ctx->stream));
+  std::vector<int64_t> rebased((size_t)n + 1);
+  for (int32_t p = 0; p <= n; p++) rebased[(size_t)p] = offsets[p] - first;
+  return s3s_checksum_ranges_device(ctx, algo, dev<uint8_t>(ctx, B_SRC), rebased.data(), n, out);
+}
+
+}  // extern "C"

@@ -1,0 +1,112 @@
+// s3s_internal.h — shared declarations of the MI355X shuffle-block codec library.
+//
+// Layout of the device workspace for one compress call (all in HBM, owned by s3s_ctx):
+//   items[n_items]        16 B plan records (host-built, uploaded once per call)
+//   part_first[N+1]       first item of every partition
+//   slots[n_chunks]       one SLOT per codec chunk: frame header right-aligned in the first
+//                         32 B, payload from +32 (16 B aligned)  -> written by the codec kernel
+//   item_size[n_items]    bytes each item contributes to the .data image
+//   item_off[n_items+1]   exclusive scan of item_size                 -> scan kernel
+//   d_index[N+1], d_sums[N]                                           -> D2H at the end
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/s3shuffle_codec.h"
+
+namespace s3s {
+
+constexpr int kWave = 64;
+constexpr int kMaxBlock = 32768;          // largest codec chunk the LDS-resident kernels take
+constexpr int kSlotHeader = 32;           // bytes reserved in front of a slot's payload
+constexpr int kSlotBytes = kSlotHeader + kMaxBlock;
+constexpr int kLz4FrameHeader = 21;       // "LZ4Block" + token + 3 x i32
+constexpr int kSnappyStreamHeader = 16;
+constexpr uint32_t kLz4BlockSeed = 0x9747b28cu;
+
+// plan record kinds
+enum : int32_t {
+  kItemLz4Chunk = 0,     // LZ4Block data frame (header + payload, payload may be RAW)
+  kItemLz4End = 1,       // 21-byte end-of-stream frame
+  kItemSnappyHeader = 2, // 16-byte SnappyOutputStream header
+  kItemSnappyChunk = 3   // i32 BE length + raw snappy
+};
+
+struct Item {
+  int64_t src_off;  // offset of the chunk in the uncompressed source (chunks only)
+  int32_t len;      // uncompressed chunk length (chunks only)
+  int32_t kind;     // low 8 bits: kind; bits 8..15: LZ4Block level nibble; bits 16..: unused
+  int32_t chunk;    // slot index for chunk items, -1 otherwise
+  int32_t part;     // owning partition
+};
+
+// item_size bit 31 marks an LZ4 chunk stored RAW (payload copied from the source)
+constexpr uint32_t kRawFlag = 0x80000000u;
+
+// ---- kernel launchers (each defined next to its kernel) ---------------------------------
+// LZ4: compress every kItemLz4Chunk item into its slot, write the frame header, item_size.
+void launch_lz4_compress(const uint8_t* d_src, const Item* d_items, int32_t n_items,
+                         uint8_t* d_slots, uint32_t* d_item_size, hipStream_t st);
+// Snappy: same for kItemSnappyChunk.
+void launch_snappy_compress(const uint8_t* d_src, const Item* d_items, int32_t n_items,
+                            uint8_t* d_slots, uint32_t* d_item_size, hipStream_t st);
+// exclusive scan of item sizes + partition index extraction
+void launch_scan_items(const Item* d_items, const uint32_t* d_item_size, int32_t n_items,
+                       int64_t* d_item_off, const int32_t* d_part_first, int32_t n_parts,
+                       int64_t* d_index, hipStream_t st);
+// copy every item to its place in the .data image; sets *d_status != 0 on capacity overflow
+void launch_gather_items(const uint8_t* d_src, const Item* d_items, int32_t n_items,
+                         const uint8_t* d_slots, const uint32_t* d_item_size,
+                         const int64_t* d_item_off, uint8_t* d_dst, int64_t dst_capacity,
+                         int32_t* d_status, hipStream_t st);
+// per-range Adler32 / CRC32: out[i] over data[offsets[i], offsets[i+1])
+//   d_seg_start[n+1]: prefix of worst-case 16 KiB segment counts (host-built from upper bounds)
+//   d_tables: constant tables (checksum_tables_build), d_partial: 4 x uint32 per segment slot
+size_t checksum_tables_bytes();
+void checksum_tables_build(void* host_buf);
+void launch_checksum_with_tables(int algo, const uint8_t* d_data, const int64_t* d_offsets,
+                                 int32_t n, const int32_t* d_seg_start, int32_t total_segs,
+                                 const void* d_tables, uint32_t* d_partial, int64_t* d_out,
+                                 hipStream_t st);
+constexpr int kChecksumSegBytes = 16384;
+
+// reduce side ------------------------------------------------------------------------------
+struct Frame {        // one discovered codec frame
+  int64_t comp_off;   // payload offset in the compressed range
+  int32_t comp_len;   // payload bytes
+  int32_t orig_len;   // decoded bytes
+  uint32_t check;     // LZ4Block: xxh32 & 0x0FFFFFFF; snappy: unused
+  int32_t method;     // 0x10 raw / 0x20 lz4 (LZ4Block); 1 = snappy chunk
+};
+// LZ4Block: walk the frame chain of every partition (one lane per partition); outputs frames
+// in stream order, compacted. d_counts[0] = n_frames, d_counts[1] = error code (0 ok).
+void launch_lz4_discover(const uint8_t* d_comp, const int64_t* d_part_off, int32_t n_parts,
+                         Frame* d_frames, int32_t max_frames, int32_t* d_part_nframes,
+                         int32_t* d_status, hipStream_t st);
+void launch_snappy_discover(const uint8_t* d_comp, const int64_t* d_part_off, int32_t n_parts,
+                            Frame* d_frames, int32_t max_frames, int32_t* d_part_nframes,
+                            int32_t* d_status, hipStream_t st);
+void launch_frame_offsets(Frame* d_frames, const int32_t* d_part_nframes, int32_t n_parts,
+                          int32_t max_frames_per_part, int64_t* d_frame_out, int32_t* d_nframes,
+                          int64_t* d_total, hipStream_t st);
+void launch_lz4_decompress(const uint8_t* d_comp, const Frame* d_frames, const int32_t* d_nframes,
+                           int32_t max_frames, const int64_t* d_frame_out, uint8_t* d_dst,
+                           int64_t dst_capacity, int32_t* d_status, hipStream_t st);
+void launch_snappy_decompress(const uint8_t* d_comp, const Frame* d_frames,
+                              const int32_t* d_nframes, int32_t max_frames,
+                              const int64_t* d_frame_out, uint8_t* d_dst, int64_t dst_capacity,
+                              int32_t* d_status, hipStream_t st);
+
+// ---- device helpers shared by several kernels --------------------------------------------
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) {
+  return __builtin_amdgcn_alignbit(x, x, 32 - r);
+}
+
+// unaligned 32-bit read from LDS: two aligned dwords + v_alignbyte
+__device__ __forceinline__ uint32_t lds_rd32(const uint8_t* base, int pos) {
+  const uint32_t* p = reinterpret_cast<const uint32_t*>(base + (pos & ~3));
+  const uint32_t lo = p[0], hi = p[1];
+  return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)pos & 3u);
+}
+
+}  // namespace s3s

@@ -1,0 +1,116 @@
+"""GPU parity: s3s_compress_map_output / s3s_checksum_ranges (HIP, through the C-ABI) must be
+bit-exact with the CPU oracle — compressed bytes, index and checksums."""
+import numpy as np
+import pytest
+
+import corpus
+
+pytestmark = pytest.mark.gpu
+
+LZ4, SNAPPY, NONE = 1, 2, 0
+ADLER, CRC = 1, 2
+
+
+def _check(gpu_codec, oracle, codec, algo, data, offsets, block_size=32768):
+    img, index, sums = gpu_codec.compress_map_output(codec, algo, data, offsets)
+    r_img, r_index, r_sums = oracle.compress_map_output(codec, algo, data, offsets, block_size)
+    assert np.array_equal(index, r_index), (index[:8], r_index[:8])
+    if algo:
+        bad = np.nonzero(sums != r_sums)[0]
+        assert bad.size == 0, (bad[:5], sums[bad[:5]], r_sums[bad[:5]])
+    assert img.size == r_img.size
+    if not np.array_equal(img, r_img):
+        first = int(np.nonzero(img != r_img)[0][0])
+        part = int(np.searchsorted(index, first, side="right") - 1)
+        raise AssertionError(f"image differs at byte {first} (partition {part}, +{first - index[part]})")
+
+
+@pytest.mark.parametrize("kind", range(corpus.N_KINDS))
+def test_lz4_single_partition_edge_lengths(gpu_codec, oracle, kind):
+    rng = np.random.default_rng(100 + kind)
+    for n in corpus.EDGE_LENGTHS:
+        if kind == 6 and n > 6000:
+            continue
+        data = corpus.chunk_corpus(kind, n, rng)
+        _check(gpu_codec, oracle, LZ4, ADLER, data, [0, n])
+
+
+@pytest.mark.parametrize("algo", [ADLER, CRC, 0])
+def test_lz4_ragged_partitions(gpu_codec, oracle, algo):
+    rng = np.random.default_rng(7 + algo)
+    for it in range(6):
+        data, offsets = corpus.ragged_map_output(rng, n_parts=int(rng.integers(1, 40)), max_len=150_000)
+        _check(gpu_codec, oracle, LZ4, algo, data, offsets)
+
+
+def test_lz4_zero_partitions_and_all_empty(gpu_codec, oracle):
+    _check(gpu_codec, oracle, LZ4, ADLER, np.zeros(0, np.uint8), [0])
+    _check(gpu_codec, oracle, LZ4, ADLER, np.zeros(0, np.uint8), [0, 0, 0, 0])
+    _check(gpu_codec, oracle, LZ4, CRC, np.zeros(0, np.uint8), [0, 0])
+
+
+def test_lz4_nonzero_first_offset(gpu_codec, oracle):
+    rng = np.random.default_rng(5)
+    data = corpus.chunk_corpus(7, 200_000, rng)
+    offs = np.array([1234, 50_000, 50_000, 199_999], np.int64)
+    img, index, sums = gpu_codec.compress_map_output(LZ4, ADLER, data, offs)
+    r_img, r_index, r_sums = oracle.compress_map_output(LZ4, ADLER, data, offs)
+    assert np.array_equal(index, r_index) and np.array_equal(sums, r_sums) and np.array_equal(img, r_img)
+
+
+def test_workload_shapes(gpu_codec, oracle):
+    from s3shuffle import datagen
+
+    d, o = datagen.terasort_map_output(8 << 20, 200, seed=2)
+    _check(gpu_codec, oracle, LZ4, ADLER, d, o)
+    d, o = datagen.terasort_map_output(4 << 20, 2000, seed=4)
+    _check(gpu_codec, oracle, LZ4, CRC, d, o)
+    d, o = datagen.kv_int_map_output(200_000, 5, seed=1)
+    _check(gpu_codec, oracle, LZ4, ADLER, d, o)
+    for kind in ("zeros", "random", "terasort"):
+        d, o = datagen.skew_block(8 << 20, kind, seed=5)
+        _check(gpu_codec, oracle, LZ4, CRC, d, o)
+
+
+def test_codec_none(gpu_codec, oracle):
+    rng = np.random.default_rng(11)
+    data, offsets = corpus.ragged_map_output(rng, 17, 100_000)
+    for algo in (ADLER, CRC):
+        _check(gpu_codec, oracle, NONE, algo, data, offsets)
+
+
+@pytest.mark.parametrize("algo", [ADLER, CRC])
+def test_checksum_ranges(gpu_codec, oracle, algo):
+    rng = np.random.default_rng(3)
+    data = rng.integers(0, 256, 3_000_000, dtype=np.uint8)
+    data[100_000:400_000] = 255  # worst case for Adler32 overflow handling
+    cuts = np.sort(rng.integers(0, data.size, 40))
+    offs = np.concatenate([[0], cuts, [cuts[5]] * 0, [data.size]]).astype(np.int64)
+    offs = np.sort(np.concatenate([offs, offs[3:6]]))  # duplicate entries -> empty ranges
+    got = gpu_codec.checksum_ranges(algo, data, offs)
+    want = np.array([oracle.checksum(algo, data[offs[i]:offs[i + 1]]) for i in range(len(offs) - 1)])
+    assert np.array_equal(got, want)
+    # known-answer vectors
+    assert gpu_codec.checksum_ranges(CRC, np.frombuffer(b"123456789", np.uint8), [0, 9])[0] == 0xCBF43926
+    assert gpu_codec.checksum_ranges(ADLER, np.frombuffer(b"Wikipedia", np.uint8), [0, 9])[0] == 0x11E60398
+
+
+def test_capacity_error(gpu_codec):
+    import s3shuffle
+
+    rng = np.random.default_rng(1)
+    data = rng.integers(0, 256, 100_000, dtype=np.uint8)
+    with pytest.raises(s3shuffle.CodecError) as ei:
+        gpu_codec.compress_map_output(LZ4, ADLER, data, [0, data.size], dst_capacity=1000)
+    assert ei.value.code == -2
+
+
+def test_block_size_option(gpu_codec, oracle):
+    rng = np.random.default_rng(21)
+    data, offsets = corpus.ragged_map_output(rng, 9, 40_000)
+    for bs in (64, 1000, 4096, 16384):
+        gpu_codec.set_option(1, bs)
+        try:
+            _check(gpu_codec, oracle, LZ4, ADLER, data, offsets, block_size=bs)
+        finally:
+            gpu_codec.set_option(1, 32768)
