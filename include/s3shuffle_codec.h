@@ -91,7 +91,10 @@ enum {
   S3S_OPT_SNAPPY_BLOCK_SIZE = 2, /* spark.io.compression.snappy.blockSize, default 32768;
                                     supported 1024..32768 (snappy-java raises smaller values
                                     to 1024) */
-  S3S_OPT_PROFILE = 3            /* 1: record per-stage HIP-event timings (s3s_stage_ms) */
+  S3S_OPT_PROFILE = 3,           /* 1: record per-stage HIP-event timings (s3s_stage_ms) */
+  S3S_OPT_LZ4_VARIANT = 4        /* tuning: 0 = chunk staged in LDS (3 wavefronts per CU),
+                                    1 = chunk read through L1/L2, table-only LDS (10 per CU);
+                                    identical output */
 };
 
 /* stages reported by s3s_stage_ms (valid after a call made with S3S_OPT_PROFILE=1) */

@@ -30,7 +30,7 @@ struct DevBuf {
 enum BufId {
   B_ITEMS, B_PART_FIRST, B_SLOTS, B_ITEM_SIZE, B_ITEM_OFF, B_INDEX, B_SUMS, B_SEG_START,
   B_PARTIAL, B_STATUS, B_TABLES, B_SRC, B_DST, B_OFFSETS, B_FRAMES, B_PART_NFRAMES,
-  B_FRAME_OUT, B_REF_SUMS, B_COUNT
+  B_FRAME_OUT, B_REF_SUMS, B_ITEM_CHECK, B_COUNT
 };
 
 }  // namespace
@@ -42,6 +42,7 @@ struct s3s_ctx {
   int64_t lz4_block = 32768;
   int64_t snappy_block = 32768;
   int profile = 0;
+  int lz4_variant = 1;
   DevBuf buf[B_COUNT];
   void* h_stage = nullptr;  // pinned
   size_t h_stage_cap = 0;
@@ -246,6 +247,10 @@ int s3s_set_option(s3s_ctx* ctx, int key, int64_t value) {
     case S3S_OPT_PROFILE:
       ctx->profile = value != 0;
       return S3S_OK;
+    case S3S_OPT_LZ4_VARIANT:
+      if (value != 0 && value != 1) return fail(ctx, S3S_E_INVALID, "lz4 variant must be 0 or 1");
+      ctx->lz4_variant = (int)value;
+      return S3S_OK;
   }
   return fail(ctx, S3S_E_INVALID, "unknown option %d", key);
 }
@@ -256,6 +261,7 @@ int64_t s3s_get_option(const s3s_ctx* ctx, int key) {
     case S3S_OPT_LZ4_BLOCK_SIZE: return ctx->lz4_block;
     case S3S_OPT_SNAPPY_BLOCK_SIZE: return ctx->snappy_block;
     case S3S_OPT_PROFILE: return ctx->profile;
+    case S3S_OPT_LZ4_VARIANT: return ctx->lz4_variant;
   }
   return S3S_E_INVALID;
 }
@@ -383,14 +389,16 @@ int s3s_compress_map_output_device(s3s_ctx* ctx, int codec, int checksum_algo,
     if ((rc = ensure(ctx, B_SLOTS, (size_t)kSlotBytes * (size_t)(n_chunks > 0 ? n_chunks : 1)))) return rc;
     if ((rc = ensure(ctx, B_ITEM_SIZE, sizeof(uint32_t) * (size_t)(n_items + 1)))) return rc;
     if ((rc = ensure(ctx, B_ITEM_OFF, sizeof(int64_t) * (size_t)(n_items + 1)))) return rc;
+    if ((rc = ensure(ctx, B_ITEM_CHECK, sizeof(uint32_t) * (size_t)(n_items + 1)))) return rc;
     if (n_items > 0)
       HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_ITEMS].p, h_items, items_bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_PART_FIRST].p, h_pf, pf_bytes, hipMemcpyHostToDevice, ctx->stream));
     // the snappy stream header has a constant size; seed item_size for every item kind the
     // codec kernel does not write
     if (codec == S3S_CODEC_LZ4)
-      launch_lz4_compress(d_src, dev<Item>(ctx, B_ITEMS), n_items, dev<uint8_t>(ctx, B_SLOTS),
-                          dev<uint32_t>(ctx, B_ITEM_SIZE), ctx->stream);
+      launch_lz4_compress(d_src, dev<Item>(ctx, B_ITEMS), n_items, dev<uint32_t>(ctx, B_ITEM_CHECK),
+                          dev<uint8_t>(ctx, B_SLOTS), dev<uint32_t>(ctx, B_ITEM_SIZE),
+                          ctx->lz4_variant, ctx->stream);
     else
       launch_snappy_compress(d_src, dev<Item>(ctx, B_ITEMS), n_items, dev<uint8_t>(ctx, B_SLOTS),
                              dev<uint32_t>(ctx, B_ITEM_SIZE), ctx->stream);
