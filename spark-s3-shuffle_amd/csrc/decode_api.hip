@@ -1,7 +1,271 @@
-// placeholder until the reduce-side kernels land
-#include "s3s_internal.h"
-extern "C" {
-int s3s_decompress_range(s3s_ctx*, int, int, const uint8_t*, int64_t, const int64_t*, const int64_t*, int32_t, uint8_t*, int64_t, int64_t*, int32_t*) { return S3S_E_UNSUPPORTED; }
-int s3s_decompress_range_device(s3s_ctx*, int, int, const uint8_t*, int64_t, const int64_t*, const int64_t*, int32_t, uint8_t*, int64_t, int64_t*, int32_t*) { return S3S_E_UNSUPPORTED; }
-int s3s_decompressed_size(s3s_ctx*, int, const uint8_t*, int64_t, int64_t*) { return S3S_E_UNSUPPORTED; }
+// decode_api.hip — reduce side of the C-ABI: verify per-partition checksums, decode the codec
+// streams of one fetched block range (ShuffleBlockId / ShuffleBlockBatchId).
+//
+// Order of checks mirrors what a reduce task observes in the reference: the checksum stream
+// (S3ChecksumValidationStream.scala:54-86) sits below the decompressor
+// (S3ShuffleReader.scala:102-108), so a partition whose bytes do not match referenceChecksums
+// raises "Invalid checksum detected" — reported here as S3S_E_CHECKSUM with the partition
+// number — and a corrupted frame raises "Stream is corrupted" (S3S_E_BAD_FRAME).
+#include "s3s_ctx.h"
+
+using namespace s3s;
+
+namespace {
+
+// Host walk over LZ4Block headers: decoded size of concatenated streams (sizing helper only).
+int lz4block_decoded_size_host(const uint8_t* c, int64_t n, int64_t* out) {
+  static const uint8_t magic[8] = {'L', 'Z', '4', 'B', 'l', 'o', 'c', 'k'};
+  int64_t ip = 0, total = 0;
+  while (ip < n) {
+    if (n - ip < kLz4FrameHeader || memcmp(c + ip, magic, 8) != 0) return S3S_E_BAD_FRAME;
+    const uint8_t* h = c + ip;
+    const int method = h[8] & 0xF0, level = 10 + (h[8] & 0x0F);
+    const int32_t cl = (int32_t)((uint32_t)h[9] | (uint32_t)h[10] << 8 | (uint32_t)h[11] << 16 | (uint32_t)h[12] << 24);
+    const int32_t ol = (int32_t)((uint32_t)h[13] | (uint32_t)h[14] << 8 | (uint32_t)h[15] << 16 | (uint32_t)h[16] << 24);
+    if ((method != 0x10 && method != 0x20) || ol < 0 || cl < 0 || ol > (1 << level) ||
+        (ol == 0) != (cl == 0) || (method == 0x10 && ol != cl) || n - ip - kLz4FrameHeader < cl)
+      return S3S_E_BAD_FRAME;
+    total += ol;
+    ip += kLz4FrameHeader + cl;
+  }
+  *out = total;
+  return S3S_OK;
 }
+
+int snappy_decoded_size_host(const uint8_t* c, int64_t n, int64_t* out) {
+  static const uint8_t hdr[8] = {0x82, 'S', 'N', 'A', 'P', 'P', 'Y', 0};
+  int64_t ip = 0, total = 0;
+  if (n == 0) {
+    *out = 0;
+    return S3S_OK;
+  }
+  if (n < kSnappyStreamHeader || memcmp(c, hdr, 8) != 0) return S3S_E_BAD_FRAME;
+  ip = kSnappyStreamHeader;
+  while (ip < n) {
+    if (n - ip < 4) return S3S_E_BAD_FRAME;
+    const uint32_t cl = (uint32_t)c[ip] << 24 | (uint32_t)c[ip + 1] << 16 | (uint32_t)c[ip + 2] << 8 | c[ip + 3];
+    if (cl == 0x82534e41u) {  // concatenated stream header
+      if (n - ip < kSnappyStreamHeader || memcmp(c + ip, hdr, 8) != 0) return S3S_E_BAD_FRAME;
+      ip += kSnappyStreamHeader;
+      continue;
+    }
+    ip += 4;
+    if ((int64_t)cl > n - ip) return S3S_E_BAD_FRAME;
+    uint32_t ulen = 0;
+    int sh = 0;
+    uint32_t i = 0;
+    for (;; i++, sh += 7) {
+      if (i >= cl || sh > 28) return S3S_E_BAD_FRAME;
+      ulen |= (uint32_t)(c[ip + i] & 0x7f) << sh;
+      if (!(c[ip + i] & 0x80)) break;
+    }
+    total += ulen;
+    ip += cl;
+  }
+  *out = total;
+  return S3S_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int s3s_decompressed_size(s3s_ctx* ctx, int codec, const uint8_t* comp, int64_t comp_len,
+                          int64_t* out_len) {
+  if (!ctx) return S3S_E_INVALID;
+  ctx->err[0] = 0;
+  if (comp_len < 0 || (comp_len > 0 && !comp) || !out_len) return fail(ctx, S3S_E_INVALID, "null/invalid argument");
+  int rc;
+  switch (codec) {
+    case S3S_CODEC_NONE:
+      *out_len = comp_len;
+      return S3S_OK;
+    case S3S_CODEC_LZ4:
+      rc = lz4block_decoded_size_host(comp, comp_len, out_len);
+      break;
+    case S3S_CODEC_SNAPPY:
+      rc = snappy_decoded_size_host(comp, comp_len, out_len);
+      break;
+    default:
+      return fail(ctx, S3S_E_INVALID, "unknown codec %d", codec);
+  }
+  if (rc != S3S_OK) return fail(ctx, rc, "Stream is corrupted");
+  return S3S_OK;
+}
+
+int s3s_decompress_range_device(s3s_ctx* ctx, int codec, int checksum_algo, const uint8_t* d_comp,
+                                int64_t comp_len, const int64_t* part_offsets,
+                                const int64_t* ref_checksums, int32_t nparts, uint8_t* d_dst,
+                                int64_t dst_capacity, int64_t* out_len, int32_t* out_bad_partition) {
+  if (!ctx) return S3S_E_INVALID;
+  ctx->err[0] = 0;
+  if (out_bad_partition) *out_bad_partition = -1;
+  if (out_len) *out_len = 0;
+  if (nparts < 0 || !part_offsets || comp_len < 0 || dst_capacity < 0)
+    return fail(ctx, S3S_E_INVALID, "null/invalid argument");
+  if (codec != S3S_CODEC_NONE && codec != S3S_CODEC_LZ4 && codec != S3S_CODEC_SNAPPY)
+    return fail(ctx, S3S_E_INVALID, "unknown codec %d", codec);
+  if (checksum_algo != S3S_CHECKSUM_NONE && checksum_algo != S3S_CHECKSUM_ADLER32 &&
+      checksum_algo != S3S_CHECKSUM_CRC32)
+    return fail(ctx, S3S_E_INVALID, "Unsupported shuffle checksum algorithm: %d", checksum_algo);
+  if (part_offsets[0] != 0 || part_offsets[nparts] != comp_len)
+    return fail(ctx, S3S_E_INVALID, "part_offsets must span [0, comp_len]");
+  for (int32_t p = 0; p < nparts; p++)
+    if (part_offsets[p + 1] < part_offsets[p]) return fail(ctx, S3S_E_INVALID, "part_offsets not monotonic at %d", p);
+  if (checksum_algo != S3S_CHECKSUM_NONE && nparts > 0 && !ref_checksums)
+    return fail(ctx, S3S_E_INVALID, "ref_checksums is null but a checksum algorithm is selected");
+  if ((comp_len > 0 && !d_comp) || (dst_capacity > 0 && !d_dst)) return fail(ctx, S3S_E_INVALID, "null data pointer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  for (auto& v : ctx->stage_ms) v = 0;
+
+  const int32_t n = nparts;
+  const int32_t n_tiles = codec == S3S_CODEC_LZ4 ? lz4_tile_count(comp_len) : 0;
+  // pinned staging: [offsets n+1][seg_start n+1][sums n][misc 8 x int64]
+  const size_t off_bytes = sizeof(int64_t) * (size_t)(n + 1), seg_bytes = sizeof(int32_t) * (size_t)(n + 1);
+  const size_t o_seg = (off_bytes + 15) & ~size_t(15), o_sums = (o_seg + seg_bytes + 15) & ~size_t(15),
+               o_misc = (o_sums + sizeof(int64_t) * (size_t)(n > 0 ? n : 1) + 15) & ~size_t(15);
+  int rc;
+  if ((rc = ensure_stage(ctx, o_misc + 64))) return rc;
+  uint8_t* hs = static_cast<uint8_t*>(ctx->h_stage);
+  int64_t* h_off = reinterpret_cast<int64_t*>(hs);
+  int32_t* h_seg = reinterpret_cast<int32_t*>(hs + o_seg);
+  int64_t* h_sums = reinterpret_cast<int64_t*>(hs + o_sums);
+  int64_t* h_misc = reinterpret_cast<int64_t*>(hs + o_misc);  // [0] n_frames/total, [1] status
+  if ((rc = ensure(ctx, B_STATUS, 16))) return rc;
+  HIP_TRY(ctx, hipMemsetAsync(ctx->buf[B_STATUS].p, 0, 16, ctx->stream));
+  record(ctx, 0);
+
+  // ---- per-partition checksum over the compressed bytes ---------------------------------------
+  const bool do_sum = checksum_algo != S3S_CHECKSUM_NONE && n > 0;
+  if (do_sum) {
+    int64_t segs = 0;
+    for (int32_t p = 0; p < n; p++) {
+      h_off[p] = part_offsets[p];
+      h_seg[p] = (int32_t)segs;
+      segs += worst_segs(part_offsets[p + 1] - part_offsets[p]);
+      if (segs > 0x7fffff00ll) return fail(ctx, S3S_E_UNSUPPORTED, "range too large for one call");
+    }
+    h_off[n] = part_offsets[n];
+    h_seg[n] = (int32_t)segs;
+    if ((rc = ensure(ctx, B_OFFSETS, off_bytes))) return rc;
+    if ((rc = ensure(ctx, B_SUMS, sizeof(int64_t) * (size_t)n))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_OFFSETS].p, h_off, off_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = run_checksum(ctx, checksum_algo, d_comp, dev<int64_t>(ctx, B_OFFSETS), n, h_seg,
+                           dev<int64_t>(ctx, B_SUMS))))
+      return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(h_sums, ctx->buf[B_SUMS].p, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  record(ctx, 1);  // ev1: checksum done
+
+  auto verify_sums = [&]() -> int {
+    if (!do_sum) return S3S_OK;
+    for (int32_t p = 0; p < n; p++)
+      if (h_sums[p] != ref_checksums[p]) {
+        if (out_bad_partition) *out_bad_partition = p;
+        return fail(ctx, S3S_E_CHECKSUM, "Invalid checksum detected for partition %d of the range", p);
+      }
+    return S3S_OK;
+  };
+  auto finish_profile = [&](int last_ev) {
+    if (!ctx->profile) return;
+    float ms = 0;
+    hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[last_ev]); ctx->stage_ms[S3S_STAGE_TOTAL] = ms;
+    hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); ctx->stage_ms[S3S_STAGE_CHECKSUM] = ms;
+    if (last_ev >= 2) { hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]); ctx->stage_ms[S3S_STAGE_DISCOVER] = ms; }
+    if (last_ev >= 3) { hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); ctx->stage_ms[S3S_STAGE_CODEC] = ms; }
+  };
+
+  if (codec == S3S_CODEC_NONE) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = verify_sums())) return rc;
+    if (comp_len > dst_capacity) return fail(ctx, S3S_E_CAPACITY, "dst_capacity %lld < %lld", (long long)dst_capacity, (long long)comp_len);
+    if (comp_len > 0) HIP_TRY(ctx, hipMemcpyAsync(d_dst, d_comp, (size_t)comp_len, hipMemcpyDeviceToDevice, ctx->stream));
+    record(ctx, 2);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    finish_profile(2);
+    if (out_len) *out_len = comp_len;
+    return S3S_OK;
+  }
+
+  if (codec == S3S_CODEC_SNAPPY) return fail(ctx, S3S_E_UNSUPPORTED, "snappy decode not available in this build");
+
+  // ---- LZ4Block: discover the frame chain --------------------------------------------------------
+  if (comp_len == 0) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = verify_sums())) return rc;
+    return S3S_OK;
+  }
+  // tile workspace lives in B_FRAME_OUT's neighbours: [spec_entry][spec_exit][true_entry][frame_base] int64, [spec_count] int32
+  const size_t tile_i64 = sizeof(int64_t) * (size_t)(n_tiles + 1);
+  if ((rc = ensure(ctx, B_PART_NFRAMES, 4 * tile_i64 + sizeof(int32_t) * (size_t)(n_tiles + 1)))) return rc;
+  int64_t* d_spec_entry = dev<int64_t>(ctx, B_PART_NFRAMES);
+  int64_t* d_spec_exit = d_spec_entry + (n_tiles + 1);
+  int64_t* d_true_entry = d_spec_exit + (n_tiles + 1);
+  int64_t* d_frame_base = d_true_entry + (n_tiles + 1);
+  int32_t* d_spec_count = reinterpret_cast<int32_t*>(d_frame_base + (n_tiles + 1));
+  launch_lz4_discover(d_comp, comp_len, n_tiles, d_spec_entry, d_spec_exit, d_spec_count, d_true_entry,
+                      d_frame_base, dev<int32_t>(ctx, B_STATUS), ctx->stream);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(&h_misc[0], d_frame_base + n_tiles, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(&h_misc[1], ctx->buf[B_STATUS].p, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if ((rc = verify_sums())) return rc;
+  if (*reinterpret_cast<int32_t*>(&h_misc[1]) != 0) return fail(ctx, S3S_E_BAD_FRAME, "Stream is corrupted (frame chain)");
+  const int64_t n_frames = h_misc[0];
+  if (n_frames > 0x7fffff00ll) return fail(ctx, S3S_E_UNSUPPORTED, "too many frames in one call");
+
+  if ((rc = ensure(ctx, B_FRAMES, sizeof(Frame) * (size_t)(n_frames + 1)))) return rc;
+  if ((rc = ensure(ctx, B_ITEM_SIZE, sizeof(uint32_t) * (size_t)(n_frames + 1)))) return rc;
+  if ((rc = ensure(ctx, B_FRAME_OUT, sizeof(int64_t) * (size_t)(n_frames + 1)))) return rc;
+  launch_lz4_emit_frames(d_comp, comp_len, n_tiles, d_true_entry, d_frame_base, dev<Frame>(ctx, B_FRAMES),
+                         dev<uint32_t>(ctx, B_ITEM_SIZE), n_frames, dev<int64_t>(ctx, B_FRAME_OUT),
+                         dev<int32_t>(ctx, B_STATUS), ctx->stream);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(&h_misc[0], dev<int64_t>(ctx, B_FRAME_OUT) + n_frames, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(&h_misc[1], ctx->buf[B_STATUS].p, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  record(ctx, 2);  // ev2: discovery done
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (*reinterpret_cast<int32_t*>(&h_misc[1]) != 0) return fail(ctx, S3S_E_BAD_FRAME, "Stream is corrupted (frame header)");
+  const int64_t total = h_misc[0];
+  if (out_len) *out_len = total;
+  if (total > dst_capacity)
+    return fail(ctx, S3S_E_CAPACITY, "dst_capacity %lld < %lld decoded bytes", (long long)dst_capacity, (long long)total);
+
+  launch_lz4_decompress(d_comp, dev<Frame>(ctx, B_FRAMES), (int32_t)n_frames, dev<int64_t>(ctx, B_FRAME_OUT),
+                        d_dst, dev<int32_t>(ctx, B_STATUS), ctx->stream);
+  HIP_TRY(ctx, hipGetLastError());
+  record(ctx, 3);  // ev3: decode done
+  HIP_TRY(ctx, hipMemcpyAsync(&h_misc[1], ctx->buf[B_STATUS].p, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  finish_profile(3);
+  const int32_t st = *reinterpret_cast<int32_t*>(&h_misc[1]);
+  if (st == S3S_E_UNSUPPORTED) return fail(ctx, S3S_E_UNSUPPORTED, "LZ4Block frame larger than %d bytes", kMaxBlock);
+  if (st != 0) return fail(ctx, S3S_E_BAD_FRAME, "Stream is corrupted");
+  return S3S_OK;
+}
+
+int s3s_decompress_range(s3s_ctx* ctx, int codec, int checksum_algo, const uint8_t* comp,
+                         int64_t comp_len, const int64_t* part_offsets, const int64_t* ref_checksums,
+                         int32_t nparts, uint8_t* dst, int64_t dst_capacity, int64_t* out_len,
+                         int32_t* out_bad_partition) {
+  if (!ctx) return S3S_E_INVALID;
+  ctx->err[0] = 0;
+  if (comp_len < 0 || (comp_len > 0 && !comp) || dst_capacity < 0 || (dst_capacity > 0 && !dst))
+    return fail(ctx, S3S_E_INVALID, "null/invalid host buffer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure(ctx, B_SRC, (size_t)comp_len + 64))) return rc;
+  if ((rc = ensure(ctx, B_DST, (size_t)dst_capacity + 64))) return rc;
+  if (comp_len > 0)
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_SRC].p, comp, (size_t)comp_len, hipMemcpyHostToDevice, ctx->stream));
+  int64_t total = 0;
+  rc = s3s_decompress_range_device(ctx, codec, checksum_algo, dev<uint8_t>(ctx, B_SRC), comp_len, part_offsets,
+                                   ref_checksums, nparts, dev<uint8_t>(ctx, B_DST), dst_capacity, &total,
+                                   out_bad_partition);
+  if (out_len) *out_len = total;
+  if (rc != S3S_OK) return rc;
+  if (total > 0) HIP_TRY(ctx, hipMemcpy(dst, ctx->buf[B_DST].p, (size_t)total, hipMemcpyDeviceToHost));
+  return S3S_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,157 @@
+// s3s_ctx.h — the context object behind the C-ABI and the helpers both API translation units
+// (codec_api.hip: map side, decode_api.hip: reduce side) share.
+#pragma once
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "s3s_internal.h"
+
+namespace s3s {
+
+inline thread_local char g_create_error[512] = "";
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+enum BufId {
+  B_ITEMS, B_PART_FIRST, B_SLOTS, B_ITEM_SIZE, B_ITEM_OFF, B_INDEX, B_SUMS, B_SEG_START,
+  B_PARTIAL, B_STATUS, B_TABLES, B_SRC, B_DST, B_OFFSETS, B_FRAMES, B_PART_NFRAMES,
+  B_FRAME_OUT, B_REF_SUMS, B_ITEM_CHECK, B_COUNT
+};
+
+}  // namespace s3s
+
+struct s3s_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  char err[512] = "";
+  int64_t lz4_block = 32768;
+  int64_t snappy_block = 32768;
+  int profile = 0;
+  int lz4_variant = 1;
+  s3s::DevBuf buf[s3s::B_COUNT];
+  void* h_stage = nullptr;  // pinned
+  size_t h_stage_cap = 0;
+  hipEvent_t ev[S3S_STAGE_COUNT + 1] = {};
+  double stage_ms[S3S_STAGE_COUNT] = {};
+};
+
+namespace s3s {
+
+inline int fail(s3s_ctx* ctx, int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  if (ctx) vsnprintf(ctx->err, sizeof ctx->err, fmt, ap);
+  else vsnprintf(g_create_error, sizeof g_create_error, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                  \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(ctx, S3S_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),    \
+                  __FILE__, __LINE__);                                                      \
+  } while (0)
+
+inline int ensure(s3s_ctx* ctx, BufId id, size_t bytes) {
+  DevBuf& b = ctx->buf[id];
+  if (bytes <= b.cap) return S3S_OK;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (b.p) HIP_TRY(ctx, hipFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+  size_t want = bytes + bytes / 4 + 4096;
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) {
+    want = bytes;
+    e = hipMalloc(&b.p, want);
+  }
+  if (e != hipSuccess) return fail(ctx, S3S_E_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+  b.cap = want;
+  return S3S_OK;
+}
+
+inline int ensure_stage(s3s_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->h_stage_cap) return S3S_OK;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->h_stage) HIP_TRY(ctx, hipHostFree(ctx->h_stage));
+  ctx->h_stage = nullptr;
+  ctx->h_stage_cap = 0;
+  const size_t want = bytes + bytes / 4 + 4096;
+  HIP_TRY(ctx, hipHostMalloc(&ctx->h_stage, want, hipHostMallocDefault));
+  ctx->h_stage_cap = want;
+  return S3S_OK;
+}
+
+template <typename T>
+inline T* dev(s3s_ctx* ctx, BufId id) {
+  return static_cast<T*>(ctx->buf[id].p);
+}
+
+inline int lz4_level(int64_t block_size) {
+  int level = 0;
+  while ((1ll << level) < block_size) level++;
+  level -= 10;
+  return level < 0 ? 0 : level;
+}
+
+inline int64_t snappy_max_len(int64_t n) { return 32 + n + n / 6; }
+
+inline int64_t effective_block(const s3s_ctx* ctx, int codec) {
+  if (codec == S3S_CODEC_LZ4) return ctx ? ctx->lz4_block : 32768;
+  if (codec == S3S_CODEC_SNAPPY) {
+    const int64_t b = ctx ? ctx->snappy_block : 32768;
+    return b < 1024 ? 1024 : b;  // snappy-java: Math.max(MIN_BLOCK_SIZE, blockSize)
+  }
+  return 0;
+}
+
+inline int64_t max_partition_size(int codec, int64_t bs, int64_t u) {
+  if (u <= 0) return 0;
+  switch (codec) {
+    case S3S_CODEC_NONE:
+      return u;
+    case S3S_CODEC_LZ4: {
+      const int64_t chunks = (u + bs - 1) / bs;
+      return u + chunks * kLz4FrameHeader + kLz4FrameHeader;  // RAW fallback caps the payload
+    }
+    case S3S_CODEC_SNAPPY: {
+      const int64_t full = u / bs, rem = u % bs;
+      return kSnappyStreamHeader + full * (4 + snappy_max_len(bs)) + (rem ? 4 + snappy_max_len(rem) : 0);
+    }
+  }
+  return -1;
+}
+
+inline void record(s3s_ctx* ctx, int slot) {
+  if (ctx->profile) hipEventRecord(ctx->ev[slot], ctx->stream);
+}
+
+// worst-case 16 KiB checksum segments of a range that is at most `bytes` long
+inline int32_t worst_segs(int64_t bytes) { return (int32_t)((bytes + kChecksumSegBytes - 1) / kChecksumSegBytes); }
+
+inline int run_checksum(s3s_ctx* ctx, int algo, const uint8_t* d_data, const int64_t* d_offsets,
+                 int32_t n, const int32_t* h_seg_start /* n+1, in pinned stage */,
+                 int64_t* d_out) {
+  const int32_t total = h_seg_start[n];
+  int rc;
+  if ((rc = ensure(ctx, B_SEG_START, sizeof(int32_t) * (size_t)(n + 1)))) return rc;
+  if ((rc = ensure(ctx, B_PARTIAL, sizeof(uint32_t) * 4 * (size_t)(total > 0 ? total : 1)))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(dev<int32_t>(ctx, B_SEG_START), h_seg_start,
+                              sizeof(int32_t) * (size_t)(n + 1), hipMemcpyHostToDevice, ctx->stream));
+  launch_checksum_with_tables(algo, d_data, d_offsets, n, dev<int32_t>(ctx, B_SEG_START), total,
+                              ctx->buf[B_TABLES].p, dev<uint32_t>(ctx, B_PARTIAL), d_out,
+                              ctx->stream);
+  HIP_TRY(ctx, hipGetLastError());
+  return S3S_OK;
+}
+
+}  // namespace s3s

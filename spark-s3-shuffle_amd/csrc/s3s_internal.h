@@ -81,24 +81,32 @@ struct Frame {        // one discovered codec frame
   uint32_t check;     // LZ4Block: xxh32 & 0x0FFFFFFF; snappy: unused
   int32_t method;     // 0x10 raw / 0x20 lz4 (LZ4Block); 1 = snappy chunk
 };
-// LZ4Block: walk the frame chain of every partition (one lane per partition); outputs frames
-// in stream order, compacted. d_counts[0] = n_frames, d_counts[1] = error code (0 ok).
-void launch_lz4_discover(const uint8_t* d_comp, const int64_t* d_part_off, int32_t n_parts,
-                         Frame* d_frames, int32_t max_frames, int32_t* d_part_nframes,
-                         int32_t* d_status, hipStream_t st);
+// LZ4Block frame discovery over the whole range (see lz4_decompress.hip): 64 KiB tiles are
+// walked speculatively, resolved into the true chain, then emitted in stream order.
+//   d_spec_count[n_tiles] (as uint32) -> d_frame_base[n_tiles+1] (exclusive scan; last = n_frames)
+int32_t lz4_tile_count(int64_t comp_len);
+void launch_lz4_discover(const uint8_t* d_comp, int64_t comp_len, int32_t n_tiles,
+                         int64_t* d_spec_entry, int64_t* d_spec_exit, int32_t* d_spec_count,
+                         int64_t* d_true_entry, int64_t* d_frame_base, int32_t* d_status,
+                         hipStream_t st);
+//   writes d_frames[n_frames], d_frame_orig[n_frames] and d_frame_out[n_frames+1] (scan of
+//   decoded sizes; last = total decoded bytes)
+void launch_lz4_emit_frames(const uint8_t* d_comp, int64_t comp_len, int32_t n_tiles,
+                            const int64_t* d_true_entry, const int64_t* d_frame_base,
+                            Frame* d_frames, uint32_t* d_frame_orig, int64_t n_frames,
+                            int64_t* d_frame_out, int32_t* d_status, hipStream_t st);
+void launch_lz4_decompress(const uint8_t* d_comp, const Frame* d_frames, int32_t n_frames,
+                           const int64_t* d_frame_out, uint8_t* d_dst, int32_t* d_status,
+                           hipStream_t st);
+// Snappy (SnappyInputStream framing): chunks are chained by their i32 BE length only, so the
+// walk is one lane per partition stream (each partition starts with the 16-byte header).
 void launch_snappy_discover(const uint8_t* d_comp, const int64_t* d_part_off, int32_t n_parts,
-                            Frame* d_frames, int32_t max_frames, int32_t* d_part_nframes,
-                            int32_t* d_status, hipStream_t st);
-void launch_frame_offsets(Frame* d_frames, const int32_t* d_part_nframes, int32_t n_parts,
-                          int32_t max_frames_per_part, int64_t* d_frame_out, int32_t* d_nframes,
-                          int64_t* d_total, hipStream_t st);
-void launch_lz4_decompress(const uint8_t* d_comp, const Frame* d_frames, const int32_t* d_nframes,
-                           int32_t max_frames, const int64_t* d_frame_out, uint8_t* d_dst,
-                           int64_t dst_capacity, int32_t* d_status, hipStream_t st);
-void launch_snappy_decompress(const uint8_t* d_comp, const Frame* d_frames,
-                              const int32_t* d_nframes, int32_t max_frames,
-                              const int64_t* d_frame_out, uint8_t* d_dst, int64_t dst_capacity,
-                              int32_t* d_status, hipStream_t st);
+                            int32_t max_frames_per_part, Frame* d_frames, uint32_t* d_frame_orig,
+                            int32_t* d_part_nframes, int32_t* d_status, hipStream_t st);
+void launch_snappy_decompress(const uint8_t* d_comp, const Frame* d_frames, int32_t n_frames,
+                              const int64_t* d_frame_out, uint8_t* d_dst, int32_t* d_status,
+                              hipStream_t st);
+void launch_scan_u32(const uint32_t* d_in, int64_t n, int64_t* d_out, hipStream_t st);
 
 // ---- device helpers shared by several kernels --------------------------------------------
 __device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) {

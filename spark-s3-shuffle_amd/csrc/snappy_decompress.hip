@@ -1,1 +1,2 @@
-// placeholder
+// placeholder until the snappy decode kernel lands
+#include "s3s_internal.h"

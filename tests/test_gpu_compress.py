@@ -11,6 +11,14 @@ LZ4, SNAPPY, NONE = 1, 2, 0
 ADLER, CRC = 1, 2
 
 
+@pytest.fixture(params=[0, 1], ids=["chunk-in-lds", "chunk-in-l2"], autouse=True)
+def lz4_variant(request, gpu_codec):
+    """Every test runs against both placements of the chunk bytes (S3S_OPT_LZ4_VARIANT)."""
+    gpu_codec.set_option(4, request.param)
+    yield request.param
+    gpu_codec.set_option(4, 1)
+
+
 def _check(gpu_codec, oracle, codec, algo, data, offsets, block_size=32768):
     img, index, sums = gpu_codec.compress_map_output(codec, algo, data, offsets)
     r_img, r_index, r_sums = oracle.compress_map_output(codec, algo, data, offsets, block_size)

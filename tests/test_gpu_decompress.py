@@ -1,0 +1,140 @@
+"""GPU parity, reduce side: s3s_decompress_range (verify + decode through the C-ABI) against the
+oracle's restatement of S3ChecksumValidationStream + LZ4BlockInputStream, on streams produced by
+the ORACLE (so decode is tested independently of the GPU compressor) and round trips."""
+import numpy as np
+import pytest
+
+import corpus
+
+pytestmark = pytest.mark.gpu
+
+LZ4, NONE = 1, 0
+ADLER, CRC = 1, 2
+
+
+def _oracle_image(oracle, codec, algo, data, offsets, block_size=32768):
+    return oracle.compress_map_output(codec, algo, data, offsets, block_size)
+
+
+@pytest.mark.parametrize("algo", [ADLER, CRC, 0])
+def test_decode_oracle_streams(gpu_codec, oracle, algo):
+    rng = np.random.default_rng(31 + algo)
+    for it in range(5):
+        data, offsets = corpus.ragged_map_output(rng, int(rng.integers(1, 30)), 120_000)
+        img, index, sums = _oracle_image(oracle, LZ4, algo, data, offsets)
+        out = gpu_codec.decompress_range(LZ4, algo, img, index, sums)
+        assert np.array_equal(out, data)
+        # batch fetch of a sub-range [r0, r1) (ShuffleBlockBatchId semantics)
+        n = len(offsets) - 1
+        r0 = int(rng.integers(0, n))
+        r1 = int(rng.integers(r0 + 1, n + 1))
+        sub = img[index[r0]:index[r1]]
+        out = gpu_codec.decompress_range(LZ4, algo, sub, index[r0:r1 + 1] - index[r0],
+                                         None if algo == 0 else sums[r0:r1])
+        assert np.array_equal(out, data[offsets[r0]:offsets[r1]])
+
+
+@pytest.mark.parametrize("kind", range(corpus.N_KINDS))
+def test_decode_edge_lengths(gpu_codec, oracle, kind):
+    rng = np.random.default_rng(200 + kind)
+    for n in corpus.EDGE_LENGTHS:
+        if kind == 6 and n > 6000:
+            continue
+        data = corpus.chunk_corpus(kind, n, rng)
+        img, index, sums = _oracle_image(oracle, LZ4, ADLER, data, [0, n])
+        out = gpu_codec.decompress_range(LZ4, ADLER, img, index, sums)
+        assert np.array_equal(out, data), (kind, n)
+
+
+def test_decode_empty_and_zero_partitions(gpu_codec):
+    out = gpu_codec.decompress_range(LZ4, ADLER, np.zeros(0, np.uint8), [0, 0, 0], [1, 1], dst_capacity=0)
+    assert out.size == 0
+    out = gpu_codec.decompress_range(LZ4, CRC, np.zeros(0, np.uint8), [0, 0], [0], dst_capacity=0)
+    assert out.size == 0
+
+
+def test_magic_inside_payload(gpu_codec, oracle):
+    """Payload bytes that look like frame headers (a RAW-stored LZ4Block stream inside the data)
+    must not derail frame discovery."""
+    rng = np.random.default_rng(77)
+    inner = oracle.compress_stream(LZ4, rng.integers(0, 256, 70_000, dtype=np.uint8))
+    parts = [inner, rng.integers(0, 256, 200_000, dtype=np.uint8), inner[:40_000], inner]
+    fake = np.frombuffer(b"LZ4Block\x25\x10\x00\x00\x00\x10\x00\x00\x00\x00\x00\x00\x00", np.uint8)
+    parts.append(np.concatenate([fake] * 3000))
+    data = np.concatenate(parts)
+    offsets = np.array([0, inner.size, data.size], np.int64)
+    img, index, sums = _oracle_image(oracle, LZ4, CRC, data, offsets)
+    out = gpu_codec.decompress_range(LZ4, CRC, img, index, sums)
+    assert np.array_equal(out, data)
+
+
+def test_round_trip_workloads(gpu_codec):
+    from s3shuffle import datagen
+
+    for d, o, algo in (datagen.terasort_map_output(8 << 20, 200, seed=2) + (ADLER,),
+                       datagen.terasort_map_output(4 << 20, 2000, seed=4) + (CRC,),
+                       datagen.kv_int_map_output(200_000, 5, seed=1) + (ADLER,),
+                       datagen.skew_block(16 << 20, "terasort", seed=5) + (CRC,),
+                       datagen.skew_block(4 << 20, "zeros", seed=5) + (CRC,),
+                       datagen.skew_block(4 << 20, "random", seed=5) + (ADLER,)):
+        img, index, sums = gpu_codec.compress_map_output(LZ4, algo, d, o)
+        out = gpu_codec.decompress_range(LZ4, algo, img, index, sums)
+        assert np.array_equal(out, d)
+
+
+def test_checksum_mismatch_reports_partition(gpu_codec, oracle):
+    import s3shuffle
+
+    rng = np.random.default_rng(5)
+    data, offsets = corpus.ragged_map_output(rng, 12, 50_000)
+    img, index, sums = _oracle_image(oracle, LZ4, ADLER, data, offsets)
+    nonempty = [p for p in range(12) if index[p + 1] > index[p]]
+    victim = nonempty[len(nonempty) // 2]
+    bad = img.copy()
+    bad[index[victim] + 30] ^= 0x40
+    with pytest.raises(s3shuffle.CodecError) as ei:
+        gpu_codec.decompress_range(LZ4, ADLER, bad, index, sums)
+    assert ei.value.code == -4 and ei.value.partition == victim
+    r_rc, _, r_bad = oracle.decompress_range(LZ4, ADLER, bad, index, sums, data.size)
+    assert r_rc == -4 and r_bad == victim
+
+
+def test_corrupt_frames_are_rejected(gpu_codec, oracle):
+    import s3shuffle
+
+    rng = np.random.default_rng(6)
+    data = corpus.chunk_corpus(7, 150_000, rng)
+    img, index, _ = _oracle_image(oracle, LZ4, 0, data, [0, data.size])
+    cases = []
+    c = img.copy(); c[3] ^= 1; cases.append(c)                       # magic
+    c = img.copy(); c[8] = 0x35; cases.append(c)                     # method
+    c = img.copy(); c[17] ^= 0xFF; cases.append(c)                   # frame hash
+    c = img.copy(); c[21 + 100] ^= 0x55; cases.append(c)             # payload
+    cases.append(img[:-5].copy())                                    # truncated end frame
+    c = img.copy(); c[9] ^= 0x10; cases.append(c)                    # compressedLen -> chain breaks
+    for i, c in enumerate(cases):
+        with pytest.raises(s3shuffle.CodecError) as ei:
+            gpu_codec.decompress_range(LZ4, 0, c, [0, c.size], None, dst_capacity=data.size + 65536)
+        assert ei.value.code == -3, i
+        rc, _, _ = oracle.decompress_range(LZ4, 0, c, [0, c.size], None, data.size + 65536)
+        assert rc == -3, i
+
+
+def test_capacity_and_sizing(gpu_codec, oracle):
+    import s3shuffle
+
+    rng = np.random.default_rng(8)
+    data = corpus.chunk_corpus(3, 100_000, rng)
+    img, index, sums = _oracle_image(oracle, LZ4, ADLER, data, [0, data.size])
+    assert gpu_codec.decompressed_size(LZ4, img) == data.size
+    with pytest.raises(s3shuffle.CodecError) as ei:
+        gpu_codec.decompress_range(LZ4, ADLER, img, index, sums, dst_capacity=1000)
+    assert ei.value.code == -2
+
+
+def test_codec_none_passthrough(gpu_codec, oracle):
+    rng = np.random.default_rng(9)
+    data, offsets = corpus.ragged_map_output(rng, 7, 30_000)
+    img, index, sums = _oracle_image(oracle, NONE, CRC, data, offsets)
+    out = gpu_codec.decompress_range(NONE, CRC, img, index, sums)
+    assert np.array_equal(out, data)

@@ -21,12 +21,13 @@ def main():
     d_dst = torch.empty(cap, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
     c.set_option(3, 1)
-    for algo in (1, 2):
-        for it in range(4):
+    for variant, algo in ((0, 1), (1, 1), (1, 2)):
+        c.set_option(4, variant)
+        for it in range(3):
             t = time.perf_counter()
             total, index, sums = c.compress_map_output_device(1, algo, d_src.data_ptr(), offs, d_dst.data_ptr(), cap)
             dt = time.perf_counter() - t
-            print(f"{kind} algo={algo} it={it}: U={data.size} C={total} ratio={data.size/total:.2f} wall={dt*1e3:.2f} ms "
+            print(f"{kind} variant={variant} algo={algo} it={it}: U={data.size} C={total} ratio={data.size/total:.2f} wall={dt*1e3:.2f} ms "
                   f"-> {data.size/dt/1e9:.1f} GB/s | stages ms total={c.stage_ms(0):.2f} codec={c.stage_ms(1):.2f} "
                   f"assemble={c.stage_ms(2):.3f} checksum={c.stage_ms(3):.3f}")
     # checksum-only roofline probe on the uncompressed data
