@@ -85,19 +85,28 @@ __device__ __forceinline__ void copy_to_global(uint8_t* dst, const Src& in, int 
 // Writes one LZ4 sequence (token, literal-length bytes, literals and — if has_match — offset
 // and match-length bytes) at out+op.  All scalar arguments are wave-uniform.  Returns the new
 // op, or -1 when the sequence would not fit in cap bytes (=> the frame is stored RAW).
+// lit_reg: when >= 0x100 the literal run is NOT available in registers; otherwise every lane k
+// holds in `lit_byte` the literal that belongs at output byte 1+... (see caller).
 template <typename Src>
 __device__ __forceinline__ int emit_sequence(uint8_t* out, int cap, int op, const Src& in,
                                              int anchor, int lit, bool has_match, int offset,
-                                             int mcode, int lane) {
+                                             int mcode, bool lit_in_regs, uint32_t lit_byte,
+                                             int lane) {
   uint8_t* o = out + op;
-  if (lit < 15 && mcode < 15 && has_match) {
-    // short form (the common case): token | literals | offset, one byte per lane
-    const int total = 3 + lit;
+  if (has_match && lit < 15 && mcode < 15 + 255) {
+    // short form (the common case): token | literals | offset | [one match-length byte]
+    const int total = 3 + lit + (mcode >= 15 ? 1 : 0);
     if (op + total > cap) return -1;
-    uint32_t b = (uint32_t)(lit << 4) | (uint32_t)mcode;
-    if (lane >= 1 && lane <= lit) b = in.rd8(anchor + lane - 1);
-    if (lane == lit + 1) b = (uint32_t)offset;
-    if (lane == lit + 2) b = (uint32_t)offset >> 8;
+    uint32_t b = lit_byte;
+    if (!lit_in_regs) {
+      int lp = anchor + lane - 1;  // lanes 1..lit carry the literals
+      lp = lp < anchor ? anchor : lp;
+      b = in.rd8(lp);
+    }
+    b = (lane == 0) ? ((uint32_t)(lit << 4) | (uint32_t)(mcode < 15 ? mcode : 15)) : b;
+    b = (lane == lit + 1) ? (uint32_t)offset : b;
+    b = (lane == lit + 2) ? ((uint32_t)offset >> 8) : b;
+    b = (lane == lit + 3) ? (uint32_t)(mcode - 15) : b;
     if (lane < total) o[lane] = (uint8_t)b;
     return op + total;
   }
@@ -110,87 +119,95 @@ __device__ __forceinline__ int emit_sequence(uint8_t* out, int cap, int op, cons
   const int lit0 = 1 + le;      // first literal byte
   const int off0 = lit0 + lit;  // offset low byte
   const uint32_t lrem = (uint32_t)((lit - 15) % 255), mrem = (uint32_t)((mcode - 15) % 255);
-  if (total <= kWave) {
-    const int k = lane;
-    uint32_t b;
-    if (k == 0) {
-      b = token;
-    } else if (k < lit0) {
-      b = (k < le) ? 255u : lrem;
-    } else if (k < off0) {
-      b = in.rd8(anchor + (k - lit0));
-    } else if (k == off0) {
-      b = (uint32_t)offset & 0xffu;
-    } else if (k == off0 + 1) {
-      b = (uint32_t)offset >> 8;
-    } else {
-      b = (k - (off0 + 2) < me - 1) ? 255u : mrem;
-    }
-    if (k < total) o[k] = (uint8_t)b;
-    return op + total;
-  }
   if (lane == 0) o[0] = (uint8_t)token;
   for (int j = lane; j < le; j += kWave) o[1 + j] = (uint8_t)(j < le - 1 ? 255u : lrem);
   copy_to_global(o + lit0, in, anchor, lit, lane);
   if (has_match) {
-    if (lane == 0) o[off0] = (uint8_t)offset;
-    if (lane == 1) o[off0 + 1] = (uint8_t)((uint32_t)offset >> 8);
+    if (lane < 2) o[off0 + lane] = (uint8_t)((uint32_t)offset >> (8 * lane));
     for (int j = lane; j < me; j += kWave) o[off0 + 2 + j] = (uint8_t)(j < me - 1 ? 255u : mrem);
   }
   return op + total;
 }
 
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+
 // The parse.  Returns the compressed size, or -1 if it would exceed len.
 template <typename Src>
-__device__ int lz4_compress_wave(const Src in, volatile uint16_t* T, int len, uint8_t* out,
-                                 int lane) {
+__device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t* out, int lane) {
+  volatile lds_u16* T = table;  // every access is a real ds_read_u16 / ds_write_b16, in order
   const int mfl1 = len - kMfLimit + 1;  // mflimitPlusOne
   const int matchlimit = len - kLastLiterals;
+  const int last4 = len - 4;
   int anchor = 0, op = 0;
 
   if (len >= kMfLimit + 1) {
-    if (lane == 0) T[hash13(in.rd32(0))] = 0;  // LZ4_putPosition(ip = source)
+    T[hash13(in.rd32(0))] = 0;  // LZ4_putPosition(ip = source); all lanes store the same value
     int base = 1, t0 = 1;
+    uint32_t vpre = in.rd32(1 + lane < last4 ? 1 + lane : last4);  // prefetched v of the next batch
+    bool have_pre = true;
+    uint32_t vput = 0;  // the 4 bytes at base-2, to insert before the batch (after a match)
+    bool put_pending = false;
     for (;;) {
       // ---- one batch: lane i evaluates probe t0+i of the current no-match run ----------------
-      int pos, nextpos;
+      int pos, nvalid;
       if (t0 <= 2) {  // probes 0..65 of a run are consecutive bytes
         pos = base + lane;
-        nextpos = pos + 1;
+        // lane valid iff its successor position <= mflimitPlusOne; the post-match probe (t = 0)
+        // is only reached with base < mflimitPlusOne, so the same bound covers it
+        nvalid = mfl1 - base;
       } else {
         const int S0 = sched_S(t0);
         pos = base + sched_S(t0 + lane) - S0;
-        nextpos = base + sched_S(t0 + lane + 1) - S0;
+        const int nextpos = base + sched_S(t0 + lane + 1) - S0;
+        nvalid = __popcll(__ballot(nextpos <= mfl1));  // valid lanes form a prefix
       }
-      // the CPU loop leaves for _last_literals BEFORE probing pos when nextpos > mflimitPlusOne;
-      // the post-match probe (t == 0) has no such test
-      const bool valid = (t0 + lane == 0) || (nextpos <= mfl1);
-      const int nvalid = __popcll(__ballot(valid));  // valid lanes form a prefix
-      uint32_t v = 0, h = 0, c = 0, r = 0;
+      nvalid = nvalid < kWave ? nvalid : kWave;
+      const bool valid = lane < nvalid;
+      if (put_pending) T[hash13(vput)] = (uint16_t)(base - 2);  // LZ4_putPosition(ip - 2)
+      put_pending = false;
+      const uint32_t v = have_pre ? vpre : in.rd32(pos < last4 ? pos : last4);
+      have_pre = false;
+      const uint32_t h = hash13(v);
+      uint32_t c = 0, r = (uint32_t)pos;
       if (valid) {
-        v = in.rd32(pos);
-        h = hash13(v);
         c = T[h];              // candidate as of the start of the batch
         T[h] = (uint16_t)pos;  // speculative insert, all lanes at once
         r = T[h];              // readback: did this lane own its slot?
       }
       const uint32_t w = in.rd32((int)c);
-      const uint64_t C = __ballot(valid && r != (uint32_t)pos);
-      const uint64_t M = __ballot(valid && w == v);
-      // lanes below `cut` have pairwise distinct hashes => their start-of-batch candidates are
-      // exactly what the sequential code would have read
-      int cut = kWave;
-      if (C) cut = (C & 1) ? 1 : __builtin_ctzll(C);
-      const int lim = cut < nvalid ? cut : nvalid;
+      const uint32_t vprev = __builtin_amdgcn_update_dpp(~v, v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+      const uint64_t L = __ballot(r != (uint32_t)pos);              // lost its slot
+      const uint64_t M = __ballot(valid && w == v);                 // start-of-batch candidate matches
+      const uint64_t A = __ballot(valid && lane > 0 && v == vprev); // repeats the previous probe
+      // Clean prefix [0,B): lanes whose start-of-batch candidate is what the sequential code reads.
+      // Everything below the smallest loser c0 is clean; c0 itself is clean iff its slot's winner is
+      // a LATER lane (an earlier member of its hash group would have lost too).
+      int B = kWave, c0 = -1;
+      bool clean0 = false;
+      if (L) {
+        c0 = __builtin_ctzll(L);
+        const uint32_t rc0 = __builtin_amdgcn_readlane(r, c0);
+        const uint32_t pc0 = __builtin_amdgcn_readlane((uint32_t)pos, c0);
+        clean0 = rc0 > pc0;
+        B = c0 + (clean0 ? 1 : 0);
+      }
+      const int lim = B < nvalid ? B : nvalid;
       const uint64_t Mv = lim >= kWave ? M : (M & ((1ull << lim) - 1ull));
       int m = -1, keep = lim;
+      bool adj = false;
       if (Mv) {
         m = __builtin_ctzll(Mv);
         keep = m + 1;
+      } else if (lim < nvalid && ((A >> lim) & 1ull)) {
+        m = lim;  // first non-clean lane repeats its clean predecessor: a certain match at offset step
+        adj = true;
+        keep = lim + 1;
       }
-      // undo inserts of lanes the sequential code never reached
+      // table fix-up: winners the sequential code never reached restore the old entry, then
+      // committed losers re-insert (c0, unless the adjacent match lane overrides the same slot)
       if (valid && lane >= keep && r == (uint32_t)pos) T[h] = (uint16_t)c;
-      if ((C & 1) && lane == 0) T[h] = (uint16_t)pos;  // lane 0 lost its race but is committed
+      const bool redo_c0 = clean0 && c0 < keep && !(adj && c0 == m - 1);
+      if ((redo_c0 && lane == c0) || (adj && lane == m)) T[h] = (uint16_t)pos;
 
       if (m < 0) {
         if (lim == nvalid && nvalid < kWave) break;  // ran into mflimit: last literals
@@ -200,8 +217,9 @@ __device__ int lz4_compress_wave(const Src in, volatile uint16_t* T, int len, ui
       }
 
       // ---- match at lane m --------------------------------------------------------------------
-      const int ip0 = base + sched_S(t0 + m) - sched_S(t0);
-      const int match0 = (int)__builtin_amdgcn_readlane(c, m);
+      const int ip0 = (int)__builtin_amdgcn_readlane((uint32_t)pos, m);
+      const int match0 = adj ? (int)__builtin_amdgcn_readlane((uint32_t)pos, m - 1)
+                             : (int)__builtin_amdgcn_readlane(c, m);
       int ip = ip0, match = match0;
       // both extensions read independent bytes: issue them together
       // backward: catch-up over pending literals, 64 bytes per round
@@ -211,9 +229,8 @@ __device__ int lz4_compress_wave(const Src in, volatile uint16_t* T, int len, ui
         ba = in.rd8(ip - 1 - lane);
         bb = in.rd8(match - 1 - lane);
       }
-      // forward count from the 4 matched bytes, 256 bytes per round (LZ4_count to matchlimit)
-      // (dwords starting at or beyond matchlimit never count, so clamping their address is free)
-      const int last4 = len - 4;
+      // forward count from the 4 matched bytes, 256 bytes per round (LZ4_count to matchlimit);
+      // dwords starting at or beyond matchlimit never count, so clamping their address is free
       int fp = ip0 + kMinMatch + 4 * lane;
       if (Src::kClamp) fp = fp < last4 ? fp : last4;
       uint32_t x = in.rd32(fp) ^ in.rd32(fp - (ip0 - match0));
@@ -247,18 +264,28 @@ __device__ int lz4_compress_wave(const Src in, volatile uint16_t* T, int len, ui
         if (Src::kClamp) fp = fp < last4 ? fp : last4;
         x = in.rd32(fp) ^ in.rd32(fp - (ip0 - match0));
       }
+      const int ipe = ip0 + kMinMatch + fwd;  // first byte after the match
+      // prefetch what the next batch needs while the sequence is being written out
+      if (ipe < mfl1) {
+        vpre = in.rd32(ipe + lane < last4 ? ipe + lane : last4);
+        vput = in.rd32(ipe - 2);
+        have_pre = true;
+        put_pending = true;
+      }
       const int mcode = (ip0 - ip) + fwd;  // bytes beyond MINMATCH, counted from the moved-back ip
-      op = emit_sequence(out, len, op, in, anchor, ip - anchor, true, ip - match, mcode, lane);
+      // literals: when the run started with this batch (post-match probe at `anchor`), output
+      // byte k (1 <= k <= lit) is the low byte of probe k-1, i.e. of the lane to the left
+      const bool lit_in_regs = (t0 == 0) && (anchor == base);
+      op = emit_sequence(out, len, op, in, anchor, ip - anchor, true, ip - match, mcode,
+                         lit_in_regs, vprev & 0xffu, lane);
       if (op < 0) return -1;
-      ip = ip0 + kMinMatch + fwd;
-      anchor = ip;
-      if (ip >= mfl1) break;  // end of chunk
-      if (lane == 0) T[hash13(in.rd32(ip - 2))] = (uint16_t)(ip - 2);  // fill table
-      base = ip;  // next batch starts with the "test next position" probe (t = 0)
+      anchor = ipe;
+      if (ipe >= mfl1) break;  // end of chunk
+      base = ipe;  // next batch starts with the "test next position" probe (t = 0)
       t0 = 0;
     }
   }
-  return emit_sequence(out, len, op, in, anchor, len - anchor, false, 0, 0, lane);
+  return emit_sequence(out, len, op, in, anchor, len - anchor, false, 0, 0, false, 0u, lane);
 }
 
 // LZ4Block frame header + item size, written by lanes 0..20 of the parsing wave
@@ -316,7 +343,7 @@ __global__ __launch_bounds__(kWave) void lz4_compress_lds_kernel(
   }
   __syncthreads();
   uint8_t* slot = slots + (size_t)item.chunk * kSlotBytes;
-  const int clen = lz4_compress_wave(SrcLds{s.in}, s.table, len, slot + kSlotHeader, lane);
+  const int clen = lz4_compress_wave(SrcLds{s.in}, (lds_u16*)s.table, len, slot + kSlotHeader, lane);
   finish_frame(slot, len, clen, item_check[it], item.kind >> 8, item_size + it, lane);
 }
 
@@ -341,7 +368,7 @@ __global__ __launch_bounds__(kWave) void lz4_compress_l2_kernel(
   }
   __syncthreads();
   uint8_t* slot = slots + (size_t)item.chunk * kSlotBytes;
-  const int clen = lz4_compress_wave(SrcGlobal{src + item.src_off}, table, item.len,
+  const int clen = lz4_compress_wave(SrcGlobal{src + item.src_off}, (lds_u16*)table, item.len,
                                      slot + kSlotHeader, lane);
   finish_frame(slot, item.len, clen, item_check[it], item.kind >> 8, item_size + it, lane);
 }

@@ -157,23 +157,41 @@ extern "C" int lz4_wave_model_compress(const uint8_t* src, int len, uint8_t* dst
         if (r[i] != (uint16_t)pos[i]) C |= 1ull << i;
         if (w[i] == v[i]) M |= 1ull << i;
       }
-      // ---- cut: lanes below it are duplicate-free, so their old candidates are the true ones -
-      int cut = WAVE;
-      if (C) cut = (C & 1) ? 1 : __builtin_ctzll(C);
-      int lim = cut < nvalid ? cut : nvalid;
+      // ---- clean prefix: lanes whose start-of-batch candidate is the true one ------------------
+      // A lane is "clean" when no earlier lane of the batch shares its hash.  Every lane below the
+      // smallest loser c0 is clean; c0 itself is clean iff its slot's winner is a LATER lane (an
+      // earlier member of its group would have lost too, contradicting minimality).
+      uint64_t A = 0;  // lane i repeats lane i-1's 4 bytes: true candidate = pos[i-1], and it matches
+      for (int i = 1; i < nvalid; i++)
+        if (v[i] == v[i - 1]) A |= 1ull << i;
+      int B = WAVE, c0 = -1;
+      bool clean0 = false;
+      if (C) {
+        c0 = __builtin_ctzll(C);
+        clean0 = r[c0] > (uint16_t)pos[c0];
+        B = c0 + (clean0 ? 1 : 0);
+      }
+      int lim = B < nvalid ? B : nvalid;
       uint64_t Mv = lim >= 64 ? M : (M & ((1ull << lim) - 1));
       int keep;  // lanes [0,keep) stay inserted
       int m = -1;
+      bool adj = false;
       if (Mv) {
         m = __builtin_ctzll(Mv);
         keep = m + 1;
+      } else if (lim < nvalid && ((A >> lim) & 1)) {
+        m = lim;  // first non-clean lane repeats its (clean) predecessor: a certain match
+        adj = true;
+        keep = lim + 1;
       } else {
         keep = lim;
       }
-      // ---- rollback: winners at/after `keep` restore the old entry; a lane-0 loser re-inserts -
+      // ---- table fix-up: (1) winners never reached restore the old entry; (2) committed losers
+      //      re-insert (c0 unless the adjacent match lane right after it overrides the same slot)
       for (int i = keep; i < nvalid; i++)
         if (r[i] == (uint16_t)pos[i]) T[h[i]] = c[i];
-      if ((C & 1) && keep >= 1) T[h[0]] = (uint16_t)pos[0];
+      if (clean0 && c0 < keep && !(adj && c0 == m - 1)) T[h[c0]] = (uint16_t)pos[c0];
+      if (adj) T[h[m]] = (uint16_t)pos[m];
 
       if (m < 0) {
         if (lim == nvalid && nvalid < WAVE) break;  // search loop ran into mflimit: last literals
@@ -186,7 +204,7 @@ extern "C" int lz4_wave_model_compress(const uint8_t* src, int len, uint8_t* dst
 
       // ---- match at lane m -------------------------------------------------------------------
       nb_seq++;
-      int ip = pos[m], match = c[m];
+      int ip = pos[m], match = adj ? pos[m - 1] : c[m];
       // catch-up (backward extension), 64 bytes per round
       for (;;) {
         int maxback = ip - anchor < match ? ip - anchor : match;
