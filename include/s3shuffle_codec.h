@@ -100,11 +100,12 @@ enum {
 /* stages reported by s3s_stage_ms (valid after a call made with S3S_OPT_PROFILE=1) */
 enum {
   S3S_STAGE_TOTAL = 0,      /* first kernel start -> last kernel end of the last call */
-  S3S_STAGE_CODEC = 1,      /* the block compress (or decompress) kernel — the dominant one */
+  S3S_STAGE_CODEC = 1,      /* the block compress (or decompress) kernel ALONE — the dominant one */
   S3S_STAGE_ASSEMBLE = 2,   /* offset scan + frame gather */
   S3S_STAGE_CHECKSUM = 3,   /* per-partition Adler32 / CRC32 */
   S3S_STAGE_DISCOVER = 4,   /* reduce side: frame discovery */
-  S3S_STAGE_COUNT = 5
+  S3S_STAGE_HASH = 5,       /* map side: per-chunk xxHash32 pre-pass (LZ4Block frame check) */
+  S3S_STAGE_COUNT = 6
 };
 
 typedef struct s3s_ctx s3s_ctx;

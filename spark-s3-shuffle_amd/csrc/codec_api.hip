@@ -46,6 +46,7 @@ s3s_ctx* s3s_create(int device_ordinal, int64_t scratch_bytes) {
     return bail("hipStreamCreate", e);
   for (auto& ev : ctx->ev)
     if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = hipEventCreate(&ctx->ev_hash)) != hipSuccess) return bail("hipEventCreate", e);
   // constant tables for the checksum kernels
   const size_t tb = checksum_tables_bytes();
   std::vector<uint8_t> host_tabs(tb);
@@ -69,6 +70,7 @@ void s3s_destroy(s3s_ctx* ctx) {
   if (ctx->h_stage) hipHostFree(ctx->h_stage);
   for (auto& ev : ctx->ev)
     if (ev) hipEventDestroy(ev);
+  if (ctx->ev_hash) hipEventDestroy(ctx->ev_hash);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -151,6 +153,8 @@ int s3s_compress_map_output_device(s3s_ctx* ctx, int codec, int checksum_algo,
   for (int32_t p = 0; p < n; p++)
     if (src_offsets[p + 1] < src_offsets[p]) return fail(ctx, S3S_E_INVALID, "src_offsets not monotonic at %d", p);
   if (dst_capacity < 0) return fail(ctx, S3S_E_INVALID, "negative dst_capacity");
+  if (codec == S3S_CODEC_SNAPPY && !snappy_compress_available())
+    return fail(ctx, S3S_E_UNSUPPORTED, "snappy compression is not available in this build");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
 
   const int64_t bs = effective_block(ctx, codec);
@@ -245,7 +249,7 @@ int s3s_compress_map_output_device(s3s_ctx* ctx, int codec, int checksum_algo,
     if (codec == S3S_CODEC_LZ4)
       launch_lz4_compress(d_src, dev<Item>(ctx, B_ITEMS), n_items, dev<uint32_t>(ctx, B_ITEM_CHECK),
                           dev<uint8_t>(ctx, B_SLOTS), dev<uint32_t>(ctx, B_ITEM_SIZE),
-                          ctx->lz4_variant, ctx->stream);
+                          ctx->lz4_variant, ctx->stream, ctx->profile ? ctx->ev_hash : nullptr);
     else
       launch_snappy_compress(d_src, dev<Item>(ctx, B_ITEMS), n_items, dev<uint8_t>(ctx, B_SLOTS),
                              dev<uint32_t>(ctx, B_ITEM_SIZE), ctx->stream);
@@ -275,6 +279,11 @@ int s3s_compress_map_output_device(s3s_ctx* ctx, int codec, int checksum_algo,
     float ms = 0;
     hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]); ctx->stage_ms[S3S_STAGE_TOTAL] = ms;
     hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); ctx->stage_ms[S3S_STAGE_CODEC] = ms;
+    ctx->stage_ms[S3S_STAGE_HASH] = 0;
+    if (codec == S3S_CODEC_LZ4) {  // split the xxHash32 pre-pass off the compress kernel
+      hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev_hash); ctx->stage_ms[S3S_STAGE_HASH] = ms;
+      hipEventElapsedTime(&ms, ctx->ev_hash, ctx->ev[1]); ctx->stage_ms[S3S_STAGE_CODEC] = ms;
+    }
     hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]); ctx->stage_ms[S3S_STAGE_ASSEMBLE] = ms;
     hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); ctx->stage_ms[S3S_STAGE_CHECKSUM] = ms;
     ctx->stage_ms[S3S_STAGE_DISCOVER] = 0;

@@ -429,10 +429,14 @@ __global__ __launch_bounds__(kXxhThreads) void xxh32_items_kernel(
 
 void launch_lz4_compress(const uint8_t* d_src, const Item* d_items, int32_t n_items,
                          uint32_t* d_item_check, uint8_t* d_slots, uint32_t* d_item_size,
-                         int variant, hipStream_t st) {
-  if (n_items <= 0) return;
+                         int variant, hipStream_t st, hipEvent_t after_hash) {
+  if (n_items <= 0) {
+    if (after_hash) hipEventRecord(after_hash, st);
+    return;
+  }
   hipLaunchKernelGGL(xxh32_items_kernel, dim3((unsigned)((n_items + kXxhThreads / 4 - 1) / (kXxhThreads / 4))),
                      dim3(kXxhThreads), 0, st, d_src, d_items, n_items, kLz4BlockSeed, d_item_check);
+  if (after_hash) hipEventRecord(after_hash, st);
   if (variant == 0)
     hipLaunchKernelGGL(lz4_compress_lds_kernel, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
                        d_items, n_items, d_item_check, d_slots, d_item_size);

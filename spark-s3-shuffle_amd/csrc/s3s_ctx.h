@@ -39,6 +39,7 @@ struct s3s_ctx {
   void* h_stage = nullptr;  // pinned
   size_t h_stage_cap = 0;
   hipEvent_t ev[S3S_STAGE_COUNT + 1] = {};
+  hipEvent_t ev_hash = nullptr;  // between the xxHash32 pre-pass and the LZ4 compress kernel
   double stage_ms[S3S_STAGE_COUNT] = {};
 };
 
