@@ -97,7 +97,7 @@ int s3s_set_option(s3s_ctx* ctx, int key, int64_t value) {
       ctx->profile = value != 0;
       return S3S_OK;
     case S3S_OPT_LZ4_VARIANT:
-      if (value != 0 && value != 1) return fail(ctx, S3S_E_INVALID, "lz4 variant must be 0 or 1");
+      if (value < 0 || value > 2) return fail(ctx, S3S_E_INVALID, "lz4 variant must be 0, 1 or 2");
       ctx->lz4_variant = (int)value;
       return S3S_OK;
   }
@@ -393,5 +393,17 @@ int s3s_checksum_ranges(s3s_ctx* ctx, int algo, const uint8_t* data, const int64
   for (int32_t p = 0; p <= n; p++) rebased[(size_t)p] = offsets[p] - first;
   return s3s_checksum_ranges_device(ctx, algo, dev<uint8_t>(ctx, B_SRC), rebased.data(), n, out);
 }
+
+#ifdef S3S_LZ4_TIMING
+extern __device__ unsigned long long g_lz4_dbg[32];
+int s3s_debug_read(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lz4_dbg), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[32] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_lz4_dbg), z, sizeof z) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 
 }  // extern "C"

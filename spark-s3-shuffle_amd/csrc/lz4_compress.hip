@@ -29,6 +29,15 @@
 // compressedLength >= originalLength), so a slot is 32 B + 32 KiB.
 #include "s3s_internal.h"
 
+#ifdef S3S_LZ4_TIMING
+__device__ unsigned long long g_lz4_dbg[32];
+#define DBG_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define DBG_ADD(slot, val) dbg[slot] += (val)
+#else
+#define DBG_T(var)
+#define DBG_ADD(slot, val)
+#endif
+
 namespace s3s {
 namespace {
 
@@ -66,6 +75,16 @@ struct SrcGlobal {  // chunk read in place (L1/L2)
     return v;
   }
   __device__ __forceinline__ uint32_t rd8(int pos) const { return base[pos]; }
+  __device__ __forceinline__ uint4 ld16(int pos) const {
+    uint4 x;
+    __builtin_memcpy(&x, base + pos, 16);  // unaligned global_load_dwordx4
+    return x;
+  }
+  __device__ __forceinline__ uint2 ld8(int pos) const {
+    uint2 x;
+    __builtin_memcpy(&x, base + pos, 8);
+    return x;
+  }
 };
 
 // n bytes chunk -> global, dword-vectorised on the destination alignment.
@@ -129,16 +148,110 @@ __device__ __forceinline__ int emit_sequence(uint8_t* out, int cap, int op, cons
   return op + total;
 }
 
+
+// lanes [lo,hi) as a 64-bit mask (0 <= lo <= 63, 0 <= hi <= 64)
+__device__ __forceinline__ uint64_t lane_range(int lo, int hi) {
+  const uint64_t top = hi >= 64 ? ~0ull : ((1ull << hi) - 1ull);
+  return hi <= lo ? 0ull : (top & ~((1ull << lo) - 1ull));
+}
+
+// index of the first differing byte of two 16-byte blocks given x = a ^ b (16 if equal)
+__device__ __forceinline__ int first_diff16(uint4 x) {
+  int r = 16;
+  r = x.w ? 12 + (__builtin_ctz(x.w) >> 3) : r;
+  r = x.z ? 8 + (__builtin_ctz(x.z) >> 3) : r;
+  r = x.y ? 4 + (__builtin_ctz(x.y) >> 3) : r;
+  r = x.x ? (__builtin_ctz(x.x) >> 3) : r;
+  return r;
+}
+
+// Cooperative match extension (LZ4 catch-up + LZ4_count), all arguments wave-uniform:
+// backward over the pending literals 64 bytes per round, forward 256 bytes per round.
+// Returns the number of bytes beyond MINMATCH; nback = bytes the match start moves back.
+template <typename Src>
+__device__ __forceinline__ int extend_match(const Src& in, int ip0, int match0, int anchor,
+                                            int matchlimit, int last4, int lane, int& nback) {
+  int ip = ip0, match = match0;
+  int maxback = ip - anchor < match ? ip - anchor : match;
+  uint32_t ba = 0, bb = 1;
+  if (lane < maxback) {
+    ba = in.rd8(ip - 1 - lane);
+    bb = in.rd8(match - 1 - lane);
+  }
+  int fp = ip0 + kMinMatch + 4 * lane;
+  if (Src::kClamp) fp = fp < last4 ? fp : last4;
+  uint32_t x = in.rd32(fp) ^ in.rd32(fp - (ip0 - match0));
+  while (maxback > 0) {
+    const uint64_t E = __ballot(lane < maxback && ba == bb);
+    const int nbk = (~E == 0ull) ? kWave : __builtin_ctzll(~E);
+    ip -= nbk;
+    match -= nbk;
+    if (nbk < kWave) break;
+    maxback -= kWave;
+    if (lane < maxback) {
+      ba = in.rd8(ip - 1 - lane);
+      bb = in.rd8(match - 1 - lane);
+    }
+  }
+  int fwd = 0;
+  for (;;) {
+    const int avail = matchlimit - (ip0 + kMinMatch + fwd);
+    if (avail <= 0) break;
+    const uint64_t D = __ballot(x != 0u);
+    int got = 4 * kWave;
+    if (D) {
+      const int f = __builtin_ctzll(D);
+      const uint32_t xf = __builtin_amdgcn_readlane(x, f);
+      got = 4 * f + (__builtin_ctz(xf) >> 3);
+    }
+    got = got < avail ? got : avail;
+    fwd += got;
+    if (got < 4 * kWave) break;
+    fp = ip0 + kMinMatch + fwd + 4 * lane;
+    if (Src::kClamp) fp = fp < last4 ? fp : last4;
+    x = in.rd32(fp) ^ in.rd32(fp - (ip0 - match0));
+  }
+  nback = ip0 - ip;
+  return fwd;
+}
+
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 
 // The parse.  Returns the compressed size, or -1 if it would exceed len.
-template <typename Src>
+//
+// kFast adds the "exact window" path in front of the general batch (DESIGN.md §6,
+// tests/model/lz4_window_model.cpp is its lock-step CPU model):
+//   the chunk is cut into aligned 64-byte windows, lane i <-> position 64k+i.  While the probe
+//   index of the current run is small, consecutive probes are consecutive bytes, so a whole
+//   window can be prepared with ONE table read and two memory round trips:
+//     cp    = T[h]                      table candidate of every lane (nothing of this window is
+//                                       in the table yet)
+//     Dp    ⊇ lanes that share their hash with an earlier lane of the window (found with two
+//             speculative store passes that are rolled back; which lane wins a same-address
+//             store only decides which superset we get)
+//     Ecp   = lanes whose table candidate matches, with per-lane forward length (<= 64) and
+//             backward equal count (<= 8) loaded and computed speculatively
+//   and then resolved run by run with SCALAR mask arithmetic only.  K collects what the
+//   sequential code inserts (probes and ip-2 positions); for a suspect probe the true candidate
+//   is the highest lane of (same hash) & K below it, else cp.  One store commits K at the end.
+template <typename Src, bool kFast>
 __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t* out, int lane) {
   volatile lds_u16* T = table;  // every access is a real ds_read_u16 / ds_write_b16, in order
   const int mfl1 = len - kMfLimit + 1;  // mflimitPlusOne
   const int matchlimit = len - kLastLiterals;
   const int last4 = len - 4;
   int anchor = 0, op = 0;
+#ifdef S3S_LZ4_TIMING
+  unsigned long long dbg[16] = {0};
+  struct DbgFlush {
+    unsigned long long* d;
+    int lane;
+    __device__ ~DbgFlush() {
+      if (lane == 0)
+        for (int i = 0; i < 16; i++) atomicAdd(&g_lz4_dbg[i], d[i]);
+    }
+  } dbg_flush{dbg, lane};
+#endif
 
   if (len >= kMfLimit + 1) {
     T[hash13(in.rd32(0))] = 0;  // LZ4_putPosition(ip = source); all lanes store the same value
@@ -147,7 +260,203 @@ __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t*
     bool have_pre = true;
     uint32_t vput = 0;  // the 4 bytes at base-2, to insert before the batch (after a match)
     bool put_pending = false;
+    // fast windows: far enough from the end of the chunk that neither mflimit nor matchlimit nor
+    // the end of the buffer can be met by a window's probes and speculative loads
+    const int fast_limit = len - 224;
+    int kn = -1;         // first position of the window whose v is held in vn
+    uint32_t vn = 0;
+    bool force_general = false;
     for (;;) {
+      if constexpr (kFast) {
+        const int wbase = base & ~63;
+        if (!force_general && t0 <= 48 && wbase <= fast_limit) {
+          if (put_pending) T[hash13(vput)] = (uint16_t)(base - 2);  // LZ4_putPosition(ip - 2)
+          put_pending = false;
+          have_pre = false;
+          // ================= window preparation (vector work, every lane = one position) ============
+          DBG_T(tw0);
+          DBG_ADD(8, 1);
+          const int p = wbase + lane;
+          const uint32_t v = (kn == wbase) ? vn : in.rd32(p);
+          vn = in.rd32(p + 64);
+          kn = wbase + 64;
+          const uint32_t h = hash13(v);
+          const int rs0 = base - wbase;
+          const bool live = lane >= rs0;
+          // table candidates, and duplicate-hash groups among the live lanes (two speculative store
+          // passes, rolled back: lanes of a group of >= 2 either lose pass 1 or see pass 2's winner)
+          const uint32_t cp = T[h];
+          bool grp = false;
+          if (live) {
+            T[h] = (uint16_t)p;
+            const uint32_t r1 = T[h];
+            const bool lost1 = r1 != (uint32_t)p;
+            if (lost1) T[h] = (uint16_t)p;
+            const uint32_t r2 = T[h];
+            grp = lost1 || (r2 != (uint32_t)p);
+            if (r2 == (uint32_t)p) T[h] = (uint16_t)cp;  // the slot's current owner restores it
+          }
+          DBG_T(tw1);
+          const uint32_t w = in.rd32((int)cp);
+          const bool em = live && (w == v);
+          DBG_T(tw2x);
+          DBG_ADD(1, tw2x - tw1 + (__ballot(em) & 0));
+          DBG_T(tw2);
+          // per-lane event record: [15:0] table candidate, [22:16] forward length 0..64,
+          // [27:24] backward equal bytes 0..8 (8 = at least, 9 = unknown), [31] suspect lane (member of
+          // a duplicate-hash group)
+          uint32_t info = grp ? 0x80000000u : 0u;
+          if (em) {
+            const int pa = p + kMinMatch, pb = (int)cp + kMinMatch;
+            const uint4 a0 = in.ld16(pa), b0 = in.ld16(pb);
+            const uint4 a1 = in.ld16(pa + 16), b1 = in.ld16(pb + 16);
+            const uint4 a2 = in.ld16(pa + 32), b2 = in.ld16(pb + 32);
+            const uint4 a3 = in.ld16(pa + 48), b3 = in.ld16(pb + 48);
+            uint32_t be = 9;  // 9 = unknown (too close to the start of the chunk), 8 = at least 8
+            if (cp >= 8u && p >= 8) {
+              const uint2 qa = in.ld8(p - 8), qb = in.ld8((int)cp - 8);
+              const uint32_t xh = qa.y ^ qb.y, xl = qa.x ^ qb.x;
+              be = xh ? (uint32_t)(__builtin_clz(xh) >> 3) : (xl ? 4u + (uint32_t)(__builtin_clz(xl) >> 3) : 8u);
+            }
+            int fl = first_diff16(make_uint4(a0.x ^ b0.x, a0.y ^ b0.y, a0.z ^ b0.z, a0.w ^ b0.w));
+            if (fl == 16) {
+              fl = 16 + first_diff16(make_uint4(a1.x ^ b1.x, a1.y ^ b1.y, a1.z ^ b1.z, a1.w ^ b1.w));
+              if (fl == 32) {
+                fl = 32 + first_diff16(make_uint4(a2.x ^ b2.x, a2.y ^ b2.y, a2.z ^ b2.z, a2.w ^ b2.w));
+                if (fl == 48) fl = 48 + first_diff16(make_uint4(a3.x ^ b3.x, a3.y ^ b3.y, a3.z ^ b3.z, a3.w ^ b3.w));
+              }
+            }
+            info = cp | ((uint32_t)fl << 16) | (be << 24) | (grp ? 0x80000000u : 0u);
+          }
+          // vn (issued before every load above) has landed by now: pin it here, before the emit stores,
+          // so that no later use has to drain the in-order vmcnt queue behind those stores
+          asm volatile("" : "+v"(vn));
+          const uint64_t Ecp = __ballot(em);
+          const uint64_t Dp = __ballot(grp);
+          uint64_t ED = Ecp | Dp;  // lanes the run loop has to look at
+          DBG_T(tw3);
+          DBG_ADD(0, tw1 - tw0);
+          DBG_ADD(2, tw3 - tw2 + (__builtin_amdgcn_readfirstlane(info) & 0));
+          // ================= runs (scalar work) ========================================================
+          uint64_t K = 0;      // lanes the sequential code inserts: probes and ip-2 positions
+          int rs = rs0, rt = t0, pend_q = -1;
+          int exit_kind;       // 0: next window / batch, 1: last literals, 2: the general batch takes over
+          // the first run may continue an older one: its probes are consecutive only up to lane e0-1
+          const int e0 = rs0 + 66 - t0;  // t0 <= 48  =>  e0 >= rs0 + 18
+          int elim = e0 < kWave ? e0 : kWave;
+          uint64_t runmask = e0 < kWave ? ((1ull << e0) - 1ull) : ~0ull;
+          for (;;) {
+            const uint64_t cm = ED & runmask & (~0ull << rs);
+            if (cm == 0ull) {  // the run leaves the window (or its consecutive part) without a match
+              K |= runmask & (~0ull << rs);
+              base = wbase + elim;
+              t0 = rt + (elim - rs);
+              exit_kind = elim < kWave ? 2 : 0;
+              break;
+            }
+            const int m = __builtin_ctzll(cm);
+            const uint32_t inf = __builtin_amdgcn_readlane(info, m);
+            const int ip0 = wbase + m;
+            int mpos = (int)(inf & 0xffffu);
+            int fwd = (int)((inf >> 16) & 0x7fu);
+            const int be = (int)((inf >> 24) & 0xfu);
+            const int nbmax = ip0 - anchor;  // (the table candidate of a lane with known be is >= 8)
+            int nb = be < nbmax ? be : nbmax;
+            bool need_ext = fwd >= 64 || (be >= 8 && nbmax > (be == 8 ? 8 : 0));  // a length hit its cap
+            if (__builtin_expect((int)inf < 0, 0)) {
+              // ---- suspect lane: another live lane of the window has the same hash ----------------------
+              const uint64_t bit = 1ull << m;
+              bool is_match = (Ecp & bit) != 0ull;
+              const uint32_t hv = __builtin_amdgcn_readlane(h, m);
+              const uint64_t dk = __ballot(h == hv) & (bit - 1ull) & (K | (runmask & (~0ull << rs)));
+              if (dk) {  // the sequential code's candidate is an earlier position of this window
+                const int d = 63 - __builtin_clzll(dk);
+                is_match = __builtin_amdgcn_readlane(v, d) == __builtin_amdgcn_readlane(v, m);
+                mpos = wbase + d;
+                need_ext = true;
+              }
+              if (!is_match) {
+                ED &= ~bit;  // a plain no-match probe: the run goes on behind it
+                continue;
+              }
+            }
+            if (__builtin_expect(need_ext, 0)) {
+              DBG_T(ts0);
+              fwd = extend_match(in, ip0, mpos, anchor, matchlimit, last4, lane, nb);
+              DBG_T(ts1);
+              DBG_ADD(4, ts1 - ts0);
+              DBG_ADD(10, 1);
+            }
+            DBG_ADD(9, 1);
+            K |= ((2ull << m) - 1ull) & (~0ull << rs);
+            const int lit = ip0 - nb - anchor, offset = ip0 - mpos, mcode = nb + fwd;
+            if (__builtin_expect(anchor >= wbase && lit < 15 && mcode < 15 + 255, 1)) {
+              // every literal is the low byte of a lane's v: lane L stores its own byte, four
+              // otherwise idle lanes store token / offset / match-length byte — one store
+              const int total = 3 + lit + (mcode >= 15 ? 1 : 0);
+              if (op + total > len) return -1;
+              const int rel = (lane - (anchor - wbase)) & 63;
+              uint32_t bv = v & 0xffu;
+              int idx = rel < lit ? 1 + rel : rel;  // literals follow the token; the rest is in place
+              if (rel == lit) {
+                bv = (uint32_t)(lit << 4) | (uint32_t)(mcode < 15 ? mcode : 15);
+                idx = 0;
+              }
+              if (rel == lit + 1) bv = (uint32_t)offset;
+              if (rel == lit + 2) bv = (uint32_t)offset >> 8;
+              if (rel == lit + 3) bv = (uint32_t)(mcode - 15);
+              if (rel < total) out[op + idx] = (uint8_t)bv;
+              op += total;
+            } else {
+              op = emit_sequence(out, len, op, in, anchor, lit, true, offset, mcode, false, 0u, lane);
+              if (op < 0) return -1;
+            }
+            const int ipe = ip0 + kMinMatch + fwd;
+            anchor = ipe;
+            if (__builtin_expect(ipe >= mfl1, 0)) {
+              exit_kind = 1;
+              break;
+            }
+            const int q = ipe - 2 - wbase;  // LZ4_putPosition(ip - 2)
+            if (q < kWave) K |= 1ull << q;
+            else pend_q = q + wbase;
+            if (ipe >= wbase + kWave) {
+              base = ipe;
+              t0 = 0;
+              exit_kind = 0;
+              break;
+            }
+            rs = ipe - wbase;
+            rt = 0;
+            elim = kWave;
+            runmask = ~0ull;
+          }
+          DBG_T(tw4);
+          DBG_ADD(3, tw4 - tw3);
+          if (exit_kind == 1) break;
+          // ================= commit: the highest kept lane of every hash group writes ==================
+          uint64_t Wm = K, sus = K & Dp;
+          while (sus) {
+            const int i = __builtin_ctzll(sus);
+            sus &= sus - 1ull;
+            const uint32_t hv = __builtin_amdgcn_readlane(h, i);
+            if (__ballot(h == hv) & K & ~((2ull << i) - 1ull)) Wm &= ~(1ull << i);
+          }
+          if ((Wm >> lane) & 1ull) T[h] = (uint16_t)p;
+          if (pend_q >= 0) {
+            const uint32_t vq = pend_q < wbase + 2 * kWave
+                                    ? __builtin_amdgcn_readlane(vn, pend_q - wbase - kWave)
+                                    : in.rd32(pend_q);
+            T[hash13(vq)] = (uint16_t)pend_q;
+          }
+          force_general = exit_kind == 2;
+          DBG_T(tw5);
+          DBG_ADD(5, tw5 - tw4);
+          continue;
+        }
+        force_general = false;
+      }
+      DBG_ADD(11, 1);
       // ---- one batch: lane i evaluates probe t0+i of the current no-match run ----------------
       int pos, nvalid;
       if (t0 <= 2) {  // probes 0..65 of a run are consecutive bytes
@@ -220,50 +529,9 @@ __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t*
       const int ip0 = (int)__builtin_amdgcn_readlane((uint32_t)pos, m);
       const int match0 = adj ? (int)__builtin_amdgcn_readlane((uint32_t)pos, m - 1)
                              : (int)__builtin_amdgcn_readlane(c, m);
-      int ip = ip0, match = match0;
-      // both extensions read independent bytes: issue them together
-      // backward: catch-up over pending literals, 64 bytes per round
-      int maxback = ip - anchor < match ? ip - anchor : match;
-      uint32_t ba = 0, bb = 1;
-      if (lane < maxback) {
-        ba = in.rd8(ip - 1 - lane);
-        bb = in.rd8(match - 1 - lane);
-      }
-      // forward count from the 4 matched bytes, 256 bytes per round (LZ4_count to matchlimit);
-      // dwords starting at or beyond matchlimit never count, so clamping their address is free
-      int fp = ip0 + kMinMatch + 4 * lane;
-      if (Src::kClamp) fp = fp < last4 ? fp : last4;
-      uint32_t x = in.rd32(fp) ^ in.rd32(fp - (ip0 - match0));
-      while (maxback > 0) {
-        const uint64_t E = __ballot(lane < maxback && ba == bb);
-        const int nbk = (~E == 0ull) ? kWave : __builtin_ctzll(~E);
-        ip -= nbk;
-        match -= nbk;
-        if (nbk < kWave) break;
-        maxback -= kWave;
-        if (lane < maxback) {
-          ba = in.rd8(ip - 1 - lane);
-          bb = in.rd8(match - 1 - lane);
-        }
-      }
-      int fwd = 0;
-      for (;;) {
-        const int avail = matchlimit - (ip0 + kMinMatch + fwd);
-        if (avail <= 0) break;
-        const uint64_t D = __ballot(x != 0u);
-        int got = 4 * kWave;
-        if (D) {
-          const int f = __builtin_ctzll(D);
-          const uint32_t xf = __builtin_amdgcn_readlane(x, f);
-          got = 4 * f + (__builtin_ctz(xf) >> 3);
-        }
-        got = got < avail ? got : avail;
-        fwd += got;
-        if (got < 4 * kWave) break;
-        fp = ip0 + kMinMatch + fwd + 4 * lane;
-        if (Src::kClamp) fp = fp < last4 ? fp : last4;
-        x = in.rd32(fp) ^ in.rd32(fp - (ip0 - match0));
-      }
+      int nb = 0;
+      const int fwd = extend_match(in, ip0, match0, anchor, matchlimit, last4, lane, nb);
+      const int ip = ip0 - nb, match = match0 - nb;
       const int ipe = ip0 + kMinMatch + fwd;  // first byte after the match
       // prefetch what the next batch needs while the sequence is being written out
       if (ipe < mfl1) {
@@ -272,7 +540,7 @@ __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t*
         have_pre = true;
         put_pending = true;
       }
-      const int mcode = (ip0 - ip) + fwd;  // bytes beyond MINMATCH, counted from the moved-back ip
+      const int mcode = nb + fwd;  // bytes beyond MINMATCH, counted from the moved-back ip
       // literals: when the run started with this batch (post-match probe at `anchor`), output
       // byte k (1 <= k <= lit) is the low byte of probe k-1, i.e. of the lane to the left
       const bool lit_in_regs = (t0 == 0) && (anchor == base);
@@ -343,11 +611,12 @@ __global__ __launch_bounds__(kWave) void lz4_compress_lds_kernel(
   }
   __syncthreads();
   uint8_t* slot = slots + (size_t)item.chunk * kSlotBytes;
-  const int clen = lz4_compress_wave(SrcLds{s.in}, (lds_u16*)s.table, len, slot + kSlotHeader, lane);
+  const int clen = lz4_compress_wave<SrcLds, false>(SrcLds{s.in}, (lds_u16*)s.table, len, slot + kSlotHeader, lane);
   finish_frame(slot, len, clen, item_check[it], item.kind >> 8, item_size + it, lane);
 }
 
 // ---- variant B: chunk read in place, only the table in LDS ----------------------------------
+template <bool kFast>
 __global__ __launch_bounds__(kWave) void lz4_compress_l2_kernel(
     const uint8_t* __restrict__ src, const Item* __restrict__ items, int32_t n_items,
     const uint32_t* __restrict__ item_check, uint8_t* __restrict__ slots,
@@ -368,8 +637,8 @@ __global__ __launch_bounds__(kWave) void lz4_compress_l2_kernel(
   }
   __syncthreads();
   uint8_t* slot = slots + (size_t)item.chunk * kSlotBytes;
-  const int clen = lz4_compress_wave(SrcGlobal{src + item.src_off}, (lds_u16*)table, item.len,
-                                     slot + kSlotHeader, lane);
+  const int clen = lz4_compress_wave<SrcGlobal, kFast>(SrcGlobal{src + item.src_off}, (lds_u16*)table,
+                                                      item.len, slot + kSlotHeader, lane);
   finish_frame(slot, item.len, clen, item_check[it], item.kind >> 8, item_size + it, lane);
 }
 
@@ -440,8 +709,11 @@ void launch_lz4_compress(const uint8_t* d_src, const Item* d_items, int32_t n_it
   if (variant == 0)
     hipLaunchKernelGGL(lz4_compress_lds_kernel, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
                        d_items, n_items, d_item_check, d_slots, d_item_size);
+  else if (variant == 1)
+    hipLaunchKernelGGL(lz4_compress_l2_kernel<false>, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
+                       d_items, n_items, d_item_check, d_slots, d_item_size);
   else
-    hipLaunchKernelGGL(lz4_compress_l2_kernel, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
+    hipLaunchKernelGGL(lz4_compress_l2_kernel<true>, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
                        d_items, n_items, d_item_check, d_slots, d_item_size);
 }
 

@@ -46,7 +46,8 @@ constexpr uint32_t kRawFlag = 0x80000000u;
 // ---- kernel launchers (each defined next to its kernel) ---------------------------------
 // LZ4: compress every kItemLz4Chunk item into its slot, write the frame header, item_size.
 //   d_item_check: per-item xxHash32 workspace (written by the xxh32 pre-pass)
-//   variant 0: chunk staged in LDS (3 wavefronts/CU); 1: chunk read through L1/L2 (10/CU)
+//   variant 0: chunk staged in LDS (3 wavefronts/CU); 1: chunk read through L1/L2 (10/CU);
+//   2: as 1 plus the window-speculative parse (default)
 void launch_lz4_compress(const uint8_t* d_src, const Item* d_items, int32_t n_items,
                          uint32_t* d_item_check, uint8_t* d_slots, uint32_t* d_item_size,
                          int variant, hipStream_t st, hipEvent_t after_hash = nullptr);

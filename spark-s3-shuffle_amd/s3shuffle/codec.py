@@ -39,6 +39,11 @@ class CodecError(RuntimeError):
 
 
 def library_path() -> str:
+    """The product library; S3S_CODEC_LIB selects another build of the SAME library (e.g. the
+    instrumented one used by tools/lz4_timing.py) — never a fallback implementation."""
+    override = os.environ.get("S3S_CODEC_LIB")
+    if override:
+        return override
     return os.path.join(_PKG_ROOT, "lib", "libs3shuffle_codec.so")
 
 

@@ -11,7 +11,7 @@ LZ4, SNAPPY, NONE = 1, 2, 0
 ADLER, CRC = 1, 2
 
 
-@pytest.fixture(params=[0, 1], ids=["chunk-in-lds", "chunk-in-l2"], autouse=True)
+@pytest.fixture(params=[0, 1, 2], ids=["chunk-in-lds", "chunk-in-l2", "window"], autouse=True)
 def lz4_variant(request, gpu_codec):
     """Every test runs against both placements of the chunk bytes (S3S_OPT_LZ4_VARIANT)."""
     gpu_codec.set_option(4, request.param)
