@@ -234,7 +234,7 @@ typedef __attribute__((address_space(3))) uint16_t lds_u16;
 //   and then resolved run by run with SCALAR mask arithmetic only.  K collects what the
 //   sequential code inserts (probes and ip-2 positions); for a suspect probe the true candidate
 //   is the highest lane of (same hash) & K below it, else cp.  One store commits K at the end.
-template <typename Src, bool kFast>
+template <typename Src, int kMode>
 __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t* out, int lane) {
   volatile lds_u16* T = table;  // every access is a real ds_read_u16 / ds_write_b16, in order
   const int mfl1 = len - kMfLimit + 1;  // mflimitPlusOne
@@ -263,11 +263,266 @@ __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t*
     // fast windows: far enough from the end of the chunk that neither mflimit nor matchlimit nor
     // the end of the buffer can be met by a window's probes and speculative loads
     const int fast_limit = len - 224;
+    const int pipe_limit = len - 448;  // pipelined windows prefetch up to 323 bytes ahead
     int kn = -1;         // first position of the window whose v is held in vn
     uint32_t vn = 0;
     bool force_general = false;
     for (;;) {
-      if constexpr (kFast) {
+      if constexpr (kMode == 2) {
+        // ===== pipelined exact windows: window k is resolved while the loads of k+1, k+2, k+3 fly =====
+        //   stage A  v   = rd32(position)                 issued 3 windows ahead
+        //   stage B  cp  = T[hash(v)], w = rd32(cp)       table snapshot + candidate bytes, 2 ahead
+        //   stage C  em  = (w == v), 64+8 bytes at p and cp for the em lanes ("raw")   1 ahead
+        //   stage D  info = lengths from raw                        at the start of the window's turn
+        // A snapshot is validated when its window is resolved: cp' = T[h] again; a lane is stale iff
+        // cp' != cp.  Everything inserted since the snapshot lies in [wbase-128, p), i.e. in the v
+        // registers of this and the two previous windows, so a stale lane's match test is a
+        // cross-lane read; its lengths come from the cooperative extension.
+        if (!force_general && t0 <= 48 && (base & ~63) <= pipe_limit) {
+          if (put_pending) T[hash13(vput)] = (uint16_t)(base - 2);  // LZ4_putPosition(ip - 2)
+          put_pending = false;
+          have_pre = false;
+          int wbase = base & ~63;
+          // ---- (re)start: fill the pipeline synchronously ---------------------------------------------
+          uint32_t v0 = in.rd32(wbase + lane), v1 = in.rd32(wbase + 64 + lane);
+          uint32_t v2 = in.rd32(wbase + 128 + lane), vA = in.rd32(wbase + 192 + lane);
+          uint32_t vm1 = in.rd32((wbase >= 64 ? wbase - 64 : 0) + lane);
+          uint32_t vm2 = in.rd32((wbase >= 128 ? wbase - 128 : 0) + lane);
+          uint32_t cp0 = T[hash13(v0)], cp1 = T[hash13(v1)], cp2 = T[hash13(v2)];
+          uint32_t wN;
+          uint32_t info0;
+          uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;  // raw: 64 bytes behind p+4 and behind cp+4
+          uint2 rqa, rqb;                                // raw: 8 bytes in front of p and of cp
+          bool rem;                                      // raw belongs to an em lane
+#define S3S_STAGE_C(VV, CP, WW, WB)                                                   \
+  {                                                                                   \
+    rem = (WW) == (VV);                                                               \
+    if (rem) {                                                                        \
+      const int pa_ = (WB) + lane + kMinMatch, pb_ = (int)(CP) + kMinMatch;           \
+      ra0 = in.ld16(pa_), rb0 = in.ld16(pb_);                                         \
+      ra1 = in.ld16(pa_ + 16), rb1 = in.ld16(pb_ + 16);                               \
+      ra2 = in.ld16(pa_ + 32), rb2 = in.ld16(pb_ + 32);                               \
+      ra3 = in.ld16(pa_ + 48), rb3 = in.ld16(pb_ + 48);                               \
+      const int qa_ = (WB) + lane >= 8 ? (WB) + lane - 8 : 0;                         \
+      const int qb_ = (CP) >= 8u ? (int)(CP) - 8 : 0;                                 \
+      rqa = in.ld8(qa_), rqb = in.ld8(qb_);                                           \
+    }                                                                                 \
+  }
+#define S3S_STAGE_D(CP, WB, INFO)                                                     \
+  {                                                                                   \
+    INFO = 0u;                                                                        \
+    if (rem) {                                                                        \
+      uint32_t be_ = 9;                                                               \
+      if ((CP) >= 8u && (WB) + lane >= 8) {                                           \
+        const uint32_t xh_ = rqa.y ^ rqb.y, xl_ = rqa.x ^ rqb.x;                      \
+        be_ = xh_ ? (uint32_t)(__builtin_clz(xh_) >> 3)                               \
+                  : (xl_ ? 4u + (uint32_t)(__builtin_clz(xl_) >> 3) : 8u);            \
+      }                                                                               \
+      int fl_ = first_diff16(make_uint4(ra0.x ^ rb0.x, ra0.y ^ rb0.y, ra0.z ^ rb0.z, ra0.w ^ rb0.w)); \
+      if (fl_ == 16) {                                                                \
+        fl_ = 16 + first_diff16(make_uint4(ra1.x ^ rb1.x, ra1.y ^ rb1.y, ra1.z ^ rb1.z, ra1.w ^ rb1.w)); \
+        if (fl_ == 32) {                                                              \
+          fl_ = 32 + first_diff16(make_uint4(ra2.x ^ rb2.x, ra2.y ^ rb2.y, ra2.z ^ rb2.z, ra2.w ^ rb2.w)); \
+          if (fl_ == 48)                                                              \
+            fl_ = 48 + first_diff16(make_uint4(ra3.x ^ rb3.x, ra3.y ^ rb3.y, ra3.z ^ rb3.z, ra3.w ^ rb3.w)); \
+        }                                                                             \
+      }                                                                               \
+      INFO = (CP) | ((uint32_t)fl_ << 16) | (be_ << 24) | 0x20000000u;                \
+    }                                                                                 \
+  }
+          {
+            const uint32_t w0 = in.rd32((int)cp0), w1 = in.rd32((int)cp1);
+            wN = in.rd32((int)cp2);
+            S3S_STAGE_C(v0, cp0, w0, wbase);
+            S3S_STAGE_D(cp0, wbase, info0);
+            S3S_STAGE_C(v1, cp1, w1, wbase + 64);  // raw(k+1) stays in flight
+          }
+          // ---- steady state: one window per iteration -------------------------------------------------
+          int exit_kind = 0;  // 0: leave to the outer loop, 1: last literals, 2: the general batch takes over
+          int pend_far = -1;
+          for (;;) {
+            DBG_ADD(8, 1);
+            DBG_T(pa);
+            const int p = wbase + lane;
+            const uint32_t h = hash13(v0);
+            const int rs0 = base - wbase;
+            const bool live = lane >= rs0;
+            // fresh candidates + duplicate-hash groups among the live lanes (rolled back)
+            const uint32_t cpn = T[h];
+            bool grp = false;
+            if (live) {
+              T[h] = (uint16_t)p;
+              const uint32_t r1 = T[h];
+              const bool lost1 = r1 != (uint32_t)p;
+              if (lost1) T[h] = (uint16_t)p;
+              const uint32_t r2 = T[h];
+              grp = lost1 || (r2 != (uint32_t)p);
+              if (r2 == (uint32_t)p) T[h] = (uint16_t)cpn;
+            }
+            // info: [15:0] candidate [22:16] forward 0..64 [27:24] backward 0..8 / 9 unknown
+            //       [29] candidate matches [30] lengths unknown (stale snapshot) [31] suspect lane
+            uint32_t info = info0;
+            const bool stale = live && (cpn != cp0);
+            if (__ballot(stale)) {
+              const int idx = (int)(cpn & 63u);
+              const int dwin = (wbase - (int)(cpn & ~63u)) >> 6;  // 0, 1 or 2 windows back
+              uint32_t sv = __shfl(v0, idx);
+              const uint32_t s1 = __shfl(vm1, idx), s2 = __shfl(vm2, idx);
+              sv = dwin == 1 ? s1 : sv;
+              sv = dwin == 2 ? s2 : sv;
+              // (dwin <= 2 by construction: everything inserted since the snapshot is in these windows)
+              if (stale) info = (sv == v0) ? (cpn | 0x60000000u) : 0u;
+            }
+            const bool em = live && ((info & 0x20000000u) != 0u);
+            if (grp) info |= 0x80000000u;
+            const uint64_t Ecp = __ballot(em);
+            const uint64_t Dp = __ballot(grp);
+            uint64_t ED = Ecp | Dp;
+            DBG_T(pb);
+            DBG_ADD(0, pb - pa);
+            // ---- runs (scalar) ---------------------------------------------------------------------------
+            uint64_t K = 0;
+            int rs = rs0, rt = t0, pend_q = -1;
+            const int e0 = rs0 + 66 - t0;
+            int elim = e0 < kWave ? e0 : kWave;
+            uint64_t runmask = e0 < kWave ? ((1ull << e0) - 1ull) : ~0ull;
+            for (;;) {
+              const uint64_t cm = ED & runmask & (~0ull << rs);
+              if (cm == 0ull) {
+                K |= runmask & (~0ull << rs);
+                base = wbase + elim;
+                t0 = rt + (elim - rs);
+                exit_kind = elim < kWave ? 2 : 0;
+                break;
+              }
+              const int m = __builtin_ctzll(cm);
+              const uint32_t inf = __builtin_amdgcn_readlane(info, m);
+              const int ip0 = wbase + m;
+              int mpos = (int)(inf & 0xffffu);
+              int fwd = (int)((inf >> 16) & 0x7fu);
+              const int be = (int)((inf >> 24) & 0xfu);
+              const int nbmax = ip0 - anchor;
+              int nb = be < nbmax ? be : nbmax;
+              bool need_ext = fwd >= 64 || (be >= 8 && nbmax > (be == 8 ? 8 : 0)) || (inf & 0x40000000u) != 0u;
+              if (__builtin_expect((int)inf < 0, 0)) {
+                const uint64_t bit = 1ull << m;
+                bool is_match = (Ecp & bit) != 0ull;
+                const uint32_t hv = __builtin_amdgcn_readlane(h, m);
+                const uint64_t dk = __ballot(h == hv) & (bit - 1ull) & (K | (runmask & (~0ull << rs)));
+                if (dk) {
+                  const int d = 63 - __builtin_clzll(dk);
+                  is_match = __builtin_amdgcn_readlane(v0, d) == __builtin_amdgcn_readlane(v0, m);
+                  mpos = wbase + d;
+                  need_ext = true;
+                }
+                if (!is_match) {
+                  ED &= ~bit;
+                  continue;
+                }
+              }
+              if (__builtin_expect(need_ext, 0)) {
+                DBG_ADD(10, 1);
+                fwd = extend_match(in, ip0, mpos, anchor, matchlimit, last4, lane, nb);
+              }
+              DBG_ADD(9, 1);
+              K |= ((2ull << m) - 1ull) & (~0ull << rs);
+              const int lit = ip0 - nb - anchor, offset = ip0 - mpos, mcode = nb + fwd;
+              if (__builtin_expect(anchor >= wbase && lit < 15 && mcode < 15 + 255, 1)) {
+                const int total = 3 + lit + (mcode >= 15 ? 1 : 0);
+                if (op + total > len) return -1;
+                const int rel = (lane - (anchor - wbase)) & 63;
+                uint32_t bv = v0 & 0xffu;
+                int idx = rel < lit ? 1 + rel : rel;
+                if (rel == lit) {
+                  bv = (uint32_t)(lit << 4) | (uint32_t)(mcode < 15 ? mcode : 15);
+                  idx = 0;
+                }
+                if (rel == lit + 1) bv = (uint32_t)offset;
+                if (rel == lit + 2) bv = (uint32_t)offset >> 8;
+                if (rel == lit + 3) bv = (uint32_t)(mcode - 15);
+#ifndef S3S_ABL_NOSTORE
+                if (rel < total) out[op + idx] = (uint8_t)bv;
+#else
+                asm volatile("" ::"v"(bv), "v"(idx));
+#endif
+                op += total;
+              } else {
+                op = emit_sequence(out, len, op, in, anchor, lit, true, offset, mcode, false, 0u, lane);
+                if (op < 0) return -1;
+              }
+              const int ipe = ip0 + kMinMatch + fwd;
+              anchor = ipe;
+              if (__builtin_expect(ipe >= mfl1, 0)) {
+                exit_kind = 1;
+                break;
+              }
+              const int q = ipe - 2 - wbase;
+              if (q < kWave) K |= 1ull << q;
+              else pend_q = q + wbase;
+              if (ipe >= wbase + kWave) {
+                base = ipe;
+                t0 = 0;
+                exit_kind = 0;
+                break;
+              }
+              rs = ipe - wbase;
+              rt = 0;
+              elim = kWave;
+              runmask = ~0ull;
+            }
+            DBG_T(pc);
+            DBG_ADD(3, pc - pb);
+            if (exit_kind == 1) break;
+            // ---- commit ---------------------------------------------------------------------------------
+            uint64_t Wm = K, sus = K & Dp;
+            while (sus) {
+              const int i = __builtin_ctzll(sus);
+              sus &= sus - 1ull;
+              const uint32_t hv = __builtin_amdgcn_readlane(h, i);
+              if (__ballot(h == hv) & K & ~((2ull << i) - 1ull)) Wm &= ~(1ull << i);
+            }
+            if ((Wm >> lane) & 1ull) T[h] = (uint16_t)p;
+            if (pend_q >= 0) {
+              if (pend_q < wbase + 3 * kWave) {
+                const uint32_t vq = pend_q < wbase + 2 * kWave
+                                        ? __builtin_amdgcn_readlane(v1, pend_q - wbase - kWave)
+                                        : __builtin_amdgcn_readlane(v2, pend_q - wbase - 2 * kWave);
+                T[hash13(vq)] = (uint16_t)pend_q;
+                pend_q = -1;
+              } else {
+                pend_far = pend_q;  // beyond the pipeline: inserted after the loop (it ends here)
+              }
+            }
+            DBG_T(pd);
+            DBG_ADD(5, pd - pc);
+            // ---- advance: only a step into the very next window keeps the pipeline -----------------------
+            if (exit_kind != 0 || t0 > 48 || (base & ~63) != wbase + kWave || wbase + kWave > pipe_limit) break;
+            wbase += kWave;
+            S3S_STAGE_D(cp1, wbase, info0);              // raw(k+1) -> info of the new current window
+            vm2 = vm1;
+            vm1 = v0;
+            v0 = v1;
+            cp0 = cp1;
+            v1 = v2;
+            cp1 = cp2;
+            S3S_STAGE_C(v1, cp1, wN, wbase + 64);        // w of the new k+1 landed long ago
+            v2 = vA;
+            cp2 = T[hash13(v2)];
+            wN = in.rd32((int)cp2);
+            vA = in.rd32(wbase + 192 + lane);
+            DBG_T(pe);
+            DBG_ADD(2, pe - pd);
+          }
+#undef S3S_STAGE_C
+#undef S3S_STAGE_D
+          if (exit_kind == 1) break;
+          if (pend_far >= 0) T[hash13(in.rd32(pend_far))] = (uint16_t)pend_far;  // LZ4_putPosition(ip - 2)
+          force_general = exit_kind == 2;
+          continue;
+        }
+        force_general = false;
+      }
+      if constexpr (kMode == 1) {
         const int wbase = base & ~63;
         if (!force_general && t0 <= 48 && wbase <= fast_limit) {
           if (put_pending) T[hash13(vput)] = (uint16_t)(base - 2);  // LZ4_putPosition(ip - 2)
@@ -611,12 +866,12 @@ __global__ __launch_bounds__(kWave) void lz4_compress_lds_kernel(
   }
   __syncthreads();
   uint8_t* slot = slots + (size_t)item.chunk * kSlotBytes;
-  const int clen = lz4_compress_wave<SrcLds, false>(SrcLds{s.in}, (lds_u16*)s.table, len, slot + kSlotHeader, lane);
+  const int clen = lz4_compress_wave<SrcLds, 0>(SrcLds{s.in}, (lds_u16*)s.table, len, slot + kSlotHeader, lane);
   finish_frame(slot, len, clen, item_check[it], item.kind >> 8, item_size + it, lane);
 }
 
 // ---- variant B: chunk read in place, only the table in LDS ----------------------------------
-template <bool kFast>
+template <int kMode>
 __global__ __launch_bounds__(kWave) void lz4_compress_l2_kernel(
     const uint8_t* __restrict__ src, const Item* __restrict__ items, int32_t n_items,
     const uint32_t* __restrict__ item_check, uint8_t* __restrict__ slots,
@@ -637,7 +892,7 @@ __global__ __launch_bounds__(kWave) void lz4_compress_l2_kernel(
   }
   __syncthreads();
   uint8_t* slot = slots + (size_t)item.chunk * kSlotBytes;
-  const int clen = lz4_compress_wave<SrcGlobal, kFast>(SrcGlobal{src + item.src_off}, (lds_u16*)table,
+  const int clen = lz4_compress_wave<SrcGlobal, kMode>(SrcGlobal{src + item.src_off}, (lds_u16*)table,
                                                       item.len, slot + kSlotHeader, lane);
   finish_frame(slot, item.len, clen, item_check[it], item.kind >> 8, item_size + it, lane);
 }
@@ -710,10 +965,13 @@ void launch_lz4_compress(const uint8_t* d_src, const Item* d_items, int32_t n_it
     hipLaunchKernelGGL(lz4_compress_lds_kernel, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
                        d_items, n_items, d_item_check, d_slots, d_item_size);
   else if (variant == 1)
-    hipLaunchKernelGGL(lz4_compress_l2_kernel<false>, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
+    hipLaunchKernelGGL(lz4_compress_l2_kernel<0>, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
+                       d_items, n_items, d_item_check, d_slots, d_item_size);
+  else if (variant == 2)
+    hipLaunchKernelGGL(lz4_compress_l2_kernel<1>, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
                        d_items, n_items, d_item_check, d_slots, d_item_size);
   else
-    hipLaunchKernelGGL(lz4_compress_l2_kernel<true>, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
+    hipLaunchKernelGGL(lz4_compress_l2_kernel<2>, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
                        d_items, n_items, d_item_check, d_slots, d_item_size);
 }
 

@@ -20,8 +20,8 @@ d_src = torch.from_numpy(data).cuda()
 cap = c.max_compressed_size(1, offs)
 d_dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
 torch.cuda.synchronize()
-names = ["prep_lds", "w_wait", "phaseB", "runs", "slow_ext", "commit", "", "", "windows", "seqs", "slow", "general"]
-for variant in (2,):
+names = ["validate", "w_wait", "advance", "runs", "slow_ext", "commit", "", "", "windows", "seqs", "slow", "general"]
+for variant in (3,):
     c.set_option(4, variant)
     for it in range(2):
         buf = (ctypes.c_ulonglong * 32)()
