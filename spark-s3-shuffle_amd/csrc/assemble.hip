@@ -71,7 +71,7 @@ __device__ __forceinline__ void copy_bytes(uint8_t* __restrict__ dst, const uint
 
 __global__ __launch_bounds__(kGatherThreads) void gather_items_kernel(
     const uint8_t* __restrict__ src, const Item* __restrict__ items, int32_t n_items,
-    const uint8_t* __restrict__ slots, const uint32_t* __restrict__ item_size,
+    const uint8_t* __restrict__ slots, int64_t slot_stride, const uint32_t* __restrict__ item_size,
     const int64_t* __restrict__ item_off, uint8_t* __restrict__ dst, int64_t dst_capacity,
     int32_t* __restrict__ status) {
   const int it = blockIdx.x;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kGatherThreads) void gather_items_kernel(
     }
     return;
   }
-  const uint8_t* slot = slots + (size_t)item.chunk * kSlotBytes;
+  const uint8_t* slot = slots + (size_t)item.chunk * (size_t)slot_stride;
   if (kind == kItemLz4Chunk) {
     if (sz & kRawFlag) {
       copy_bytes(d, slot + (kSlotHeader - kLz4FrameHeader), kLz4FrameHeader, tid);
@@ -131,12 +131,12 @@ void launch_scan_items(const Item*, const uint32_t* d_item_size, int32_t n_items
 }
 
 void launch_gather_items(const uint8_t* d_src, const Item* d_items, int32_t n_items,
-                         const uint8_t* d_slots, const uint32_t* d_item_size,
+                         const uint8_t* d_slots, int64_t slot_stride, const uint32_t* d_item_size,
                          const int64_t* d_item_off, uint8_t* d_dst, int64_t dst_capacity,
                          int32_t* d_status, hipStream_t st) {
   if (n_items <= 0) return;
   hipLaunchKernelGGL(gather_items_kernel, dim3((unsigned)n_items), dim3(kGatherThreads), 0, st,
-                     d_src, d_items, n_items, d_slots, d_item_size, d_item_off, d_dst,
+                     d_src, d_items, n_items, d_slots, slot_stride, d_item_size, d_item_off, d_dst,
                      dst_capacity, d_status);
 }
 

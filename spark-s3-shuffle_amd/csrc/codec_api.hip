@@ -237,7 +237,12 @@ int s3s_compress_map_output_device(s3s_ctx* ctx, int codec, int checksum_algo,
   } else {
     if ((rc = ensure(ctx, B_ITEMS, items_bytes + 16))) return rc;
     if ((rc = ensure(ctx, B_PART_FIRST, pf_bytes))) return rc;
-    if ((rc = ensure(ctx, B_SLOTS, (size_t)kSlotBytes * (size_t)(n_chunks > 0 ? n_chunks : 1)))) return rc;
+    // a slot holds one chunk's codec output: LZ4 payloads never exceed the chunk (RAW fallback), a raw
+    // snappy block can grow to MaxCompressedLength(chunk)
+    const int64_t slot_stride = codec == S3S_CODEC_SNAPPY
+                                    ? (int64_t)kSlotHeader + ((snappy_max_len(bs) + 15) & ~int64_t(15))
+                                    : (int64_t)kSlotBytes;
+    if ((rc = ensure(ctx, B_SLOTS, (size_t)slot_stride * (size_t)(n_chunks > 0 ? n_chunks : 1)))) return rc;
     if ((rc = ensure(ctx, B_ITEM_SIZE, sizeof(uint32_t) * (size_t)(n_items + 1)))) return rc;
     if ((rc = ensure(ctx, B_ITEM_OFF, sizeof(int64_t) * (size_t)(n_items + 1)))) return rc;
     if ((rc = ensure(ctx, B_ITEM_CHECK, sizeof(uint32_t) * (size_t)(n_items + 1)))) return rc;
@@ -252,13 +257,13 @@ int s3s_compress_map_output_device(s3s_ctx* ctx, int codec, int checksum_algo,
                           ctx->lz4_variant, ctx->stream, ctx->profile ? ctx->ev_hash : nullptr);
     else
       launch_snappy_compress(d_src, dev<Item>(ctx, B_ITEMS), n_items, dev<uint8_t>(ctx, B_SLOTS),
-                             dev<uint32_t>(ctx, B_ITEM_SIZE), ctx->stream);
+                             slot_stride, dev<uint32_t>(ctx, B_ITEM_SIZE), ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     record(ctx, 1);
     launch_scan_items(dev<Item>(ctx, B_ITEMS), dev<uint32_t>(ctx, B_ITEM_SIZE), n_items,
                       dev<int64_t>(ctx, B_ITEM_OFF), dev<int32_t>(ctx, B_PART_FIRST), n,
                       dev<int64_t>(ctx, B_INDEX), ctx->stream);
-    launch_gather_items(d_src, dev<Item>(ctx, B_ITEMS), n_items, dev<uint8_t>(ctx, B_SLOTS),
+    launch_gather_items(d_src, dev<Item>(ctx, B_ITEMS), n_items, dev<uint8_t>(ctx, B_SLOTS), slot_stride,
                         dev<uint32_t>(ctx, B_ITEM_SIZE), dev<int64_t>(ctx, B_ITEM_OFF), d_dst,
                         dst_capacity, dev<int32_t>(ctx, B_STATUS), ctx->stream);
     HIP_TRY(ctx, hipGetLastError());

@@ -187,7 +187,58 @@ int s3s_decompress_range_device(s3s_ctx* ctx, int codec, int checksum_algo, cons
     return S3S_OK;
   }
 
-  if (codec == S3S_CODEC_SNAPPY) return fail(ctx, S3S_E_UNSUPPORTED, "snappy decode not available in this build");
+  if (codec == S3S_CODEC_SNAPPY) {
+    // ---- SnappyInputStream framing: count chunks per partition, scan, emit frames, decode ---------
+    if (comp_len == 0 || n == 0) {
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      if ((rc = verify_sums())) return rc;
+      return S3S_OK;
+    }
+    if (!do_sum) {
+      for (int32_t p = 0; p <= n; p++) h_off[p] = part_offsets[p];
+      if ((rc = ensure(ctx, B_OFFSETS, off_bytes))) return rc;
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_OFFSETS].p, h_off, off_bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    const size_t cnt_bytes = (sizeof(uint32_t) * (size_t)(n + 1) + 15) & ~size_t(15);
+    if ((rc = ensure(ctx, B_PART_NFRAMES, cnt_bytes + sizeof(int64_t) * (size_t)(n + 2)))) return rc;
+    uint32_t* d_cnt = dev<uint32_t>(ctx, B_PART_NFRAMES);
+    int64_t* d_base = reinterpret_cast<int64_t*>(dev<uint8_t>(ctx, B_PART_NFRAMES) + cnt_bytes);
+    launch_snappy_count_frames(d_comp, dev<int64_t>(ctx, B_OFFSETS), n, d_cnt, dev<int32_t>(ctx, B_STATUS), ctx->stream);
+    launch_scan_u32(d_cnt, n, d_base, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(&h_misc[0], d_base + n, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(&h_misc[1], ctx->buf[B_STATUS].p, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = verify_sums())) return rc;
+    if (*reinterpret_cast<int32_t*>(&h_misc[1]) != 0) return fail(ctx, S3S_E_BAD_FRAME, "Stream is corrupted (snappy chunk chain)");
+    const int64_t n_frames = h_misc[0];
+    if (n_frames > 0x7fffff00ll) return fail(ctx, S3S_E_UNSUPPORTED, "too many frames in one call");
+    if ((rc = ensure(ctx, B_FRAMES, sizeof(Frame) * (size_t)(n_frames + 1)))) return rc;
+    if ((rc = ensure(ctx, B_ITEM_SIZE, sizeof(uint32_t) * (size_t)(n_frames + 1)))) return rc;
+    if ((rc = ensure(ctx, B_FRAME_OUT, sizeof(int64_t) * (size_t)(n_frames + 1)))) return rc;
+    launch_snappy_emit_frames(d_comp, dev<int64_t>(ctx, B_OFFSETS), n, d_base, dev<Frame>(ctx, B_FRAMES),
+                              dev<uint32_t>(ctx, B_ITEM_SIZE), dev<int32_t>(ctx, B_STATUS), ctx->stream);
+    launch_scan_u32(dev<uint32_t>(ctx, B_ITEM_SIZE), n_frames, dev<int64_t>(ctx, B_FRAME_OUT), ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(&h_misc[0], dev<int64_t>(ctx, B_FRAME_OUT) + n_frames, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    record(ctx, 2);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t total = h_misc[0];
+    if (out_len) *out_len = total;
+    if (total > dst_capacity)
+      return fail(ctx, S3S_E_CAPACITY, "dst_capacity %lld < %lld decoded bytes", (long long)dst_capacity, (long long)total);
+    launch_snappy_decompress(d_comp, dev<Frame>(ctx, B_FRAMES), (int32_t)n_frames, dev<int64_t>(ctx, B_FRAME_OUT),
+                             d_dst, dev<int32_t>(ctx, B_STATUS), ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    record(ctx, 3);
+    HIP_TRY(ctx, hipMemcpyAsync(&h_misc[1], ctx->buf[B_STATUS].p, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    finish_profile(3);
+    const int32_t st = *reinterpret_cast<int32_t*>(&h_misc[1]);
+    if (st == S3S_E_UNSUPPORTED) return fail(ctx, S3S_E_UNSUPPORTED, "snappy block larger than %d bytes", kMaxBlock);
+    if (st != 0) return fail(ctx, S3S_E_BAD_FRAME, "Stream is corrupted");
+    return S3S_OK;
+  }
 
   // ---- LZ4Block: discover the frame chain --------------------------------------------------------
   if (comp_len == 0) {

@@ -426,6 +426,10 @@ void launch_lz4_emit_frames(const uint8_t* d_comp, int64_t comp_len, int32_t n_t
                      d_frame_out);
 }
 
+void launch_scan_u32(const uint32_t* d_in, int64_t n, int64_t* d_out, hipStream_t st) {
+  hipLaunchKernelGGL(scan_u32_kernel, dim3(1), dim3(kScanThreads), 0, st, d_in, n, d_out);
+}
+
 void launch_lz4_decompress(const uint8_t* d_comp, const Frame* d_frames, int32_t n_frames,
                            const int64_t* d_frame_out, uint8_t* d_dst, int32_t* d_status,
                            hipStream_t st) {

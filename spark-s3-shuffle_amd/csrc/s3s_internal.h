@@ -53,15 +53,17 @@ void launch_lz4_compress(const uint8_t* d_src, const Item* d_items, int32_t n_it
                          int variant, hipStream_t st, hipEvent_t after_hash = nullptr);
 // Snappy: same for kItemSnappyChunk.
 bool snappy_compress_available();
+//   slot_stride: bytes between slots (a raw snappy block can be larger than its chunk)
 void launch_snappy_compress(const uint8_t* d_src, const Item* d_items, int32_t n_items,
-                            uint8_t* d_slots, uint32_t* d_item_size, hipStream_t st);
+                            uint8_t* d_slots, int64_t slot_stride, uint32_t* d_item_size,
+                            hipStream_t st);
 // exclusive scan of item sizes + partition index extraction
 void launch_scan_items(const Item* d_items, const uint32_t* d_item_size, int32_t n_items,
                        int64_t* d_item_off, const int32_t* d_part_first, int32_t n_parts,
                        int64_t* d_index, hipStream_t st);
 // copy every item to its place in the .data image; sets *d_status != 0 on capacity overflow
 void launch_gather_items(const uint8_t* d_src, const Item* d_items, int32_t n_items,
-                         const uint8_t* d_slots, const uint32_t* d_item_size,
+                         const uint8_t* d_slots, int64_t slot_stride, const uint32_t* d_item_size,
                          const int64_t* d_item_off, uint8_t* d_dst, int64_t dst_capacity,
                          int32_t* d_status, hipStream_t st);
 // per-range Adler32 / CRC32: out[i] over data[offsets[i], offsets[i+1])
@@ -100,11 +102,15 @@ void launch_lz4_emit_frames(const uint8_t* d_comp, int64_t comp_len, int32_t n_t
 void launch_lz4_decompress(const uint8_t* d_comp, const Frame* d_frames, int32_t n_frames,
                            const int64_t* d_frame_out, uint8_t* d_dst, int32_t* d_status,
                            hipStream_t st);
-// Snappy (SnappyInputStream framing): chunks are chained by their i32 BE length only, so the
-// walk is one lane per partition stream (each partition starts with the 16-byte header).
-void launch_snappy_discover(const uint8_t* d_comp, const int64_t* d_part_off, int32_t n_parts,
-                            int32_t max_frames_per_part, Frame* d_frames, uint32_t* d_frame_orig,
-                            int32_t* d_part_nframes, int32_t* d_status, hipStream_t st);
+// Snappy (SnappyInputStream framing): chunks are chained by their i32 BE length only, so the walk
+// is one lane per partition (each non-empty partition is one or more complete streams, each
+// starting with the 16-byte header).  Pass 1 counts, pass 2 (after a scan of the counts) writes
+// d_frames / d_frame_orig at d_frame_base[partition].
+void launch_snappy_count_frames(const uint8_t* d_comp, const int64_t* d_part_off, int32_t n_parts,
+                                uint32_t* d_part_nframes, int32_t* d_status, hipStream_t st);
+void launch_snappy_emit_frames(const uint8_t* d_comp, const int64_t* d_part_off, int32_t n_parts,
+                               const int64_t* d_frame_base, Frame* d_frames, uint32_t* d_frame_orig,
+                               int32_t* d_status, hipStream_t st);
 void launch_snappy_decompress(const uint8_t* d_comp, const Frame* d_frames, int32_t n_frames,
                               const int64_t* d_frame_out, uint8_t* d_dst, int32_t* d_status,
                               hipStream_t st);

@@ -56,3 +56,59 @@ def test_model_stats_on_terasort(model, oracle):
     got = _run(model, d, 2, 7, stats)
     assert np.array_equal(got, oracle.lz4_compress_block(d))
     assert stats[0] > 0 and stats[2] > 0
+
+
+# ---- Snappy -------------------------------------------------------------------------------------
+SN_SRC = os.path.join(HERE, "model", "snappy_wave_model.cpp")
+SN_SO = os.path.join(HERE, "model", "libsnappy_wave_model.so")
+
+
+@pytest.fixture(scope="module")
+def sn_model():
+    if not os.path.exists(SN_SO) or os.path.getmtime(SN_SO) < os.path.getmtime(SN_SRC):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", SN_SO, SN_SRC], check=True)
+    L = ctypes.CDLL(SN_SO)
+    L.snappy_wave_model_compress.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                             ctypes.c_uint64, ctypes.c_void_p]
+    return L
+
+
+@pytest.mark.parametrize("kind", range(corpus.N_KINDS))
+def test_snappy_model_matches_oracle(sn_model, oracle, kind):
+    rng = np.random.default_rng(700 + kind)
+    for n in [1, 14, 15, 16, 20, 64, 65, 130, 1000, 4096, 18442, 20000, 32767, 32768]:
+        if kind == 6 and n > 6000:
+            continue
+        d = corpus.chunk_corpus(kind, n, rng)
+        want = oracle.snappy_compress_block(d)
+        for mode in (0, 1, 2):
+            out = np.empty(d.size + d.size // 6 + 64, np.uint8)
+            m = sn_model.snappy_wave_model_compress(d.ctypes.data, d.size, out.ctypes.data, mode, n, None)
+            assert np.array_equal(out[:m], want), (kind, n, mode)
+
+
+def test_window_model_matches_oracle(oracle):
+    """Exact-window parse (tests/model/lz4_window_model.cpp): fast windows + general batches, with
+    candidate snapshots taken 0..2 windows early, must equal the oracle byte for byte."""
+    src = os.path.join(HERE, "model", "lz4_window_model.cpp")
+    so = os.path.join(HERE, "model", "liblz4_window_model.so")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src], check=True)
+    L = ctypes.CDLL(so)
+    L.lz4_window_model_compress.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                            ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_void_p]
+    for kind in range(corpus.N_KINDS):
+        rng = np.random.default_rng(500 + kind)
+        for n in [13, 64, 65, 129, 1000, 4096, 32768]:
+            if kind == 6 and n > 6000:
+                continue
+            d = corpus.chunk_corpus(kind, n, rng)
+            want = oracle.lz4_compress_block(d)
+            for la in (0, 2):
+                out = np.empty(d.size + 64, np.uint8)
+                m = L.lz4_window_model_compress(d.ctypes.data, d.size, out.ctypes.data, 2, n, 1, 64, 8, la, None)
+                if m < 0:
+                    assert want.size >= d.size
+                else:
+                    assert np.array_equal(out[:m], want), (kind, n, la)
