@@ -40,8 +40,9 @@ HBM_COPY_CEILING_GBPS = 6290.0  # measured float4-copy ceiling, same guide
 WORKLOADS = {
     # name: (generator, partitions, codec, checksum)
     "terasort-10g-200p-lz4": ("terasort", 200, "lz4", "adler32"),     # configs[1]  (N=1 headline)
+    "tpcds-wide-100g-200p-snappy": ("tpcds", 200, "snappy", "adler32"),   # configs[2]
     "terasort-100g-2000p-lz4-crc32": ("terasort", 2000, "lz4", "crc32"),  # configs[3]
-    "skew-1part-lz4": ("skew", 1, "lz4", "adler32"),                  # configs[4] compress side
+    "skew-1part-lz4": ("skew", 1, "lz4", "adler32"),                  # configs[4] (use --direction decompress)
 }
 
 
@@ -56,6 +57,8 @@ def parse_args():
     ap.add_argument("--task-threads", type=int, default=1,
                     help="concurrent task threads per GPU, one s3s_ctx (stream) each")
     ap.add_argument("--lz4-variant", type=int, default=-1, help="S3S_OPT_LZ4_VARIANT override")
+    ap.add_argument("--direction", default="compress", choices=["compress", "decompress"],
+                    help="decompress = reduce-side verify + decode of the same map outputs (batch-fetch range)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU leg")
     ap.add_argument("--verify", action="store_true", help="check one map task against the oracle first")
@@ -68,7 +71,25 @@ def make_map_output(workload: str, map_id: int, n_bytes: int):
     gen, nparts, _, _ = WORKLOADS[workload]
     if gen == "terasort":
         return datagen.terasort_map_output(n_bytes, nparts, seed=2, map_id=map_id)
+    if gen == "tpcds":
+        return datagen.tpcds_wide_map_output(n_bytes, nparts, seed=3, map_id=map_id)
     return datagen.skew_block(n_bytes, "terasort", seed=5, map_id=map_id)
+
+
+def usable_cores() -> int:
+    """Host threads this process may really use: min(affinity mask, cgroup cpu.max quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return n
 
 
 def cpu_baseline(workload: str, target_s: float):
@@ -78,29 +99,33 @@ def cpu_baseline(workload: str, target_s: float):
     from oracle import binding as oracle
 
     _, nparts, codec, algo = WORKLOADS[workload]
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     sample_mib = 32
     parts = max(1, nparts * sample_mib // 128)  # same bytes per partition as the GPU workload
     from s3shuffle import datagen
     if WORKLOADS[workload][0] == "terasort":
         data, offs = datagen.terasort_map_output(sample_mib << 20, parts, seed=2, map_id=0)
+    elif WORKLOADS[workload][0] == "tpcds":
+        data, offs = datagen.tpcds_wide_map_output(sample_mib << 20, parts, seed=3, map_id=0)
     else:
         data, offs = datagen.skew_block(sample_mib << 20, "terasort", seed=5, map_id=0)
     algo_id = {"adler32": oracle.CHECKSUM_ADLER32, "crc32": oracle.CHECKSUM_CRC32}[algo]
-    have_liblz4 = bool(oracle.lib().s3o_mt_have_liblz4())
+    codec_o = oracle.CODEC_LZ4 if codec == "lz4" else oracle.CODEC_SNAPPY
+    have_liblz4 = bool(oracle.lib().s3o_mt_have_liblz4()) and codec == "lz4"
     # calibrate with one rep, then size the run to ~target_s
-    s1, _ = oracle.mt_compress_bench(oracle.CODEC_LZ4, algo_id, data, offs, cores, reps=1)
+    s1, _ = oracle.mt_compress_bench(codec_o, algo_id, data, offs, cores, reps=1)
     reps = max(1, min(400, int(target_s / max(s1, 1e-3))))
-    s, _ = oracle.mt_compress_bench(oracle.CODEC_LZ4, algo_id, data, offs, cores, reps=reps)
+    s, _ = oracle.mt_compress_bench(codec_o, algo_id, data, offs, cores, reps=reps)
     value = data.size * cores * reps / s / 1e9
-    t1, _ = oracle.mt_compress_bench(oracle.CODEC_LZ4, algo_id, data, offs, 1, reps=2)
+    t1, _ = oracle.mt_compress_bench(codec_o, algo_id, data, offs, 1, reps=2)
     one = data.size * 2 / t1 / 1e9
     return {
         "value": round(value, 3), "unit": "GB/s", "cores": cores, "kind": "port",
-        "sample": f"{cores} threads x {reps} reps x one {sample_mib} MiB TeraSort map-task slice "
-                  f"({parts} partitions), LZ4Block+{algo}; block compressor = "
+        "sample": f"{cores} threads x {reps} reps x one {sample_mib} MiB map-task slice of the workload "
+                  f"({parts} partitions), {codec}+{algo}, map-side compress+checksum; block compressor = "
                   f"{'liblz4 1.9.3 LZ4_compress_default (the code lz4-java JNI binds)' if have_liblz4 else 'oracle restatement'}; "
-                  f"JVM/JNI overheads not included (upper bound on the reference path)",
+                  f"JVM/JNI overheads not included (upper bound on the reference path); "
+                  f"os.cpu_count()={os.cpu_count()}, cgroup/affinity limit={cores}",
         "single_thread_GBps": round(one, 3), "wall_s": round(s, 2),
     }
 
@@ -131,7 +156,7 @@ def main():
         dist = dist_mod
 
     gen, nparts, codec_name, algo_name = WORKLOADS[args.workload]
-    codec_id = s3shuffle.CODEC_LZ4
+    codec_id = s3shuffle.CODEC_LZ4 if codec_name == "lz4" else s3shuffle.CODEC_SNAPPY
     algo_id = {"adler32": s3shuffle.CHECKSUM_ADLER32, "crc32": s3shuffle.CHECKSUM_CRC32}[algo_name]
 
     # ---- this rank's shard: map tasks with mapId % nGPU == rank --------------------------------
@@ -169,7 +194,7 @@ def main():
         t = tasks[0]
         total, index, sums = codecs[0].compress_map_output_device(codec_id, algo_id, t["src"].data_ptr(), offs,
                                                                   t["dst"].data_ptr(), t["cap"])
-        r_img, r_index, r_sums = oracle.compress_map_output(oracle.CODEC_LZ4, algo_id, data, offs)
+        r_img, r_index, r_sums = oracle.compress_map_output(codec_id, algo_id, data, offs)
         img = t["dst"][:total].cpu().numpy()
         assert np.array_equal(index, r_index) and np.array_equal(sums, r_sums) and np.array_equal(img, r_img), \
             "GPU output differs from the oracle"
@@ -180,6 +205,19 @@ def main():
     comp_bytes = [0] * len(tasks)
     lock = threading.Lock()
 
+    decompress = args.direction == "decompress"
+    if decompress:
+        # reduce side: every map output is first compressed once (untimed); the timed step verifies the
+        # per-partition checksums and decodes the whole range [index[0], index[N]) — a
+        # ShuffleBlockBatchId-style batch fetch of all partitions of the map output
+        for i, t in enumerate(tasks):
+            total, index, sums = codecs[0].compress_map_output_device(codec_id, algo_id, t["src"].data_ptr(), t["offs"],
+                                                                      t["dst"].data_ptr(), t["cap"])
+            t["total"], t["index"], t["sums"] = total, index, sums
+            t["out"] = torch.empty(t["u"], dtype=torch.uint8, device=dev)
+            comp_bytes[i] = total
+        torch.cuda.synchronize()
+
     def run_step(record: bool):
         def worker(tid):
             c = codecs[tid]
@@ -187,9 +225,14 @@ def main():
             n = 0
             for i in range(tid, len(tasks), n_threads):
                 t = tasks[i]
-                total, _, _ = c.compress_map_output_device(codec_id, algo_id, t["src"].data_ptr(), t["offs"],
-                                                           t["dst"].data_ptr(), t["cap"])
-                comp_bytes[i] = total
+                if decompress:
+                    got = c.decompress_range_device(codec_id, algo_id, t["dst"].data_ptr(), t["total"], t["index"],
+                                                    t["sums"], t["out"].data_ptr(), t["u"])
+                    assert got == t["u"]
+                else:
+                    total, _, _ = c.compress_map_output_device(codec_id, algo_id, t["src"].data_ptr(), t["offs"],
+                                                               t["dst"].data_ptr(), t["cap"])
+                    comp_bytes[i] = total
                 if record:
                     acc[0] += c.stage_ms(s3shuffle.codec.STAGE_CODEC)
                     acc[1] += c.stage_ms(s3shuffle.codec.STAGE_HASH)
@@ -243,11 +286,14 @@ def main():
         codec_ms = stage["codec"] / launches          # the LZ4 block-compress kernel alone
         u_launch = u_rank / len(tasks)
         c_launch = c_rank / len(tasks)
-        payload_launch = c_launch - 21.0 * (u_launch / 32768.0 + nparts)  # frame headers come later
-        alg_bytes = u_launch + max(payload_launch, 0.0)  # chunk bytes read + payload bytes written
+        if codec_name == "lz4" and not decompress:
+            payload_launch = c_launch - 21.0 * (u_launch / 32768.0 + nparts)  # frame headers come later
+        else:
+            payload_launch = c_launch
+        alg_bytes = u_launch + max(payload_launch, 0.0)  # chunk bytes read + payload bytes written (or the reverse)
         achieved = alg_bytes / (codec_ms * 1e-3) / 1e9 if codec_ms > 0 else 0.0
         out = {
-            "metric": "shuffle_block_compress_checksum_throughput",
+            "metric": "shuffle_block_verify_decompress_throughput" if decompress else "shuffle_block_compress_checksum_throughput",
             "value": round(value, 3),
             "unit": "GB/s",
             "n_gpus": world,
@@ -262,7 +308,9 @@ def main():
             "config": {
                 "workload": args.workload,
                 "generator": "TeraGen-like 100-byte records, seed 2" if gen == "terasort" else "TeraGen-like skew block, seed 5",
-                "codec": "lz4 (LZ4Block frames, 32 KiB blocks, bit-exact with lz4-java/liblz4 1.9.3)",
+                "direction": args.direction,
+                "codec": "lz4 (LZ4Block frames, 32 KiB blocks, bit-exact with lz4-java/liblz4 1.9.3)" if codec_name == "lz4"
+                         else "snappy (SnappyOutputStream framing, 32 KiB blocks, byte-exact with snappy 1.1.8)",
                 "checksum": algo_name,
                 "partitions_per_map_task": nparts,
                 "map_task_bytes": tasks[0]["u"],
@@ -276,7 +324,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "lz4_compress (one wavefront per 32 KiB block)",
+                "kernel": ("%s_decompress (one workgroup per frame)" if decompress else "%s_compress (one wavefront per 32 KiB block)") % codec_name,
                 "achieved": round(achieved, 3),
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
@@ -289,7 +337,7 @@ def main():
             },
             "stages_ms_per_map_task": {k: round(stage[k] / launches, 4) for k in ("hash", "codec", "assemble", "checksum", "total")},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not decompress:
             cb = cpu_baseline(args.workload, args.cpu_seconds)
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_all_cores"] = round(value / cb["value"], 3)

@@ -48,3 +48,12 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
             out["pmc"].setdefault(k, {}).update({cn: v[0] for cn, v in cs.items()})
             print(f"  {k:42s}", {cn: round(v[0], 1) for cn, v in cs.items()}, "launches=", max(v[1] for v in cs.values()))
 json.dump(out, open(os.path.join(root, "summary.json"), "w"), indent=1)
+# HBM traffic of the dominant kernel per launch: 2 x FETCH_SIZE (gfx950 half-count, calibrated on
+# xxh32_items_kernel which reads its input exactly once) + WRITE_SIZE, KB -> bytes
+for k, c in out["pmc"].items():
+    if k.startswith("lz4_compress") and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        t = {"kernel": k, "lz4_compress_hbm_bytes_per_launch": int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024),
+             "fetch_kb": c["FETCH_SIZE"], "write_kb": c["WRITE_SIZE"],
+             "xxh32_fetch_kb (calibration: input read once)": out["pmc"].get("xxh32_items_kernel", {}).get("FETCH_SIZE")}
+        json.dump(t, open(os.path.join(root, "traffic.json"), "w"), indent=1)
+        print("== traffic", t)
