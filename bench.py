@@ -54,9 +54,12 @@ def parse_args():
     ap.add_argument("--workload", default="terasort-10g-200p-lz4", choices=sorted(WORKLOADS))
     ap.add_argument("--map-mib", type=int, default=128, help="uncompressed MiB per map task (input split)")
     ap.add_argument("--maps-per-gpu", type=int, default=8)
-    ap.add_argument("--task-threads", type=int, default=1,
-                    help="concurrent task threads per GPU, one s3s_ctx (stream) each")
+    ap.add_argument("--task-threads", type=int, default=2,
+                    help="concurrent task threads per GPU, one s3s_ctx (HIP stream) each — an executor runs "
+                         "several tasks at once (spark.executor.cores = 4 in the reference's examples); 2 keeps "
+                         "the GPU busy across the tail of each map task's launch")
     ap.add_argument("--lz4-variant", type=int, default=-1, help="S3S_OPT_LZ4_VARIANT override")
+    ap.add_argument("--lz4-decode-variant", type=int, default=-1, help="S3S_OPT_LZ4_DECODE_VARIANT override")
     ap.add_argument("--direction", default="compress", choices=["compress", "decompress"],
                     help="decompress = reduce-side verify + decode of the same map outputs (batch-fetch range)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -180,6 +183,8 @@ def main():
         c.set_option(s3shuffle.codec.OPT_PROFILE, 1)
         if args.lz4_variant >= 0:
             c.set_option(s3shuffle.codec.OPT_LZ4_VARIANT, args.lz4_variant)
+        if args.lz4_decode_variant >= 0:
+            c.set_option(s3shuffle.codec.OPT_LZ4_DECODE_VARIANT, args.lz4_decode_variant)
     for (data, offs) in outputs:
         d_src = torch.from_numpy(data).to(dev)
         cap = codecs[0].max_compressed_size(codec_id, offs)

@@ -92,9 +92,12 @@ enum {
                                     supported 1024..32768 (snappy-java raises smaller values
                                     to 1024) */
   S3S_OPT_PROFILE = 3,           /* 1: record per-stage HIP-event timings (s3s_stage_ms) */
-  S3S_OPT_LZ4_VARIANT = 4        /* tuning, identical output: 0 = chunk staged in LDS (3
+  S3S_OPT_LZ4_VARIANT = 4,       /* tuning, identical output: 0 = chunk staged in LDS (3
                                     wavefronts per CU), 1 = chunk read through L1/L2, table-only
-                                    LDS (10 per CU; default), 2 = 1 + window-speculative parse */
+                                    LDS (10 per CU; default), 2 = 1 + window-speculative parse,
+                                    3 = 2 with software-pipelined windows */
+  S3S_OPT_LZ4_DECODE_VARIANT = 5 /* tuning, identical output: 0 = frame staged in LDS,
+                                    1 = decoded straight to global memory (no LDS) */
 };
 
 /* stages reported by s3s_stage_ms (valid after a call made with S3S_OPT_PROFILE=1) */

@@ -96,6 +96,10 @@ int s3s_set_option(s3s_ctx* ctx, int key, int64_t value) {
     case S3S_OPT_PROFILE:
       ctx->profile = value != 0;
       return S3S_OK;
+    case S3S_OPT_LZ4_DECODE_VARIANT:
+      if (value != 0 && value != 1) return fail(ctx, S3S_E_INVALID, "lz4 decode variant must be 0 or 1");
+      ctx->lz4_decode_variant = (int)value;
+      return S3S_OK;
     case S3S_OPT_LZ4_VARIANT:
       if (value < 0 || value > 3) return fail(ctx, S3S_E_INVALID, "lz4 variant must be 0..3");
       ctx->lz4_variant = (int)value;
@@ -111,6 +115,7 @@ int64_t s3s_get_option(const s3s_ctx* ctx, int key) {
     case S3S_OPT_SNAPPY_BLOCK_SIZE: return ctx->snappy_block;
     case S3S_OPT_PROFILE: return ctx->profile;
     case S3S_OPT_LZ4_VARIANT: return ctx->lz4_variant;
+    case S3S_OPT_LZ4_DECODE_VARIANT: return ctx->lz4_decode_variant;
   }
   return S3S_E_INVALID;
 }
@@ -400,6 +405,15 @@ int s3s_checksum_ranges(s3s_ctx* ctx, int algo, const uint8_t* data, const int64
 }
 
 #ifdef S3S_LZ4_TIMING
+extern __device__ unsigned long long g_dec_dbg[16];
+int s3s_debug_read_dec(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dec_dbg), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_dec_dbg), z, sizeof z) != hipSuccess) return -1;
+  }
+  return 0;
+}
 extern __device__ unsigned long long g_lz4_dbg[32];
 int s3s_debug_read(unsigned long long* out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lz4_dbg), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;

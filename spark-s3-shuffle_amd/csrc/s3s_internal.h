@@ -99,9 +99,10 @@ void launch_lz4_emit_frames(const uint8_t* d_comp, int64_t comp_len, int32_t n_t
                             const int64_t* d_true_entry, const int64_t* d_frame_base,
                             Frame* d_frames, uint32_t* d_frame_orig, int64_t n_frames,
                             int64_t* d_frame_out, int32_t* d_status, hipStream_t st);
+//   variant 0: frame staged in LDS (3 frames per CU); 1: straight to global memory (no LDS)
 void launch_lz4_decompress(const uint8_t* d_comp, const Frame* d_frames, int32_t n_frames,
                            const int64_t* d_frame_out, uint8_t* d_dst, int32_t* d_status,
-                           hipStream_t st);
+                           int variant, hipStream_t st);
 // Snappy (SnappyInputStream framing): chunks are chained by their i32 BE length only, so the walk
 // is one lane per partition (each non-empty partition is one or more complete streams, each
 // starting with the 16-byte header).  Pass 1 counts, pass 2 (after a scan of the counts) writes

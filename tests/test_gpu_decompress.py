@@ -12,6 +12,15 @@ LZ4, NONE = 1, 0
 ADLER, CRC = 1, 2
 
 
+@pytest.fixture(params=[0, 1], ids=["frame-in-lds", "frame-in-global"], autouse=True)
+def lz4_decode_variant(request, gpu_codec):
+    """Every test runs against both decoders (S3S_OPT_LZ4_DECODE_VARIANT)."""
+    default = gpu_codec.get_option(5)
+    gpu_codec.set_option(5, request.param)
+    yield request.param
+    gpu_codec.set_option(5, default)
+
+
 def _oracle_image(oracle, codec, algo, data, offsets, block_size=32768):
     return oracle.compress_map_output(codec, algo, data, offsets, block_size)
 
