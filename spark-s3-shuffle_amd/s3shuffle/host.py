@@ -1,0 +1,182 @@
+"""ctypes binding of the C++ host-side mirror (spark-s3-shuffle_amd/host/s3shuffle_host.h): the
+reference plugin's data-plane classes restated on top of the codec C-ABI.  Test/bench plumbing."""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import List, Tuple
+
+import numpy as np
+
+from .codec import load_library
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = None
+
+KIND_SHUFFLE, KIND_BATCH, KIND_DATA, KIND_INDEX, KIND_CHECKSUM = 0, 1, 2, 3, 4
+
+
+class SparkException(RuntimeError):
+    pass
+
+
+class IOException(RuntimeError):
+    pass
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        load_library()  # the codec library first (dependency)
+        path = os.path.join(_PKG_ROOT, "lib", "libs3shuffle_host.so")
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} is missing: build it with `make -C spark-s3-shuffle_amd/host`")
+        L = ctypes.CDLL(path)
+        L.s3sh_last_error.restype = ctypes.c_char_p
+        L.s3sh_dispatcher_create.restype = ctypes.c_void_p
+        L.s3sh_dispatcher_create.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+        vp = ctypes.c_void_p
+        L.s3sh_dispatcher_destroy.argtypes = [vp]
+        L.s3sh_get_path.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
+        L.s3sh_device_for_map.argtypes = [vp, ctypes.c_longlong]
+        L.s3sh_write_partition_lengths.argtypes = [vp, ctypes.c_int, ctypes.c_longlong, vp, ctypes.c_int]
+        L.s3sh_read_block_as_array.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_longlong, vp, ctypes.c_int, vp]
+        L.s3sh_remove_shuffle.argtypes = [vp, ctypes.c_int]
+        L.s3sh_remove_root.argtypes = [vp]
+        L.s3sh_writer_create.restype = vp
+        L.s3sh_writer_create.argtypes = [vp, ctypes.c_int, ctypes.c_longlong, ctypes.c_int]
+        L.s3sh_writer_destroy.argtypes = [vp]
+        L.s3sh_writer_get_partition_writer.argtypes = [vp, ctypes.c_int]
+        L.s3sh_writer_write.argtypes = [vp, vp, ctypes.c_longlong]
+        L.s3sh_writer_close_partition.argtypes = [vp]
+        L.s3sh_writer_num_bytes_written.restype = ctypes.c_longlong
+        L.s3sh_writer_num_bytes_written.argtypes = [vp]
+        L.s3sh_writer_commit.argtypes = [vp, vp]
+        L.s3sh_writer_abort.argtypes = [vp]
+        L.s3sh_reader_read.restype = vp
+        L.s3sh_reader_read.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.s3sh_result_count.argtypes = [vp]
+        L.s3sh_result_block_len.restype = ctypes.c_longlong
+        L.s3sh_result_block_len.argtypes = [vp, ctypes.c_int]
+        L.s3sh_result_block_info.argtypes = [vp, ctypes.c_int, vp, vp, vp, ctypes.c_char_p, ctypes.c_int]
+        L.s3sh_result_block_copy.argtypes = [vp, ctypes.c_int, vp]
+        L.s3sh_result_destroy.argtypes = [vp]
+        _LIB = L
+    return _LIB
+
+
+def _check(rc: int):
+    if rc == 0:
+        return
+    msg = _lib().s3sh_last_error().decode()
+    if rc == -2:
+        raise SparkException(msg)
+    if rc == -3:
+        raise IOException(msg)
+    raise RuntimeError(msg)
+
+
+class Dispatcher:
+    """S3ShuffleDispatcher (config + path scheme + local block store)."""
+
+    def __init__(self, root_dir: str, app_id: str = "app", folder_prefixes: int = 10, always_create_index: bool = False,
+                 checksum_enabled: bool = True, checksum_algorithm: str = "ADLER32", compress: bool = True,
+                 codec: str = "lz4", block_size: int = 32768, num_gpus: int = 0):
+        self._h = _lib().s3sh_dispatcher_create(root_dir.encode(), app_id.encode(), folder_prefixes, int(always_create_index),
+                                                int(checksum_enabled), checksum_algorithm.encode(), int(compress),
+                                                codec.encode(), block_size, num_gpus)
+        if not self._h:
+            _check(-1)
+
+    def close(self):
+        if self._h:
+            _lib().s3sh_dispatcher_destroy(self._h)
+            self._h = None
+
+    def get_path(self, kind: int, shuffle_id: int, map_id: int, r0: int = 0, r1: int = 1) -> str:
+        buf = ctypes.create_string_buffer(1024)
+        _check(_lib().s3sh_get_path(self._h, kind, shuffle_id, map_id, r0, r1, buf, 1024))
+        return buf.value.decode()
+
+    def device_for_map(self, map_id: int) -> int:
+        return int(_lib().s3sh_device_for_map(self._h, map_id))
+
+    def write_partition_lengths(self, shuffle_id: int, map_id: int, lengths):
+        a = np.ascontiguousarray(lengths, dtype=np.int64)
+        _check(_lib().s3sh_write_partition_lengths(self._h, shuffle_id, map_id, a.ctypes.data, a.size))
+
+    def read_block_as_array(self, kind: int, shuffle_id: int, map_id: int) -> np.ndarray:
+        out = np.zeros(1 << 16, np.int64)
+        n = ctypes.c_int(0)
+        _check(_lib().s3sh_read_block_as_array(self._h, kind, shuffle_id, map_id, out.ctypes.data, out.size, ctypes.byref(n)))
+        return out[: n.value].copy()
+
+    def remove_shuffle(self, shuffle_id: int):
+        _check(_lib().s3sh_remove_shuffle(self._h, shuffle_id))
+
+    def remove_root(self):
+        _check(_lib().s3sh_remove_root(self._h))
+
+
+class MapOutputWriter:
+    """S3ShuffleMapOutputWriter + its partition writer streams."""
+
+    def __init__(self, dispatcher: Dispatcher, shuffle_id: int, map_id: int, num_partitions: int):
+        self._n = num_partitions
+        self._h = _lib().s3sh_writer_create(dispatcher._h, shuffle_id, map_id, num_partitions)
+        if not self._h:
+            _check(-1)
+
+    def get_partition_writer(self, reduce_partition_id: int):
+        _check(_lib().s3sh_writer_get_partition_writer(self._h, reduce_partition_id))
+
+    def write(self, data):
+        a = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray)) else data, dtype=np.uint8)
+        _check(_lib().s3sh_writer_write(self._h, a.ctypes.data, a.size))
+
+    def close_partition(self):
+        _check(_lib().s3sh_writer_close_partition(self._h))
+
+    def num_bytes_written(self) -> int:
+        return int(_lib().s3sh_writer_num_bytes_written(self._h))
+
+    def commit_all_partitions(self) -> np.ndarray:
+        out = np.zeros(max(self._n, 1), np.int64)
+        _check(_lib().s3sh_writer_commit(self._h, out.ctypes.data))
+        return out[: self._n]
+
+    def abort(self):
+        _check(_lib().s3sh_writer_abort(self._h))
+
+    def close(self):
+        if self._h:
+            _lib().s3sh_writer_destroy(self._h)
+            self._h = None
+
+
+def read_shuffle(dispatcher: Dispatcher, shuffle_id: int, start_partition: int, end_partition: int,
+                 do_batch_fetch: bool) -> List[Tuple[str, int, int, int, np.ndarray]]:
+    """S3ShuffleReader.read(): [(block name, mapId, r0, r1, decoded bytes)]."""
+    L = _lib()
+    r = L.s3sh_reader_read(dispatcher._h, shuffle_id, start_partition, end_partition, int(do_batch_fetch))
+    if not r:
+        msg = L.s3sh_last_error().decode()
+        if msg.startswith("SparkException"):
+            raise SparkException(msg)
+        if msg.startswith("IOException"):
+            raise IOException(msg)
+        raise RuntimeError(msg)
+    out = []
+    try:
+        for i in range(L.s3sh_result_count(r)):
+            n = L.s3sh_result_block_len(r, i)
+            buf = np.empty(max(n, 1), np.uint8)
+            L.s3sh_result_block_copy(r, i, buf.ctypes.data)
+            m, r0, r1 = ctypes.c_longlong(0), ctypes.c_int(0), ctypes.c_int(0)
+            name = ctypes.create_string_buffer(128)
+            L.s3sh_result_block_info(r, i, ctypes.byref(m), ctypes.byref(r0), ctypes.byref(r1), name, 128)
+            out.append((name.value.decode(), int(m.value), int(r0.value), int(r1.value), buf[:n]))
+    finally:
+        L.s3sh_result_destroy(r)
+    return out
