@@ -544,6 +544,10 @@ __global__ __launch_bounds__(kWave) void lz4_decompress_global_kernel(
   const uint8_t* c = comp + fr.comp_off;
   uint8_t* out = dst + frame_out[f];
   bool bad = false;
+#ifdef S3S_LZ4_TIMING
+  const unsigned long long gk0 = __builtin_amdgcn_s_memtime();
+  unsigned long long g_seq = 0, g_flush = 0, g_drain = 0, g_slow = 0;
+#endif
   if (fr.method == 0x10) {  // stored frame
     for (int j = lane * 4; j < olen; j += kWave * 4) {
       if (j + 4 <= olen) {
@@ -571,17 +575,27 @@ __global__ __launch_bounds__(kWave) void lz4_decompress_global_kernel(
     uint32_t pv0 = 0, pv1 = 0, pv2 = 0, pv3 = 0;
     auto flush = [&]() {
       if (npend > 0) {
+#ifdef S3S_LZ4_TIMING
+        g_flush++;
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // loads landed; every earlier store is complete
         drained = pop0;
+#ifndef S3S_ABL_DEC_NOSTORE
         if (lane < pml0) out[pop0 + lane] = (uint8_t)pv0;
         if (npend > 1 && lane < pml1) out[pop1 + lane] = (uint8_t)pv1;
         if (npend > 2 && lane < pml2) out[pop2 + lane] = (uint8_t)pv2;
         if (npend > 3 && lane < pml3) out[pop3 + lane] = (uint8_t)pv3;
+#else
+        asm volatile("" ::"v"(pv0), "v"(pv1), "v"(pv2), "v"(pv3));
+#endif
         npend = 0;
       }
     };
     for (;;) {
       if (ip >= clen) { bad = true; break; }
+#ifdef S3S_LZ4_TIMING
+      g_seq++;
+#endif
       int lit, ml, offset;
       bool fast = false;
       if (ip + 20 <= clen) {
@@ -618,7 +632,11 @@ __global__ __launch_bounds__(kWave) void lz4_decompress_global_kernel(
             if (lit > 0) {  // literal j is stream byte ip+1+j, i.e. a byte of the window
               const uint32_t la = (uint32_t)(a - WB) + 1u + (uint32_t)lane;
               const uint32_t dwv = (uint32_t)__shfl((int)win, (int)((la >> 2) & 63u));
+#ifndef S3S_ABL_DEC_NOSTORE
               if (lane < lit) out[op + lane] = (uint8_t)(dwv >> (8u * (la & 3u)));
+#else
+              asm volatile("" ::"v"(dwv));
+#endif
             }
             op += lit;
             ip += b + 2;
@@ -676,6 +694,9 @@ __global__ __launch_bounds__(kWave) void lz4_decompress_global_kernel(
         if (src_end > drained) {
           flush();
           if (src_end > drained) {
+#ifdef S3S_LZ4_TIMING
+            g_drain++;
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             drained = op;
           }
@@ -721,23 +742,38 @@ __global__ __launch_bounds__(kWave) void lz4_decompress_global_kernel(
     return;
   }
   // ---- LZ4Block check: xxHash32(seed 0x9747b28c) & 0x0FFFFFFF over the decoded frame ------------
+  // all stores complete in L2, then drop this CU's (possibly stale) L1 lines: plain loads below
+  // are served with what L2 holds.  The frame is streamed 256 bytes per coalesced load; the four
+  // stripe accumulators live in lanes 0..3 and pull their words out of the block by cross-lane reads.
+#ifdef S3S_LZ4_TIMING
+  const unsigned long long gk1 = __builtin_amdgcn_s_memtime();
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   {
     const uint32_t seed = kLz4BlockSeed;
     uint32_t acc = lane == 0 ? seed + XXP1 + XXP2 : lane == 1 ? seed + XXP2 : lane == 2 ? seed : seed - XXP1;
     const int stripes = olen >> 4;
-    // out + frame_out is only byte aligned: assemble dwords from L2 byte-exactly via two aligned loads
-    const uint64_t oaddr = reinterpret_cast<uint64_t>(out);
-    const uint32_t* obase = reinterpret_cast<const uint32_t*>(oaddr & ~uint64_t(3));
-    const uint32_t osh = (uint32_t)(oaddr & 3u) * 8u;
-    auto rd32o = [&](int byte_pos) -> uint32_t {  // byte_pos multiple of 4
-      const uint32_t a = ld_u32_l2(obase + (byte_pos >> 2));
-      if (osh == 0) return a;
-      const uint32_t b = ld_u32_l2(obase + (byte_pos >> 2) + 1);
-      return (uint32_t)((((uint64_t)b << 32) | a) >> osh);
+    const int nblk = olen >> 8;
+    auto ld32u = [&](int byte_pos) -> uint32_t {
+      uint32_t x;
+      __builtin_memcpy(&x, out + byte_pos, 4);  // unaligned global_load_dword
+      return x;
     };
-    if (lane < 4)
-      for (int j = 0; j < stripes; j++) acc = rotl32(acc + rd32o(16 * j + 4 * lane) * XXP2, 13) * XXP1;
+    uint32_t cur = nblk > 0 ? ld32u(4 * lane) : 0u;
+    for (int bk = 0; bk < nblk; bk++) {
+      const uint32_t nxt = bk + 1 < nblk ? ld32u(256 * (bk + 1) + 4 * lane) : 0u;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const uint32_t wv = (uint32_t)__shfl((int)cur, 4 * j + (lane & 3));
+        acc = rotl32(acc + wv * XXP2, 13) * XXP1;
+      }
+      cur = nxt;
+    }
+    for (int j = nblk * 16; j < stripes; j++) {  // < 16 leftover stripes
+      const uint32_t wv = ld32u(16 * j + 4 * (lane & 3));
+      acc = rotl32(acc + wv * XXP2, 13) * XXP1;
+    }
     uint32_t h;
     if (olen >= 16) {
       const uint32_t v1 = __builtin_amdgcn_readlane(acc, 0), v2 = __builtin_amdgcn_readlane(acc, 1),
@@ -748,12 +784,534 @@ __global__ __launch_bounds__(kWave) void lz4_decompress_global_kernel(
     }
     h += (uint32_t)olen;
     int p = stripes << 4;
-    for (; p + 4 <= olen; p += 4) {
-      uint32_t x = ld_u8_l2(out + p) | (ld_u8_l2(out + p + 1) << 8) | (ld_u8_l2(out + p + 2) << 16) |
-                   (ld_u8_l2(out + p + 3) << 24);
-      h = rotl32(h + x * XXP3, 17) * XXP4;
+    for (; p + 4 <= olen; p += 4) h = rotl32(h + ld32u(p) * XXP3, 17) * XXP4;
+    for (; p < olen; p++) h = rotl32(h + (uint32_t)out[p] * XXP5, 11) * XXP1;
+    h ^= h >> 15;
+    h *= XXP2;
+    h ^= h >> 13;
+    h *= XXP3;
+    h ^= h >> 16;
+    if (lane == 0 && (h & 0x0FFFFFFFu) != fr.check) atomicExch(status, S3S_E_BAD_FRAME);
+  }
+#ifdef S3S_LZ4_TIMING
+  if (lane == 0) {
+    const unsigned long long gk2 = __builtin_amdgcn_s_memtime();
+    atomicAdd(&g_dec_dbg[8], gk1 - gk0);
+    atomicAdd(&g_dec_dbg[9], gk2 - gk1);
+    atomicAdd(&g_dec_dbg[10], 1ull);
+    atomicAdd(&g_dec_dbg[11], g_seq);
+    atomicAdd(&g_dec_dbg[12], g_flush);
+    atomicAdd(&g_dec_dbg[13], g_drain);
+  }
+#endif
+}
+
+// ---- frame decode, variant 2: variant 1 plus an LDS ring of the last 8 KiB of output -------------
+// Near matches (the bulk for shuffle data) are LDS -> LDS and never wait for memory; only far
+// matches take the L2 round trip of variant 1.  8 KiB per frame keeps 20 frames per CU resident.
+constexpr int kRing = 8192;
+__global__ __launch_bounds__(kWave) void lz4_decompress_ring_kernel(
+    const uint8_t* __restrict__ comp, const Frame* __restrict__ frames, int32_t n_frames,
+    const int64_t* __restrict__ frame_out, uint8_t* dst, int32_t* __restrict__ status) {
+  const int f = blockIdx.x;
+  if (f >= n_frames) return;
+  const Frame fr = frames[f];
+  const int olen = fr.orig_len, clen = fr.comp_len;
+  if (olen == 0) return;
+  const int lane = threadIdx.x;
+  // the last kRing output bytes of the frame, so that near matches never leave the CU
+  __shared__ uint8_t ring[kRing];
+  const uint8_t* c = comp + fr.comp_off;
+  uint8_t* out = dst + frame_out[f];
+  bool bad = false;
+  if (fr.method == 0x10) {  // stored frame
+    for (int j = lane * 4; j < olen; j += kWave * 4) {
+      if (j + 4 <= olen) {
+        uint32_t x;
+        __builtin_memcpy(&x, c + j, 4);
+        __builtin_memcpy(out + j, &x, 4);
+      } else {
+        for (int k = j; k < olen; k++) out[k] = c[k];
+      }
     }
-    for (; p < olen; p++) h = rotl32(h + ld_u8_l2(out + p) * XXP5, 11) * XXP1;
+  } else {
+    int ip = 0, op = 0, drained = 0;
+    // 256-byte window of the compressed stream held across the wave: lane i owns the dword at WB+4i.
+    // Parsing a sequence is then 5 v_readlane + scalar shifts, its literals one ds_bpermute — no
+    // memory round trip.  The window is reloaded (one coalesced load) every ~240 stream bytes.
+    const uint64_t c_addr = reinterpret_cast<uint64_t>(c);
+    const uint64_t last_dw = (c_addr + (uint64_t)clen - 1u) & ~uint64_t(3);  // last dword holding stream bytes
+    uint64_t WB = 0;
+    uint32_t win = 0;
+    bool have_win = false;
+    // up to 4 match copies ride in registers between their load and their store, so the wave pays one
+    // L2 round trip per 4 sequences instead of one per sequence.  A copy may join the flight only if
+    // its source lies entirely below `drained` (= everything below is complete in L2).
+    int npend = 0, pop0 = 0, pop1 = 0, pop2 = 0, pop3 = 0, pml0 = 0, pml1 = 0, pml2 = 0, pml3 = 0;
+    uint32_t pv0 = 0, pv1 = 0, pv2 = 0, pv3 = 0;
+    auto flush = [&]() {
+      if (npend > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // loads landed; every earlier store is complete
+        drained = pop0;
+        if (lane < pml0) { out[pop0 + lane] = (uint8_t)pv0; ring[(pop0 + lane) & (kRing - 1)] = (uint8_t)pv0; }
+        if (npend > 1 && lane < pml1) { out[pop1 + lane] = (uint8_t)pv1; ring[(pop1 + lane) & (kRing - 1)] = (uint8_t)pv1; }
+        if (npend > 2 && lane < pml2) { out[pop2 + lane] = (uint8_t)pv2; ring[(pop2 + lane) & (kRing - 1)] = (uint8_t)pv2; }
+        if (npend > 3 && lane < pml3) { out[pop3 + lane] = (uint8_t)pv3; ring[(pop3 + lane) & (kRing - 1)] = (uint8_t)pv3; }
+        npend = 0;
+      }
+    };
+    for (;;) {
+      if (ip >= clen) { bad = true; break; }
+      // a copy in flight owns ring slots it has not written yet: land it before the ring wraps onto them
+      if (npend > 0 && op - pop0 > kRing / 2) flush();
+      int lit, ml, offset;
+      bool fast = false;
+      if (ip + 20 <= clen) {
+        const uint64_t a = c_addr + (uint64_t)ip;
+        if (!have_win || a + 20u > WB + 256u) {
+          WB = a & ~uint64_t(3);
+          uint64_t la = WB + 4u * (uint64_t)lane;
+          la = la < last_dw ? la : last_dw;
+          win = *reinterpret_cast<const uint32_t*>(la);
+          have_win = true;
+        }
+        const int k = (int)((a - WB) >> 2);
+        const uint32_t sh = (uint32_t)(a & 3u) * 8u;
+        const uint32_t d0 = __builtin_amdgcn_readlane(win, k), d1 = __builtin_amdgcn_readlane(win, k + 1);
+        const uint32_t d2 = __builtin_amdgcn_readlane(win, k + 2), d3 = __builtin_amdgcn_readlane(win, k + 3);
+        const uint32_t d4 = __builtin_amdgcn_readlane(win, k + 4);
+        const uint32_t w0 = (uint32_t)((((uint64_t)d1 << 32) | d0) >> sh);
+        const uint32_t w1 = (uint32_t)((((uint64_t)d2 << 32) | d1) >> sh);
+        const uint32_t w2 = (uint32_t)((((uint64_t)d3 << 32) | d2) >> sh);
+        const uint32_t w3 = (uint32_t)((((uint64_t)d4 << 32) | d3) >> sh);
+        lit = (int)((w0 >> 4) & 15u);
+        ml = (int)(w0 & 15u);
+        if (lit <= 12) {
+          const int b = 1 + lit;
+          const int dw = b >> 2;
+          const uint32_t lo = dw == 0 ? w0 : (dw == 1 ? w1 : (dw == 2 ? w2 : w3));
+          const uint32_t hi = dw == 0 ? w1 : (dw == 1 ? w2 : (dw == 2 ? w3 : 0u));
+          const uint32_t three = (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (b & 3))) & 0xffffffu;
+          offset = (int)(three & 0xffffu);
+          const uint32_t ext = three >> 16;
+          if (!(ml == 15 && ext == 255u)) {
+            fast = true;
+            if (lit > olen - op) { bad = true; break; }
+            if (lit > 0) {  // literal j is stream byte ip+1+j, i.e. a byte of the window
+              const uint32_t la = (uint32_t)(a - WB) + 1u + (uint32_t)lane;
+              const uint32_t dwv = (uint32_t)__shfl((int)win, (int)((la >> 2) & 63u));
+              if (lane < lit) {
+                const uint8_t bv = (uint8_t)(dwv >> (8u * (la & 3u)));
+                out[op + lane] = bv;
+                ring[(op + lane) & (kRing - 1)] = bv;
+              }
+            }
+            op += lit;
+            ip += b + 2;
+            if (ml == 15) {
+              ml += (int)ext;
+              ip += 1;
+            }
+          }
+        }
+      }
+      if (!fast) {
+        // byte-wise parse (long literal runs, long matches, the tail of the frame): wave-uniform
+        // vector loads, rare enough not to matter
+        flush();
+        const uint32_t token = __builtin_amdgcn_readfirstlane((uint32_t)c[ip]);
+        ip++;
+        lit = (int)(token >> 4);
+        if (lit == 15) {
+          uint32_t b;
+          do {
+            if (ip >= clen) { bad = true; break; }
+            b = __builtin_amdgcn_readfirstlane((uint32_t)c[ip]);
+            ip++;
+            lit += (int)b;
+          } while (b == 255);
+          if (bad) break;
+        }
+        if (lit > clen - ip || lit > olen - op) { bad = true; break; }
+        for (int j = lane; j < lit; j += kWave) {
+          const uint8_t bv = c[ip + j];
+          out[op + j] = bv;
+          ring[(op + j) & (kRing - 1)] = bv;
+        }
+        ip += lit;
+        op += lit;
+        if (ip == clen) break;  // last sequence carries literals only
+        if (clen - ip < 2) { bad = true; break; }
+        offset = (int)__builtin_amdgcn_readfirstlane((uint32_t)c[ip] | ((uint32_t)c[ip + 1] << 8));
+        ip += 2;
+        ml = (int)(token & 15u);
+        if (ml == 15) {
+          uint32_t b;
+          do {
+            if (ip >= clen) { bad = true; break; }
+            b = __builtin_amdgcn_readfirstlane((uint32_t)c[ip]);
+            ip++;
+            ml += (int)b;
+          } while (b == 255);
+          if (bad) break;
+        }
+      }
+      if (offset == 0 || offset > op) { bad = true; break; }
+      ml += 4;
+      if (ml > olen - op) { bad = true; break; }
+      const uint8_t* src = out + op - offset;
+      if (offset + kWave <= kRing) {
+        // ---- near match: the source is in the ring (LDS executes this wave's accesses in order, so
+        // rounds of a long copy and overlapping copies need no waits)
+        if (npend > 0 && op - offset + ml > pop0) flush();  // ... unless it is still in flight
+        if (offset >= kWave) {
+          for (int j0 = 0; j0 < ml; j0 += kWave) {
+            const int j = j0 + lane;
+            if (j < ml) {
+              const uint8_t bv = ring[(op - offset + j) & (kRing - 1)];
+              ring[(op + j) & (kRing - 1)] = bv;
+              out[op + j] = bv;
+            }
+          }
+        } else {  // overlap: periodic in the last `offset` bytes; one register byte per lane
+          const int span = (kWave / offset) * offset;
+          const uint8_t bv = ring[(op - offset + (lane % offset)) & (kRing - 1)];
+          if (lane < span)
+            for (int j = lane; j < ml; j += span) {
+              ring[(op + j) & (kRing - 1)] = bv;
+              out[op + j] = bv;
+            }
+        }
+      } else if (ml <= kWave) {
+        // ---- far match, one round: rides in registers between its L2 load and its stores
+        const int src_end = op - offset + ml;
+        if (src_end > drained) {
+          flush();
+          if (src_end > drained) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            drained = op;
+          }
+        }
+        if (npend == 4) flush();
+        uint32_t val = 0;
+        if (lane < ml) val = ld_u8_l2(src + lane);
+        if (npend == 0) { pv0 = val; pop0 = op; pml0 = ml; }
+        else if (npend == 1) { pv1 = val; pop1 = op; pml1 = ml; }
+        else if (npend == 2) { pv2 = val; pop2 = op; pml2 = ml; }
+        else { pv3 = val; pop3 = op; pml3 = ml; }
+        npend++;
+      } else {
+        // ---- far match, several rounds (offset > kRing - 64 >= 64: rounds never overlap their source)
+        flush();
+        for (int j0 = 0; j0 < ml; j0 += kWave) {
+          const int need = op - offset + (ml - j0 < kWave ? ml : j0 + kWave);
+          if (need > drained) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            drained = op + j0;
+          }
+          const int j = j0 + lane;
+          if (j < ml) {
+            const uint8_t bv = (uint8_t)ld_u8_l2(src + j);
+            out[op + j] = bv;
+            ring[(op + j) & (kRing - 1)] = bv;
+          }
+        }
+      }
+      op += ml;
+    }
+    flush();
+    if (!bad && op != olen) bad = true;
+  }
+  if (bad) {
+    if (lane == 0) atomicExch(status, S3S_E_BAD_FRAME);
+    return;
+  }
+  // ---- LZ4Block check: xxHash32(seed 0x9747b28c) & 0x0FFFFFFF over the decoded frame ------------
+  // all stores complete in L2, then drop this CU's (possibly stale) L1 lines: plain loads below
+  // are served with what L2 holds.  The frame is streamed 256 bytes per coalesced load; the four
+  // stripe accumulators live in lanes 0..3 and pull their words out of the block by cross-lane reads.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  {
+    const uint32_t seed = kLz4BlockSeed;
+    uint32_t acc = lane == 0 ? seed + XXP1 + XXP2 : lane == 1 ? seed + XXP2 : lane == 2 ? seed : seed - XXP1;
+    const int stripes = olen >> 4;
+    const int nblk = olen >> 8;
+    auto ld32u = [&](int byte_pos) -> uint32_t {
+      uint32_t x;
+      __builtin_memcpy(&x, out + byte_pos, 4);  // unaligned global_load_dword
+      return x;
+    };
+    uint32_t cur = nblk > 0 ? ld32u(4 * lane) : 0u;
+    for (int bk = 0; bk < nblk; bk++) {
+      const uint32_t nxt = bk + 1 < nblk ? ld32u(256 * (bk + 1) + 4 * lane) : 0u;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const uint32_t wv = (uint32_t)__shfl((int)cur, 4 * j + (lane & 3));
+        acc = rotl32(acc + wv * XXP2, 13) * XXP1;
+      }
+      cur = nxt;
+    }
+    for (int j = nblk * 16; j < stripes; j++) {  // < 16 leftover stripes
+      const uint32_t wv = ld32u(16 * j + 4 * (lane & 3));
+      acc = rotl32(acc + wv * XXP2, 13) * XXP1;
+    }
+    uint32_t h;
+    if (olen >= 16) {
+      const uint32_t v1 = __builtin_amdgcn_readlane(acc, 0), v2 = __builtin_amdgcn_readlane(acc, 1),
+                     v3 = __builtin_amdgcn_readlane(acc, 2), v4 = __builtin_amdgcn_readlane(acc, 3);
+      h = rotl32(v1, 1) + rotl32(v2, 7) + rotl32(v3, 12) + rotl32(v4, 18);
+    } else {
+      h = seed + XXP5;
+    }
+    h += (uint32_t)olen;
+    int p = stripes << 4;
+    for (; p + 4 <= olen; p += 4) h = rotl32(h + ld32u(p) * XXP3, 17) * XXP4;
+    for (; p < olen; p++) h = rotl32(h + (uint32_t)out[p] * XXP5, 11) * XXP1;
+    h ^= h >> 15;
+    h *= XXP2;
+    h ^= h >> 13;
+    h *= XXP3;
+    h ^= h >> 16;
+    if (lane == 0 && (h & 0x0FFFFFFFu) != fr.check) atomicExch(status, S3S_E_BAD_FRAME);
+  }
+}
+
+// ---- frame decode, variant 3: ring decoder written for the VALU ---------------------------------
+// PMC on variants 1/2 shows ~160 scalar instructions per LZ4 sequence and the CU's single scalar
+// ALU ~75 % busy: wave-serial decoders on CDNA are bounded by SALU issue, not by memory.  Here
+// every wave-uniform quantity of the parse (token fields, offset, positions) is computed
+// redundantly by all 64 lanes on the vector ALU — values come out of ds_bpermute, so the compiler
+// keeps them in VGPRs — and only branch conditions are turned scalar (v_readfirstlane).  Far
+// matches (source older than the ring) are rare and handled synchronously.
+__global__ __launch_bounds__(kWave) void lz4_decompress_valu_kernel(
+    const uint8_t* __restrict__ comp, const Frame* __restrict__ frames, int32_t n_frames,
+    const int64_t* __restrict__ frame_out, uint8_t* dst, int32_t* __restrict__ status) {
+  __shared__ uint8_t ring[kRing];
+  const int f = blockIdx.x;
+  if (f >= n_frames) return;
+  const Frame fr = frames[f];
+  const int olen = fr.orig_len, clen = fr.comp_len;
+  if (olen == 0) return;
+  const int lane = threadIdx.x;
+  const uint8_t* c = comp + fr.comp_off;
+  uint8_t* out = dst + frame_out[f];
+  int bad = 0;
+  if (fr.method == 0x10) {  // stored frame
+    for (int j = lane * 4; j < olen; j += kWave * 4) {
+      if (j + 4 <= olen) {
+        uint32_t x;
+        __builtin_memcpy(&x, c + j, 4);
+        __builtin_memcpy(out + j, &x, 4);
+      } else {
+        for (int k = j; k < olen; k++) out[k] = c[k];
+      }
+    }
+  } else {
+    // per-lane copies of the wave-uniform state (kept in VGPRs on purpose)
+    int ip = 0, op = 0;
+    asm volatile("" : "+v"(ip), "+v"(op));
+    int drained = 0;  // scalar: only the rare far path uses it
+    const uint32_t c_lo = (uint32_t)(reinterpret_cast<uint64_t>(c) & 3u);  // stream byte s sits at dword-space byte s + c_lo
+    const uint8_t* c_al = c - c_lo;                                        // dword-aligned base of the stream
+    const int last_dw = (int)((c_lo + (uint32_t)clen - 1u) >> 2);          // last dword index holding stream bytes
+    int wb = -1 << 20;   // dword index (relative to c_al) of window lane 0; VGPR-uniform
+    asm volatile("" : "+v"(wb));
+    uint32_t win = 0;
+    for (;;) {
+      // ---- loop control: everything scalar the loop needs, from one readfirstlane -----------------
+      const int ipu = __builtin_amdgcn_readfirstlane(ip);
+      if (ipu >= clen) { bad = 1; break; }
+      int lit, ml, offset;
+      bool fast = false;
+      if (ipu + 20 <= clen) {
+        const int ab = ip + (int)c_lo;        // byte position in dword space
+        int k = (ab >> 2) - wb;               // window lane of the token's dword
+        if (__builtin_amdgcn_readfirstlane((int)(k < 0 || k > 58))) {  // (re)load the 256-byte window
+          wb = ab >> 2;
+          int di = wb + lane;
+          di = di < last_dw ? di : last_dw;
+          win = reinterpret_cast<const uint32_t*>(c_al)[di];
+          k = 0;
+        }
+        const uint32_t d0 = (uint32_t)__shfl((int)win, k), d1 = (uint32_t)__shfl((int)win, k + 1);
+        const uint32_t d2 = (uint32_t)__shfl((int)win, k + 2), d3 = (uint32_t)__shfl((int)win, k + 3);
+        const uint32_t d4 = (uint32_t)__shfl((int)win, k + 4);
+        const uint32_t sh = ((uint32_t)ab & 3u) * 8u;
+        const uint32_t w0 = __builtin_amdgcn_alignbit(d1, d0, sh), w1 = __builtin_amdgcn_alignbit(d2, d1, sh);
+        const uint32_t w2 = __builtin_amdgcn_alignbit(d3, d2, sh), w3 = __builtin_amdgcn_alignbit(d4, d3, sh);
+        lit = (int)((w0 >> 4) & 15u);
+        ml = (int)(w0 & 15u);
+        const int b = 1 + lit;  // byte index of the offset inside the 16-byte view (valid for lit <= 12)
+        const int dw = b >> 2;
+        const uint32_t lo = dw == 0 ? w0 : (dw == 1 ? w1 : (dw == 2 ? w2 : w3));
+        const uint32_t hi = dw == 0 ? w1 : (dw == 1 ? w2 : (dw == 2 ? w3 : 0u));
+        const uint32_t three = __builtin_amdgcn_alignbit(hi, lo, 8u * ((uint32_t)b & 3u)) & 0xffffffu;
+        offset = (int)(three & 0xffffu);
+        const uint32_t ext = three >> 16;
+        const int okv = (lit <= 12) & !((ml == 15) & (ext == 255u)) & (lit <= olen - op);
+        if (__builtin_amdgcn_readfirstlane(okv)) {
+          fast = true;
+          // literal j is stream byte ip+1+j: a byte of the window
+          const uint32_t la = (uint32_t)(ab - 4 * wb) + 1u + (uint32_t)lane;
+          const uint32_t dwv = (uint32_t)__shfl((int)win, (int)((la >> 2) & 63u));
+          if (lane < lit) {
+            const uint8_t bv = (uint8_t)(dwv >> (8u * (la & 3u)));
+            out[op + lane] = bv;
+            ring[(op + lane) & (kRing - 1)] = bv;
+          }
+          op += lit;
+          const int m15 = (ml == 15) ? 1 : 0;
+          ml += m15 ? (int)ext : 0;
+          ip += b + 2 + m15;
+        }
+      }
+      if (!fast) {
+        // byte-wise parse (long literal runs, long matches, the tail of the frame): rare
+        int ips = ipu, ops = __builtin_amdgcn_readfirstlane(op);
+        const uint32_t token = __builtin_amdgcn_readfirstlane((uint32_t)c[ips]);
+        ips++;
+        lit = (int)(token >> 4);
+        if (lit == 15) {
+          uint32_t bb;
+          do {
+            if (ips >= clen) { bad = 1; break; }
+            bb = __builtin_amdgcn_readfirstlane((uint32_t)c[ips]);
+            ips++;
+            lit += (int)bb;
+          } while (bb == 255);
+          if (bad) break;
+        }
+        if (lit > clen - ips || lit > olen - ops) { bad = 1; break; }
+        for (int j = lane; j < lit; j += kWave) {
+          const uint8_t bv = c[ips + j];
+          out[ops + j] = bv;
+          ring[(ops + j) & (kRing - 1)] = bv;
+        }
+        ips += lit;
+        ops += lit;
+        ip = ips;
+        op = ops;
+        if (ips == clen) break;  // last sequence carries literals only
+        if (clen - ips < 2) { bad = 1; break; }
+        offset = (int)__builtin_amdgcn_readfirstlane((uint32_t)c[ips] | ((uint32_t)c[ips + 1] << 8));
+        ips += 2;
+        ml = (int)(token & 15u);
+        if (ml == 15) {
+          uint32_t bb;
+          do {
+            if (ips >= clen) { bad = 1; break; }
+            bb = __builtin_amdgcn_readfirstlane((uint32_t)c[ips]);
+            ips++;
+            ml += (int)bb;
+          } while (bb == 255);
+          if (bad) break;
+        }
+        ip = ips;
+      }
+      ml += 4;
+      // one scalar decision word: bit0 malformed, bit1 near (source in the ring), bit2 single round
+      const int near = (offset + kWave <= kRing);
+      const int dec = ((offset == 0) | (offset > op) | (ml > olen - op)) | (near << 1) | ((ml <= kWave) << 2);
+      const int decu = __builtin_amdgcn_readfirstlane(dec);
+      if (decu & 1) { bad = 1; break; }
+      if ((decu & 6) == 6) {
+        // near, one round: byte j of the copy is source byte j (mod offset when the copy overlaps)
+        const int sj = offset >= kWave ? lane : (lane % offset);
+        if (lane < ml) {
+          const uint8_t bv = ring[(op - offset + sj) & (kRing - 1)];
+          ring[(op + lane) & (kRing - 1)] = bv;
+          out[op + lane] = bv;
+        }
+      } else if (decu & 2) {
+        const int mlu = __builtin_amdgcn_readfirstlane(ml);
+        const int offu = __builtin_amdgcn_readfirstlane(offset);
+        if (offu >= kWave) {
+          // rounds of 64: the source trails the write head by `offset` <= kRing - 64 bytes
+          for (int j0 = 0; j0 < mlu; j0 += kWave) {
+            const int j = j0 + lane;
+            if (j < ml) {
+              const uint8_t bv = ring[(op - offset + j) & (kRing - 1)];
+              ring[(op + j) & (kRing - 1)] = bv;
+              out[op + j] = bv;
+            }
+          }
+        } else {
+          // overlapping copy of any length = periodic pattern: each lane keeps ONE byte of the period
+          // in a register (the copy may be longer than the ring, which would eat its own source)
+          const int span = (kWave / offu) * offu;
+          const uint8_t bv = ring[(op - offset + (lane % offu)) & (kRing - 1)];
+          if (lane < span)
+            for (int j = lane; j < mlu; j += span) {
+              ring[(op + j) & (kRing - 1)] = bv;
+              out[op + j] = bv;
+            }
+        }
+      } else {
+        // far: the source left the ring; read it back from L2 once this wave's stores have landed
+        const int opu = __builtin_amdgcn_readfirstlane(op), offu = __builtin_amdgcn_readfirstlane(offset);
+        const int mlu = __builtin_amdgcn_readfirstlane(ml);
+        const uint8_t* src = out + opu - offu;
+        for (int j0 = 0; j0 < mlu; j0 += kWave) {
+          const int need = opu - offu + (mlu - j0 < kWave ? mlu : j0 + kWave);
+          if (need > drained) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            drained = opu + j0;
+          }
+          const int j = j0 + lane;
+          if (j < mlu) {
+            const uint8_t bv = (uint8_t)ld_u8_l2(src + j);
+            out[opu + j] = bv;
+            ring[(opu + j) & (kRing - 1)] = bv;
+          }
+        }
+      }
+      op += ml;
+    }
+    if (!bad && __builtin_amdgcn_readfirstlane(op) != olen) bad = 1;
+  }
+  if (bad) {
+    if (lane == 0) atomicExch(status, S3S_E_BAD_FRAME);
+    return;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  {
+    const uint32_t seed = kLz4BlockSeed;
+    uint32_t acc = lane == 0 ? seed + XXP1 + XXP2 : lane == 1 ? seed + XXP2 : lane == 2 ? seed : seed - XXP1;
+    const int stripes = olen >> 4;
+    const int nblk = olen >> 8;
+    auto ld32u = [&](int byte_pos) -> uint32_t {
+      uint32_t x;
+      __builtin_memcpy(&x, out + byte_pos, 4);
+      return x;
+    };
+    uint32_t cur = nblk > 0 ? ld32u(4 * lane) : 0u;
+    for (int bk = 0; bk < nblk; bk++) {
+      const uint32_t nxt = bk + 1 < nblk ? ld32u(256 * (bk + 1) + 4 * lane) : 0u;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const uint32_t wv = (uint32_t)__shfl((int)cur, 4 * j + (lane & 3));
+        acc = rotl32(acc + wv * XXP2, 13) * XXP1;
+      }
+      cur = nxt;
+    }
+    for (int j = nblk * 16; j < stripes; j++) {
+      const uint32_t wv = ld32u(16 * j + 4 * (lane & 3));
+      acc = rotl32(acc + wv * XXP2, 13) * XXP1;
+    }
+    uint32_t h;
+    if (olen >= 16) {
+      const uint32_t v1 = __builtin_amdgcn_readlane(acc, 0), v2 = __builtin_amdgcn_readlane(acc, 1),
+                     v3 = __builtin_amdgcn_readlane(acc, 2), v4 = __builtin_amdgcn_readlane(acc, 3);
+      h = rotl32(v1, 1) + rotl32(v2, 7) + rotl32(v3, 12) + rotl32(v4, 18);
+    } else {
+      h = seed + XXP5;
+    }
+    h += (uint32_t)olen;
+    int p = stripes << 4;
+    for (; p + 4 <= olen; p += 4) h = rotl32(h + ld32u(p) * XXP3, 17) * XXP4;
+    for (; p < olen; p++) h = rotl32(h + (uint32_t)out[p] * XXP5, 11) * XXP1;
     h ^= h >> 15;
     h *= XXP2;
     h ^= h >> 13;
@@ -800,6 +1358,16 @@ void launch_lz4_decompress(const uint8_t* d_comp, const Frame* d_frames, int32_t
                            const int64_t* d_frame_out, uint8_t* d_dst, int32_t* d_status,
                            int variant, hipStream_t st) {
   if (n_frames <= 0) return;
+  if (variant == 3) {
+    hipLaunchKernelGGL(lz4_decompress_valu_kernel, dim3((unsigned)n_frames), dim3(kWave), 0, st, d_comp,
+                       d_frames, n_frames, d_frame_out, d_dst, d_status);
+    return;
+  }
+  if (variant == 2) {
+    hipLaunchKernelGGL(lz4_decompress_ring_kernel, dim3((unsigned)n_frames), dim3(kWave), 0, st, d_comp,
+                       d_frames, n_frames, d_frame_out, d_dst, d_status);
+    return;
+  }
   if (variant == 1) {
     hipLaunchKernelGGL(lz4_decompress_global_kernel, dim3((unsigned)n_frames), dim3(kWave), 0, st, d_comp,
                        d_frames, n_frames, d_frame_out, d_dst, d_status);

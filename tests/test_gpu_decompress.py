@@ -12,7 +12,7 @@ LZ4, NONE = 1, 0
 ADLER, CRC = 1, 2
 
 
-@pytest.fixture(params=[0, 1], ids=["frame-in-lds", "frame-in-global"], autouse=True)
+@pytest.fixture(params=[0, 1, 2, 3], ids=["frame-in-lds", "frame-in-global", "ring", "ring-valu"], autouse=True)
 def lz4_decode_variant(request, gpu_codec):
     """Every test runs against both decoders (S3S_OPT_LZ4_DECODE_VARIANT)."""
     default = gpu_codec.get_option(5)

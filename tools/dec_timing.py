@@ -20,6 +20,9 @@ for it in range(2):
     n = c.decompress_range_device(1, 1, d_dst.data_ptr(), total, index, sums, d_out.data_ptr(), data.size)
     lib.s3s_debug_read_dec(buf, 1)
 assert n == data.size and torch.equal(d_out, d_src)
+if buf[10]:
+    g = buf[10]
+    print(f"GLOBAL decoder: frames {g}, decode ticks/frame {buf[8]/g:.0f}, hash ticks/frame {buf[9]/g:.0f}, seqs/frame {buf[11]/g:.0f}, flushes/frame {buf[12]/g:.1f}, extra drains/frame {buf[13]/g:.1f}; kernel {c.stage_ms(1):.3f} ms")
 fr = max(buf[6], 1)
 print(f"decode kernel {c.stage_ms(1):.3f} ms, frames decoded {buf[6]}, seqs/frame {buf[4]/fr:.0f}, slow-parse/frame {buf[5]/fr:.1f}")
 print(f"per frame ticks: parse {buf[0]/fr:.0f}, match-copy {buf[1]/fr:.0f}, decode-wave total {buf[2]/fr:.0f}, workgroup total {buf[3]/fr:.0f}")
