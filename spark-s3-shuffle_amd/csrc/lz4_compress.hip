@@ -522,6 +522,259 @@ __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t*
         }
         force_general = false;
       }
+      if constexpr (kMode == 3) {
+        // ===== pipelined exact windows, VALU style (variant 4): as kMode 2, but every wave-uniform
+        // quantity of the run loop lives in VGPRs and only branch conditions are made scalar — the CU's
+        // single scalar ALU is what bounds these kernels =====
+        //   stage A  v   = rd32(position)                 issued 3 windows ahead
+        //   stage B  cp  = T[hash(v)], w = rd32(cp)       table snapshot + candidate bytes, 2 ahead
+        //   stage C  em  = (w == v), 64+8 bytes at p and cp for the em lanes ("raw")   1 ahead
+        //   stage D  info = lengths from raw                        at the start of the window's turn
+        // A snapshot is validated when its window is resolved: cp' = T[h] again; a lane is stale iff
+        // cp' != cp.  Everything inserted since the snapshot lies in [wbase-128, p), i.e. in the v
+        // registers of this and the two previous windows, so a stale lane's match test is a
+        // cross-lane read; its lengths come from the cooperative extension.
+        if (!force_general && t0 <= 48 && (base & ~63) <= pipe_limit) {
+          if (put_pending) T[hash13(vput)] = (uint16_t)(base - 2);  // LZ4_putPosition(ip - 2)
+          put_pending = false;
+          have_pre = false;
+          int wbase = base & ~63;
+          // ---- (re)start: fill the pipeline synchronously ---------------------------------------------
+          uint32_t v0 = in.rd32(wbase + lane), v1 = in.rd32(wbase + 64 + lane);
+          uint32_t v2 = in.rd32(wbase + 128 + lane), vA = in.rd32(wbase + 192 + lane);
+          uint32_t vm1 = in.rd32((wbase >= 64 ? wbase - 64 : 0) + lane);
+          uint32_t vm2 = in.rd32((wbase >= 128 ? wbase - 128 : 0) + lane);
+          uint32_t cp0 = T[hash13(v0)], cp1 = T[hash13(v1)], cp2 = T[hash13(v2)];
+          uint32_t wN;
+          uint32_t info0;
+          uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;  // raw: 64 bytes behind p+4 and behind cp+4
+          uint2 rqa, rqb;                                // raw: 8 bytes in front of p and of cp
+          bool rem;                                      // raw belongs to an em lane
+#define S3S_STAGE_C(VV, CP, WW, WB)                                                   \
+  {                                                                                   \
+    rem = (WW) == (VV);                                                               \
+    if (rem) {                                                                        \
+      const int pa_ = (WB) + lane + kMinMatch, pb_ = (int)(CP) + kMinMatch;           \
+      ra0 = in.ld16(pa_), rb0 = in.ld16(pb_);                                         \
+      ra1 = in.ld16(pa_ + 16), rb1 = in.ld16(pb_ + 16);                               \
+      ra2 = in.ld16(pa_ + 32), rb2 = in.ld16(pb_ + 32);                               \
+      ra3 = in.ld16(pa_ + 48), rb3 = in.ld16(pb_ + 48);                               \
+      const int qa_ = (WB) + lane >= 8 ? (WB) + lane - 8 : 0;                         \
+      const int qb_ = (CP) >= 8u ? (int)(CP) - 8 : 0;                                 \
+      rqa = in.ld8(qa_), rqb = in.ld8(qb_);                                           \
+    }                                                                                 \
+  }
+#define S3S_STAGE_D(CP, WB, INFO)                                                     \
+  {                                                                                   \
+    INFO = 0u;                                                                        \
+    if (rem) {                                                                        \
+      uint32_t be_ = 9;                                                               \
+      if ((CP) >= 8u && (WB) + lane >= 8) {                                           \
+        const uint32_t xh_ = rqa.y ^ rqb.y, xl_ = rqa.x ^ rqb.x;                      \
+        be_ = xh_ ? (uint32_t)(__builtin_clz(xh_) >> 3)                               \
+                  : (xl_ ? 4u + (uint32_t)(__builtin_clz(xl_) >> 3) : 8u);            \
+      }                                                                               \
+      int fl_ = first_diff16(make_uint4(ra0.x ^ rb0.x, ra0.y ^ rb0.y, ra0.z ^ rb0.z, ra0.w ^ rb0.w)); \
+      if (fl_ == 16) {                                                                \
+        fl_ = 16 + first_diff16(make_uint4(ra1.x ^ rb1.x, ra1.y ^ rb1.y, ra1.z ^ rb1.z, ra1.w ^ rb1.w)); \
+        if (fl_ == 32) {                                                              \
+          fl_ = 32 + first_diff16(make_uint4(ra2.x ^ rb2.x, ra2.y ^ rb2.y, ra2.z ^ rb2.z, ra2.w ^ rb2.w)); \
+          if (fl_ == 48)                                                              \
+            fl_ = 48 + first_diff16(make_uint4(ra3.x ^ rb3.x, ra3.y ^ rb3.y, ra3.z ^ rb3.z, ra3.w ^ rb3.w)); \
+        }                                                                             \
+      }                                                                               \
+      INFO = (CP) | ((uint32_t)fl_ << 16) | (be_ << 24) | 0x20000000u;                \
+    }                                                                                 \
+  }
+          {
+            const uint32_t w0 = in.rd32((int)cp0), w1 = in.rd32((int)cp1);
+            wN = in.rd32((int)cp2);
+            S3S_STAGE_C(v0, cp0, w0, wbase);
+            S3S_STAGE_D(cp0, wbase, info0);
+            S3S_STAGE_C(v1, cp1, w1, wbase + 64);  // raw(k+1) stays in flight
+          }
+          // ---- steady state: one window per iteration; wave-uniform state in VGPRs -------------------------
+          int vbase = base, vt0 = t0, vanchor = anchor, vop = op;
+          asm volatile("" : "+v"(vbase), "+v"(vt0), "+v"(vanchor), "+v"(vop));
+          int exit_kind = 0;  // 0: leave to the outer loop, 1: last literals, 2: the general batch takes over
+          int pend_far = -1;
+          bool overflow = false;
+          for (;;) {
+            const int p = wbase + lane;
+            const uint32_t h = hash13(v0);
+            const int rs0 = vbase - wbase;
+            const bool live = lane >= rs0;
+            const uint32_t cpn = T[h];
+            bool grp = false;
+            if (live) {
+              T[h] = (uint16_t)p;
+              const uint32_t r1 = T[h];
+              const bool lost1 = r1 != (uint32_t)p;
+              if (lost1) T[h] = (uint16_t)p;
+              const uint32_t r2 = T[h];
+              grp = lost1 || (r2 != (uint32_t)p);
+              if (r2 == (uint32_t)p) T[h] = (uint16_t)cpn;
+            }
+            uint32_t info = info0;
+            const bool stale = live && (cpn != cp0);
+            if (__ballot(stale)) {
+              const int idx = (int)(cpn & 63u);
+              const int dwin = (wbase - (int)(cpn & ~63u)) >> 6;
+              uint32_t sv = __shfl(v0, idx);
+              const uint32_t s1 = __shfl(vm1, idx), s2 = __shfl(vm2, idx);
+              sv = dwin == 1 ? s1 : sv;
+              sv = dwin == 2 ? s2 : sv;
+              if (stale) info = (sv == v0) ? (cpn | 0x60000000u) : 0u;
+            }
+            if (grp) info |= 0x80000000u;
+            bool ed = live && ((info & 0xa0000000u) != 0u);  // event lanes: candidate matches, or suspect
+            // ---- runs ---------------------------------------------------------------------------------------
+            bool kept = false;
+            int rs = rs0, rt = vt0, pendq = -1;
+            int elim = rs0 + 66 - vt0;
+            elim = elim < kWave ? elim : kWave;
+            for (;;) {
+              const bool inrun = lane >= rs && lane < elim;
+              const uint64_t cm = __ballot(ed && inrun);
+              if (cm == 0ull) {  // the run leaves the window (or its consecutive part) without a match
+                kept = kept || inrun;
+                vbase = wbase + elim;
+                vt0 = rt + (elim - rs);
+                exit_kind = __builtin_amdgcn_readfirstlane((int)(elim < kWave)) ? 2 : 0;
+                break;
+              }
+              const int m = __builtin_ctzll(cm);
+              int mv = m;
+              asm volatile("" : "+v"(mv));
+              const uint32_t inf = (uint32_t)__shfl((int)info, mv);
+              const int ip0 = wbase + mv;
+              int mpos = (int)(inf & 0xffffu);
+              int fwd = (int)((inf >> 16) & 0x7fu);
+              const int be = (int)((inf >> 24) & 0xfu);
+              const int nbmax = ip0 - vanchor;
+              int nb = be < nbmax ? be : nbmax;
+              int is_match = (int)((inf >> 29) & 1u);
+              int need_ext = (fwd >= 64) | ((be >= 8) & (nbmax > (be == 8 ? 8 : 0))) | (int)((inf >> 30) & 1u);
+              if (__builtin_amdgcn_readfirstlane((int)(inf >> 31))) {
+                // suspect lane: does a kept (or earlier-in-run) lane of this window share its hash?
+                const uint32_t hv = (uint32_t)__shfl((int)h, mv);
+                const uint64_t dk = __ballot(h == hv && lane < m && (kept || lane >= rs));
+                if (dk) {
+                  const int d = 63 - __builtin_clzll(dk);
+                  is_match = __builtin_amdgcn_readlane(v0, d) == __builtin_amdgcn_readlane(v0, m);
+                  mpos = wbase + d;
+                  need_ext = 1;
+                }
+              }
+              if (!__builtin_amdgcn_readfirstlane(is_match)) {
+                ed = ed && (lane != m);  // a plain no-match probe: the run goes on behind it
+                continue;
+              }
+              bool ended = false;
+              if (__builtin_amdgcn_readfirstlane(need_ext)) {
+                const int anchors = __builtin_amdgcn_readfirstlane(vanchor);
+                const int mposs = __builtin_amdgcn_readfirstlane(mpos);
+                int nbs = 0;
+                fwd = extend_match(in, wbase + m, mposs, anchors, matchlimit, last4, lane, nbs);
+                nb = nbs;
+                ended = wbase + m + kMinMatch + fwd >= mfl1;
+              }
+              kept = kept || (lane >= rs && lane <= m);
+              const int lit = ip0 - nb - vanchor, offset = ip0 - mpos, mcode = nb + fwd;
+              const int fe = (vanchor >= wbase) & (lit < 15) & (mcode < 15 + 255) & (vop + 20 <= len);
+              if (__builtin_amdgcn_readfirstlane(fe)) {
+                const int total = 3 + lit + (mcode >= 15 ? 1 : 0);
+                const int rel = (lane - (vanchor - wbase)) & 63;
+                uint32_t bv = v0 & 0xffu;
+                int idx = rel < lit ? 1 + rel : rel;
+                bv = rel == lit ? ((uint32_t)(lit << 4) | (uint32_t)(mcode < 15 ? mcode : 15)) : bv;
+                idx = rel == lit ? 0 : idx;
+                bv = rel == lit + 1 ? (uint32_t)offset : bv;
+                bv = rel == lit + 2 ? ((uint32_t)offset >> 8) : bv;
+                bv = rel == lit + 3 ? (uint32_t)(mcode - 15) : bv;
+                if (rel < total) out[vop + idx] = (uint8_t)bv;
+                vop += total;
+              } else {
+                const int ops = emit_sequence(out, len, __builtin_amdgcn_readfirstlane(vop), in,
+                                              __builtin_amdgcn_readfirstlane(vanchor), __builtin_amdgcn_readfirstlane(lit),
+                                              true, __builtin_amdgcn_readfirstlane(offset),
+                                              __builtin_amdgcn_readfirstlane(mcode), false, 0u, lane);
+                if (ops < 0) {
+                  overflow = true;
+                  break;
+                }
+                vop = ops;
+              }
+              const int ipe = ip0 + kMinMatch + fwd;
+              vanchor = ipe;
+              if (ended) {
+                exit_kind = 1;
+                break;
+              }
+              const int q = ipe - 2 - wbase;  // LZ4_putPosition(ip - 2)
+              kept = kept || (lane == q);
+              pendq = q >= kWave ? ipe - 2 : pendq;
+              if (__builtin_amdgcn_readfirstlane((int)(ipe >= wbase + kWave))) {
+                vbase = ipe;
+                vt0 = 0;
+                exit_kind = 0;
+                break;
+              }
+              rs = ipe - wbase;
+              rt = 0;
+              elim = kWave;
+            }
+            if (overflow || exit_kind == 1) break;
+            // ---- commit: the highest kept lane of every hash bucket must own the slot --------------------------
+            if (kept) T[h] = (uint16_t)p;
+            for (;;) {
+              uint32_t r = (uint32_t)p;
+              if (kept) r = T[h];
+              const bool redo = kept && ((uint32_t)p > r);
+              if (!__ballot(redo)) break;
+              if (redo) T[h] = (uint16_t)p;
+            }
+            const int pq = __builtin_amdgcn_readfirstlane(pendq);
+            if (pq >= 0) {
+              if (pq < wbase + 3 * kWave) {
+                const uint32_t vq = pq < wbase + 2 * kWave ? __builtin_amdgcn_readlane(v1, pq - wbase - kWave)
+                                                           : __builtin_amdgcn_readlane(v2, pq - wbase - 2 * kWave);
+                T[hash13(vq)] = (uint16_t)pq;
+              } else {
+                pend_far = pq;
+              }
+            }
+            // ---- advance: only a step into the very next window keeps the pipeline ---------------------------
+            const int keep_going = (vt0 <= 48) & ((vbase & ~63) == wbase + kWave);
+            if (exit_kind != 0 || !__builtin_amdgcn_readfirstlane(keep_going) || wbase + kWave > pipe_limit) break;
+            wbase += kWave;
+            S3S_STAGE_D(cp1, wbase, info0);
+            vm2 = vm1;
+            vm1 = v0;
+            v0 = v1;
+            cp0 = cp1;
+            v1 = v2;
+            cp1 = cp2;
+            S3S_STAGE_C(v1, cp1, wN, wbase + 64);
+            v2 = vA;
+            cp2 = T[hash13(v2)];
+            wN = in.rd32((int)cp2);
+            vA = in.rd32(wbase + 192 + lane);
+          }
+          base = __builtin_amdgcn_readfirstlane(vbase);
+          t0 = __builtin_amdgcn_readfirstlane(vt0);
+          anchor = __builtin_amdgcn_readfirstlane(vanchor);
+          op = __builtin_amdgcn_readfirstlane(vop);
+          if (overflow) return -1;
+#undef S3S_STAGE_C
+#undef S3S_STAGE_D
+          if (exit_kind == 1) break;
+          if (pend_far >= 0) T[hash13(in.rd32(pend_far))] = (uint16_t)pend_far;  // LZ4_putPosition(ip - 2)
+          force_general = exit_kind == 2;
+          continue;
+        }
+        force_general = false;
+      }
       if constexpr (kMode == 1) {
         const int wbase = base & ~63;
         if (!force_general && t0 <= 48 && wbase <= fast_limit) {
@@ -970,8 +1223,11 @@ void launch_lz4_compress(const uint8_t* d_src, const Item* d_items, int32_t n_it
   else if (variant == 2)
     hipLaunchKernelGGL(lz4_compress_l2_kernel<1>, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
                        d_items, n_items, d_item_check, d_slots, d_item_size);
-  else
+  else if (variant == 3)
     hipLaunchKernelGGL(lz4_compress_l2_kernel<2>, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
+                       d_items, n_items, d_item_check, d_slots, d_item_size);
+  else
+    hipLaunchKernelGGL(lz4_compress_l2_kernel<3>, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
                        d_items, n_items, d_item_check, d_slots, d_item_size);
 }
 

@@ -1,14 +1,14 @@
 #!/bin/bash
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmcdec; mkdir -p $O; cd /tmp
-for v in 1 2; do
+for v in 3; do
 CMD="python $R/bench.py --no-cpu-baseline --direction decompress --task-threads 1 --maps-per-gpu 2 --steps 3 --warmup 1 --lz4-decode-variant $v"
 timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS -d $O/v${v}_sq -o p -- $CMD > $O/v${v}_sq.log 2>&1
 timeout 200 rocprofv3 --pmc SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/v${v}_sq2 -o p -- $CMD > $O/v${v}_sq2.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --stats -d $O/v${v}_trace -o t -- $CMD > $O/v${v}_trace.log 2>&1
 done
 cd $R
-for v in 1 2; do
+for v in 3; do
 python - <<PY
 import sqlite3,glob
 for kind in ("sq","sq2"):
