@@ -336,6 +336,8 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBPS, 6),
                 "traffic": None,
                 "avg_launch_ms": round(codec_ms, 4),
+                "concurrent_launches": n_threads,  # one per task thread / stream; they share the GPU
+                "achieved_all_streams": round(achieved * n_threads, 3),
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "frac_of_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBPS, 6),
                 "whole_path_read_frac": round(value / world / HBM_PEAK_GBPS, 6),
