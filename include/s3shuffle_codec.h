@@ -96,7 +96,8 @@ enum {
                                     wavefronts per CU), 1 = chunk read through L1/L2, table-only
                                     LDS (10 per CU; default), 2 = 1 + window-speculative parse,
                                     3 = 2 with software-pipelined windows */
-  S3S_OPT_LZ4_DECODE_VARIANT = 5 /* tuning, identical output: 0 = frame staged in LDS, 1 = decoded
+  S3S_OPT_LZ4_DECODE_VARIANT = 5 /* tuning, identical output (Snappy: 0 = staged in LDS, else the
+                                    VALU ring decoder): 0 = frame staged in LDS, 1 = decoded
                                     straight to global memory, 2 = 1 + 8 KiB LDS ring of recent
                                     output, 3 (default) = 2 with the parse on the vector ALU */
 };

@@ -228,7 +228,7 @@ int s3s_decompress_range_device(s3s_ctx* ctx, int codec, int checksum_algo, cons
     if (total > dst_capacity)
       return fail(ctx, S3S_E_CAPACITY, "dst_capacity %lld < %lld decoded bytes", (long long)dst_capacity, (long long)total);
     launch_snappy_decompress(d_comp, dev<Frame>(ctx, B_FRAMES), (int32_t)n_frames, dev<int64_t>(ctx, B_FRAME_OUT),
-                             d_dst, dev<int32_t>(ctx, B_STATUS), ctx->stream);
+                             d_dst, dev<int32_t>(ctx, B_STATUS), ctx->lz4_decode_variant, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     record(ctx, 3);
     HIP_TRY(ctx, hipMemcpyAsync(&h_misc[1], ctx->buf[B_STATUS].p, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));

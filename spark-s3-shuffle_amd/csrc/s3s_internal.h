@@ -112,9 +112,10 @@ void launch_snappy_count_frames(const uint8_t* d_comp, const int64_t* d_part_off
 void launch_snappy_emit_frames(const uint8_t* d_comp, const int64_t* d_part_off, int32_t n_parts,
                                const int64_t* d_frame_base, Frame* d_frames, uint32_t* d_frame_orig,
                                int32_t* d_status, hipStream_t st);
+//   variant 0: block staged in LDS; otherwise the VALU ring decoder
 void launch_snappy_decompress(const uint8_t* d_comp, const Frame* d_frames, int32_t n_frames,
                               const int64_t* d_frame_out, uint8_t* d_dst, int32_t* d_status,
-                              hipStream_t st);
+                              int variant, hipStream_t st);
 void launch_scan_u32(const uint32_t* d_in, int64_t n, int64_t* d_out, hipStream_t st);
 
 // ---- device helpers shared by several kernels --------------------------------------------

@@ -207,6 +207,182 @@ __global__ __launch_bounds__(kDecThreads) void snappy_decompress_kernel(
   if (tid < olen - done) d[done + tid] = s.out[done + tid];
 }
 
+
+// ---- block decode, variant 1: ring decoder written for the VALU (same design as
+// lz4_decompress_valu_kernel: no staging of the block, 256-byte stream window across the wave,
+// 8 KiB LDS ring of recent output, wave-uniform parse values kept in VGPRs) ----
+constexpr int kSnRing = 8192;
+
+__device__ __forceinline__ uint32_t sn_ld_u8_l2(const uint8_t* p) {
+  return (uint32_t)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(kWave) void snappy_decompress_valu_kernel(
+    const uint8_t* __restrict__ comp, const Frame* __restrict__ frames, int32_t n_frames,
+    const int64_t* __restrict__ frame_out, uint8_t* dst, int32_t* __restrict__ status) {
+  __shared__ uint8_t ring[kSnRing];
+  const int f = blockIdx.x;
+  if (f >= n_frames) return;
+  const Frame fr = frames[f];
+  const int olen = fr.orig_len, clen = fr.comp_len;
+  const int lane = threadIdx.x;
+  if (olen > kMaxBlock) {
+    if (lane == 0) atomicExch(status, S3S_E_UNSUPPORTED);
+    return;
+  }
+  const uint8_t* c = comp + fr.comp_off;
+  uint8_t* out = dst + frame_out[f];
+  int bad = 0;
+  // preamble: varint32 uncompressed length (scalar, once per block)
+  int ip0 = 0;
+  {
+    uint32_t ulen = 0;
+    int sh = 0;
+    for (;;) {
+      if (ip0 >= clen || sh > 28) { bad = 1; break; }
+      const uint32_t b = __builtin_amdgcn_readfirstlane((uint32_t)c[ip0]);
+      ip0++;
+      ulen |= (b & 0x7fu) << sh;
+      if (!(b & 0x80u)) break;
+      sh += 7;
+    }
+    if (!bad && (int)ulen != olen) bad = 1;
+  }
+  if (!bad) {
+    int ip = ip0, op = 0;
+    asm volatile("" : "+v"(ip), "+v"(op));
+    int drained = 0;
+    const uint32_t c_lo = (uint32_t)(reinterpret_cast<uint64_t>(c) & 3u);
+    const uint8_t* c_al = c - c_lo;
+    const int last_dw = (int)((c_lo + (uint32_t)clen - 1u) >> 2);
+    int wb = -(1 << 20);
+    asm volatile("" : "+v"(wb));
+    uint32_t win = 0;
+    for (;;) {
+      const int ipu = __builtin_amdgcn_readfirstlane(ip);
+      if (ipu >= clen) break;
+      int len = 0, offset = 0;
+      int kind = 3;  // 0 literal done, 1 copy parsed, 3 slow
+      if (ipu + 72 <= clen) {
+        const int ab = ip + (int)c_lo;
+        int k = (ab >> 2) - wb;
+        if (__builtin_amdgcn_readfirstlane((int)(k < 0 || k > 45))) {  // window must hold tag + 64 literal bytes
+          wb = ab >> 2;
+          int di = wb + lane;
+          di = di < last_dw ? di : last_dw;
+          win = reinterpret_cast<const uint32_t*>(c_al)[di];
+          k = 0;
+        }
+        const uint32_t d0 = (uint32_t)__shfl((int)win, k), d1 = (uint32_t)__shfl((int)win, k + 1);
+        const uint32_t w0 = __builtin_amdgcn_alignbit(d1, d0, ((uint32_t)ab & 3u) * 8u);  // tag + 3 bytes
+        const uint32_t tag = w0 & 0xffu;
+        const uint32_t ty = tag & 3u;
+        const int lit_len = (int)(tag >> 2) + 1;
+        const int lit_ok = (ty == 0u) & (lit_len <= 60) & (lit_len <= olen - op);
+        const int cp_ok = (ty == 1u) | (ty == 2u);
+        const int len_c = ty == 1u ? 4 + (int)((tag >> 2) & 7u) : (int)(tag >> 2) + 1;
+        const int off_c = ty == 1u ? (int)(((tag >> 5) << 8) | ((w0 >> 8) & 0xffu)) : (int)((w0 >> 8) & 0xffffu);
+        const int sel = __builtin_amdgcn_readfirstlane(lit_ok | (cp_ok << 1));
+        if (sel & 1) {
+          // literal of <= 60 bytes: stream bytes ip+1 .. ip+len are bytes of the window
+          const uint32_t la = (uint32_t)(ab - 4 * wb) + 1u + (uint32_t)lane;
+          const uint32_t dwv = (uint32_t)__shfl((int)win, (int)((la >> 2) & 63u));
+          if (lane < lit_len) {
+            const uint8_t bv = (uint8_t)(dwv >> (8u * (la & 3u)));
+            out[op + lane] = bv;
+            ring[(op + lane) & (kSnRing - 1)] = bv;
+          }
+          op += lit_len;
+          ip += 1 + lit_len;
+          kind = 0;
+        } else if (sel & 2) {
+          len = len_c;
+          offset = off_c;
+          ip += ty == 1u ? 2 : 3;
+          kind = 1;
+        }
+      }
+      if (kind == 3) {
+        // byte-wise element parse: long literals, 4-byte-offset copies, the tail of the block (rare)
+        int ips = ipu, ops = __builtin_amdgcn_readfirstlane(op);
+        const uint32_t tag = __builtin_amdgcn_readfirstlane((uint32_t)c[ips]);
+        ips++;
+        if ((tag & 3u) == 0u) {
+          int l = (int)(tag >> 2) + 1;
+          if (l > 60) {
+            const int nb = l - 60;
+            if (clen - ips < nb) { bad = 1; break; }
+            uint32_t lv = 0;
+            for (int i = 0; i < nb; i++) lv |= __builtin_amdgcn_readfirstlane((uint32_t)c[ips + i]) << (8 * i);
+            ips += nb;
+            if (lv >= (uint32_t)kMaxBlock) { bad = 1; break; }
+            l = (int)lv + 1;
+          }
+          if (l > clen - ips || l > olen - ops) { bad = 1; break; }
+          for (int j = lane; j < l; j += kWave) {
+            const uint8_t bv = c[ips + j];
+            out[ops + j] = bv;
+            ring[(ops + j) & (kSnRing - 1)] = bv;
+          }
+          ip = ips + l;
+          op = ops + l;
+          continue;
+        }
+        if ((tag & 3u) == 1u) {
+          if (ips >= clen) { bad = 1; break; }
+          len = 4 + (int)((tag >> 2) & 7u);
+          offset = (int)((tag >> 5) << 8) | (int)__builtin_amdgcn_readfirstlane((uint32_t)c[ips]);
+          ips += 1;
+        } else if ((tag & 3u) == 2u) {
+          if (clen - ips < 2) { bad = 1; break; }
+          len = (int)(tag >> 2) + 1;
+          offset = (int)__builtin_amdgcn_readfirstlane((uint32_t)c[ips] | ((uint32_t)c[ips + 1] << 8));
+          ips += 2;
+        } else {
+          if (clen - ips < 4) { bad = 1; break; }
+          len = (int)(tag >> 2) + 1;
+          const uint32_t o = __builtin_amdgcn_readfirstlane((uint32_t)c[ips] | ((uint32_t)c[ips + 1] << 8) |
+                                                            ((uint32_t)c[ips + 2] << 16) | ((uint32_t)c[ips + 3] << 24));
+          ips += 4;
+          if (o > (uint32_t)kMaxBlock) { bad = 1; break; }
+          offset = (int)o;
+        }
+        ip = ips;
+        kind = 1;
+      }
+      if (kind == 0) continue;
+      // ---- copy of len <= 64 bytes ------------------------------------------------------------------
+      const int near = (offset + kWave <= kSnRing);
+      const int dec = ((offset == 0) | (offset > op) | (len > olen - op)) | (near << 1);
+      const int decu = __builtin_amdgcn_readfirstlane(dec);
+      if (decu & 1) { bad = 1; break; }
+      if (decu & 2) {
+        const int sj = offset >= kWave ? lane : (lane % offset);  // overlap: periodic
+        if (lane < len) {
+          const uint8_t bv = ring[(op - offset + sj) & (kSnRing - 1)];
+          ring[(op + lane) & (kSnRing - 1)] = bv;
+          out[op + lane] = bv;
+        }
+      } else {
+        const int opu = __builtin_amdgcn_readfirstlane(op), offu = __builtin_amdgcn_readfirstlane(offset);
+        const int lenu = __builtin_amdgcn_readfirstlane(len);
+        if (opu - offu + lenu > drained) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          drained = opu;
+        }
+        if (lane < lenu) {
+          const uint8_t bv = (uint8_t)sn_ld_u8_l2(out + opu - offu + lane);
+          out[opu + lane] = bv;
+          ring[(opu + lane) & (kSnRing - 1)] = bv;
+        }
+      }
+      op += len;
+    }
+    if (!bad && __builtin_amdgcn_readfirstlane(op) != olen) bad = 1;
+  }
+  if (bad && lane == 0) atomicExch(status, S3S_E_BAD_FRAME);
+}
+
 }  // namespace
 
 void launch_snappy_count_frames(const uint8_t* d_comp, const int64_t* d_part_off, int32_t n_parts,
@@ -226,8 +402,13 @@ void launch_snappy_emit_frames(const uint8_t* d_comp, const int64_t* d_part_off,
 
 void launch_snappy_decompress(const uint8_t* d_comp, const Frame* d_frames, int32_t n_frames,
                               const int64_t* d_frame_out, uint8_t* d_dst, int32_t* d_status,
-                              hipStream_t st) {
+                              int variant, hipStream_t st) {
   if (n_frames <= 0) return;
+  if (variant != 0) {
+    hipLaunchKernelGGL(snappy_decompress_valu_kernel, dim3((unsigned)n_frames), dim3(kWave), 0, st, d_comp,
+                       d_frames, n_frames, d_frame_out, d_dst, d_status);
+    return;
+  }
   hipLaunchKernelGGL(snappy_decompress_kernel, dim3((unsigned)n_frames), dim3(kDecThreads), 0, st, d_comp,
                      d_frames, n_frames, d_frame_out, d_dst, d_status);
 }

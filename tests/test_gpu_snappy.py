@@ -12,6 +12,15 @@ SNAPPY = 2
 ADLER, CRC = 1, 2
 
 
+@pytest.fixture(params=[0, 3], ids=["block-in-lds", "ring-valu"], autouse=True)
+def decode_variant(request, gpu_codec):
+    """Every test runs against both Snappy decoders (S3S_OPT_LZ4_DECODE_VARIANT: 0 / non-zero)."""
+    default = gpu_codec.get_option(5)
+    gpu_codec.set_option(5, request.param)
+    yield request.param
+    gpu_codec.set_option(5, default)
+
+
 def _check(gpu_codec, oracle, algo, data, offsets, block_size=32768):
     img, index, sums = gpu_codec.compress_map_output(SNAPPY, algo, data, offsets)
     r_img, r_index, r_sums = oracle.compress_map_output(SNAPPY, algo, data, offsets, block_size)
