@@ -1123,8 +1123,53 @@ __global__ __launch_bounds__(kWave) void lz4_compress_lds_kernel(
   finish_frame(slot, len, clen, item_check[it], item.kind >> 8, item_size + it, lane);
 }
 
+constexpr uint32_t XXP1 = 2654435761u, XXP2 = 2246822519u, XXP3 = 3266489917u,
+                   XXP4 = 668265263u, XXP5 = 374761393u;
+
+// xxHash32 of g[0,len) by one wavefront: the chunk is streamed 256 bytes per coalesced load, the four
+// stripe accumulators live in lanes 0..3 and pull their words out of the block by cross-lane reads.
+// (Fused into the compress kernel it also brings the chunk into L2 right before the parse.)
+__device__ __forceinline__ uint32_t xxh32_wave(const uint8_t* g, int len, uint32_t seed, int lane) {
+  uint32_t acc = lane == 0 ? seed + XXP1 + XXP2 : lane == 1 ? seed + XXP2 : lane == 2 ? seed : seed - XXP1;
+  const int stripes = len >> 4, nblk = len >> 8;
+  auto ld32u = [&](int byte_pos) -> uint32_t {
+    uint32_t x;
+    __builtin_memcpy(&x, g + byte_pos, 4);
+    return x;
+  };
+  uint32_t cur = nblk > 0 ? ld32u(4 * lane) : 0u;
+  for (int bk = 0; bk < nblk; bk++) {
+    const uint32_t nxt = bk + 1 < nblk ? ld32u(256 * (bk + 1) + 4 * lane) : 0u;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const uint32_t wv = (uint32_t)__shfl((int)cur, 4 * j + (lane & 3));
+      acc = rotl32(acc + wv * XXP2, 13) * XXP1;
+    }
+    cur = nxt;
+  }
+  for (int j = nblk * 16; j < stripes; j++) acc = rotl32(acc + ld32u(16 * j + 4 * (lane & 3)) * XXP2, 13) * XXP1;
+  uint32_t h;
+  if (len >= 16) {
+    const uint32_t v1 = __builtin_amdgcn_readlane(acc, 0), v2 = __builtin_amdgcn_readlane(acc, 1),
+                   v3 = __builtin_amdgcn_readlane(acc, 2), v4 = __builtin_amdgcn_readlane(acc, 3);
+    h = rotl32(v1, 1) + rotl32(v2, 7) + rotl32(v3, 12) + rotl32(v4, 18);
+  } else {
+    h = seed + XXP5;
+  }
+  h += (uint32_t)len;
+  int p = stripes << 4;
+  for (; p + 4 <= len; p += 4) h = rotl32(h + ld32u(p) * XXP3, 17) * XXP4;
+  for (; p < len; p++) h = rotl32(h + (uint32_t)g[p] * XXP5, 11) * XXP1;
+  h ^= h >> 15;
+  h *= XXP2;
+  h ^= h >> 13;
+  h *= XXP3;
+  h ^= h >> 16;
+  return h;
+}
+
 // ---- variant B: chunk read in place, only the table in LDS ----------------------------------
-template <int kMode>
+template <int kMode, bool kFusedHash = false>
 __global__ __launch_bounds__(kWave) void lz4_compress_l2_kernel(
     const uint8_t* __restrict__ src, const Item* __restrict__ items, int32_t n_items,
     const uint32_t* __restrict__ item_check, uint8_t* __restrict__ slots,
@@ -1145,14 +1190,15 @@ __global__ __launch_bounds__(kWave) void lz4_compress_l2_kernel(
   }
   __syncthreads();
   uint8_t* slot = slots + (size_t)item.chunk * kSlotBytes;
+  uint32_t check;
+  if constexpr (kFusedHash) check = xxh32_wave(src + item.src_off, item.len, kLz4BlockSeed, lane);
+  else check = item_check[it];
   const int clen = lz4_compress_wave<SrcGlobal, kMode>(SrcGlobal{src + item.src_off}, (lds_u16*)table,
                                                       item.len, slot + kSlotHeader, lane);
-  finish_frame(slot, item.len, clen, item_check[it], item.kind >> 8, item_size + it, lane);
+  finish_frame(slot, item.len, clen, check, item.kind >> 8, item_size + it, lane);
 }
 
 // ---- xxHash32 of every chunk: 4 lanes per chunk (one per stripe accumulator) ----------------
-constexpr uint32_t XXP1 = 2654435761u, XXP2 = 2246822519u, XXP3 = 3266489917u,
-                   XXP4 = 668265263u, XXP5 = 374761393u;
 constexpr int kXxhThreads = 256;
 
 __device__ __forceinline__ uint32_t ld32u(const uint8_t* p) {
@@ -1211,8 +1257,9 @@ void launch_lz4_compress(const uint8_t* d_src, const Item* d_items, int32_t n_it
     if (after_hash) hipEventRecord(after_hash, st);
     return;
   }
-  hipLaunchKernelGGL(xxh32_items_kernel, dim3((unsigned)((n_items + kXxhThreads / 4 - 1) / (kXxhThreads / 4))),
-                     dim3(kXxhThreads), 0, st, d_src, d_items, n_items, kLz4BlockSeed, d_item_check);
+  if (variant != 5)  // variant 5 computes the frame check inside the compress kernel
+    hipLaunchKernelGGL(xxh32_items_kernel, dim3((unsigned)((n_items + kXxhThreads / 4 - 1) / (kXxhThreads / 4))),
+                       dim3(kXxhThreads), 0, st, d_src, d_items, n_items, kLz4BlockSeed, d_item_check);
   if (after_hash) hipEventRecord(after_hash, st);
   if (variant == 0)
     hipLaunchKernelGGL(lz4_compress_lds_kernel, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
@@ -1226,8 +1273,11 @@ void launch_lz4_compress(const uint8_t* d_src, const Item* d_items, int32_t n_it
   else if (variant == 3)
     hipLaunchKernelGGL(lz4_compress_l2_kernel<2>, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
                        d_items, n_items, d_item_check, d_slots, d_item_size);
-  else
+  else if (variant == 4)
     hipLaunchKernelGGL(lz4_compress_l2_kernel<3>, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
+                       d_items, n_items, d_item_check, d_slots, d_item_size);
+  else
+    hipLaunchKernelGGL((lz4_compress_l2_kernel<0, true>), dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
                        d_items, n_items, d_item_check, d_slots, d_item_size);
 }
 

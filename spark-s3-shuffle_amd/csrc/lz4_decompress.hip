@@ -1212,12 +1212,20 @@ __global__ __launch_bounds__(kWave) void lz4_decompress_valu_kernel(
       ml += 4;
       // one scalar decision word: bit0 malformed, bit1 near (source in the ring), bit2 single round
       const int near = (offset + kWave <= kRing);
-      const int dec = ((offset == 0) | (offset > op) | (ml > olen - op)) | (near << 1) | ((ml <= kWave) << 2);
+      const int dec = ((offset == 0) | (offset > op) | (ml > olen - op)) | (near << 1) | ((ml <= kWave) << 2) |
+                      ((offset >= kWave) << 3);
       const int decu = __builtin_amdgcn_readfirstlane(dec);
       if (decu & 1) { bad = 1; break; }
-      if ((decu & 6) == 6) {
-        // near, one round: byte j of the copy is source byte j (mod offset when the copy overlaps)
-        const int sj = offset >= kWave ? lane : (lane % offset);
+      if ((decu & 14) == 14) {
+        // near, one round, no overlap (the common copy): LDS -> LDS + global
+        if (lane < ml) {
+          const uint8_t bv = ring[(op - offset + lane) & (kRing - 1)];
+          ring[(op + lane) & (kRing - 1)] = bv;
+          out[op + lane] = bv;
+        }
+      } else if ((decu & 6) == 6) {
+        // near, one round, overlapping: byte j of the copy is source byte j mod offset
+        const int sj = lane % offset;
         if (lane < ml) {
           const uint8_t bv = ring[(op - offset + sj) & (kRing - 1)];
           ring[(op + lane) & (kRing - 1)] = bv;

@@ -353,11 +353,17 @@ __global__ __launch_bounds__(kWave) void snappy_decompress_valu_kernel(
       if (kind == 0) continue;
       // ---- copy of len <= 64 bytes ------------------------------------------------------------------
       const int near = (offset + kWave <= kSnRing);
-      const int dec = ((offset == 0) | (offset > op) | (len > olen - op)) | (near << 1);
+      const int dec = ((offset == 0) | (offset > op) | (len > olen - op)) | (near << 1) | ((offset >= kWave) << 2);
       const int decu = __builtin_amdgcn_readfirstlane(dec);
       if (decu & 1) { bad = 1; break; }
-      if (decu & 2) {
-        const int sj = offset >= kWave ? lane : (lane % offset);  // overlap: periodic
+      if ((decu & 6) == 6) {
+        if (lane < len) {  // the common copy: no overlap
+          const uint8_t bv = ring[(op - offset + lane) & (kSnRing - 1)];
+          ring[(op + lane) & (kSnRing - 1)] = bv;
+          out[op + lane] = bv;
+        }
+      } else if (decu & 2) {
+        const int sj = lane % offset;  // overlap: periodic
         if (lane < len) {
           const uint8_t bv = ring[(op - offset + sj) & (kSnRing - 1)];
           ring[(op + lane) & (kSnRing - 1)] = bv;

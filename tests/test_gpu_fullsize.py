@@ -1,0 +1,83 @@
+"""Full-size property checks on the GPU (BASELINE.json sizes, where the oracle would take too long):
+size-independent properties instead of byte comparison — compress -> verify+decompress round trip,
+index consistency, checksum-of-output re-derived by the checksum kernel, idempotence (same bytes on a
+second run and on a second context) — plus an oracle spot check on a few whole partitions."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LZ4, SNAPPY = 1, 2
+ADLER, CRC = 1, 2
+
+
+def _roundtrip(gpu_codec, oracle, codec, algo, data, offsets, spot_parts=()):
+    """Host-buffer entry points on purpose (no torch in the test process: the library brings its own
+    HIP runtime binding and must be the only one initialised)."""
+    import s3shuffle
+
+    img, index, sums = gpu_codec.compress_map_output(codec, algo, data, offsets)
+    total = img.size
+    assert index[0] == 0 and index[-1] == total and (np.diff(index) >= 0).all()
+    empty = np.diff(np.asarray(offsets)) == 0
+    assert (np.diff(index)[empty] == 0).all()                      # empty partition = 0 bytes
+    # checksums over the compressed bytes, recomputed by the checksum-only entry point
+    again = gpu_codec.checksum_ranges(algo, img, index)
+    assert np.array_equal(again, sums)
+    # idempotence: a second context produces the same image
+    with s3shuffle.Codec(0) as other:
+        img2, index2, sums2 = other.compress_map_output(codec, algo, data, offsets)
+        assert np.array_equal(index2, index) and np.array_equal(sums2, sums) and np.array_equal(img2, img)
+        del img2
+    # reduce side: whole range (batch fetch of every partition) round-trips
+    out = gpu_codec.decompress_range(codec, algo, img, index, sums, dst_capacity=data.size)
+    assert out.size == data.size and np.array_equal(out, data)
+    del out
+    # oracle spot check on a few whole partitions (their streams are self-contained)
+    for p in spot_parts:
+        part = data[offsets[p]:offsets[p + 1]]
+        want = oracle.compress_stream(codec, part) if part.size else np.zeros(0, np.uint8)
+        assert np.array_equal(img[index[p]:index[p + 1]], want), p
+        assert sums[p] == oracle.checksum(algo, want)
+    return total
+
+
+def test_terasort_128mib_200_partitions_lz4(gpu_codec, oracle):
+    from s3shuffle import datagen
+
+    data, offs = datagen.terasort_map_output(128 << 20, 200, seed=2, map_id=1)
+    total = _roundtrip(gpu_codec, oracle, LZ4, ADLER, data, offs, spot_parts=(0, 99, 199))
+    assert 3.5 < data.size / total < 5.5
+
+
+def test_terasort_128mib_2000_partitions_lz4_crc32(gpu_codec, oracle):
+    from s3shuffle import datagen
+
+    data, offs = datagen.terasort_map_output(128 << 20, 2000, seed=4, map_id=5)
+    _roundtrip(gpu_codec, oracle, LZ4, CRC, data, offs, spot_parts=(0, 1000, 1999))
+
+
+def test_skew_1gib_single_partition_lz4(gpu_codec, oracle):
+    from s3shuffle import datagen
+
+    data, offs = datagen.skew_block(1 << 30, "terasort", seed=5)
+    _roundtrip(gpu_codec, oracle, LZ4, ADLER, data, offs)
+
+
+def test_skew_extremes_256mib(gpu_codec, oracle):
+    from s3shuffle import datagen
+
+    for kind in ("zeros", "random"):
+        data, offs = datagen.skew_block(256 << 20, kind, seed=5)
+        total = _roundtrip(gpu_codec, oracle, LZ4, CRC, data, offs)
+        if kind == "random":
+            assert total == data.size + 21 * (data.size // 32768) + 21   # every frame stored RAW
+        else:
+            assert total < data.size // 200
+
+
+def test_tpcds_wide_128mib_snappy(gpu_codec, oracle):
+    from s3shuffle import datagen
+
+    data, offs = datagen.tpcds_wide_map_output(128 << 20, 200, seed=3)
+    _roundtrip(gpu_codec, oracle, SNAPPY, ADLER, data, offs, spot_parts=(0, 100))
