@@ -92,10 +92,11 @@ enum {
                                     supported 1024..32768 (snappy-java raises smaller values
                                     to 1024) */
   S3S_OPT_PROFILE = 3,           /* 1: record per-stage HIP-event timings (s3s_stage_ms) */
-  S3S_OPT_LZ4_VARIANT = 4,       /* tuning, identical output: 0 = chunk staged in LDS (3
-                                    wavefronts per CU), 1 = chunk read through L1/L2, table-only
-                                    LDS (10 per CU; default), 2 = 1 + window-speculative parse,
-                                    3 = 2 with software-pipelined windows */
+  S3S_OPT_LZ4_VARIANT = 4,       /* tuning, identical output: 0 = chunk staged in LDS (3 wavefronts per CU),
+                                    1 = chunk read through L1/L2, table-only LDS (10 per CU; default),
+                                    2 = 1 + exact-window parse, 3 = 2 software-pipelined, 4 = 3 with the
+                                    run loop on the vector ALU, 5 = 1 with the frame check fused in,
+                                    6 / 7 = 1 at 5 / 7 wavefronts per CU (occupancy experiments) */
   S3S_OPT_LZ4_DECODE_VARIANT = 5 /* tuning, identical output (Snappy: 0 = staged in LDS, else the
                                     VALU ring decoder): 0 = frame staged in LDS, 1 = decoded
                                     straight to global memory, 2 = 1 + 8 KiB LDS ring of recent

@@ -101,7 +101,7 @@ int s3s_set_option(s3s_ctx* ctx, int key, int64_t value) {
       ctx->lz4_decode_variant = (int)value;
       return S3S_OK;
     case S3S_OPT_LZ4_VARIANT:
-      if (value < 0 || value > 5) return fail(ctx, S3S_E_INVALID, "lz4 variant must be 0..5");
+      if (value < 0 || value > 7) return fail(ctx, S3S_E_INVALID, "lz4 variant must be 0..7");
       ctx->lz4_variant = (int)value;
       return S3S_OK;
   }

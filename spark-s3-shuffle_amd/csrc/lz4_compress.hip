@@ -1169,12 +1169,12 @@ __device__ __forceinline__ uint32_t xxh32_wave(const uint8_t* g, int len, uint32
 }
 
 // ---- variant B: chunk read in place, only the table in LDS ----------------------------------
-template <int kMode, bool kFusedHash = false>
+template <int kMode, bool kFusedHash = false, int kLdsPad = 0>
 __global__ __launch_bounds__(kWave) void lz4_compress_l2_kernel(
     const uint8_t* __restrict__ src, const Item* __restrict__ items, int32_t n_items,
     const uint32_t* __restrict__ item_check, uint8_t* __restrict__ slots,
     uint32_t* __restrict__ item_size) {
-  __shared__ __attribute__((aligned(16))) uint16_t table[8192];
+  __shared__ __attribute__((aligned(16))) uint16_t table[8192 + kLdsPad / 2];  // kLdsPad: occupancy experiments
   const int it = blockIdx.x;
   if (it >= n_items) return;
   const Item item = items[it];
@@ -1289,8 +1289,14 @@ void launch_lz4_compress(const uint8_t* d_src, const Item* d_items, int32_t n_it
   else if (variant == 4)
     hipLaunchKernelGGL(lz4_compress_l2_kernel<3>, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
                        d_items, n_items, d_item_check, d_slots, d_item_size);
-  else
+  else if (variant == 5)
     hipLaunchKernelGGL((lz4_compress_l2_kernel<0, true>), dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
+                       d_items, n_items, d_item_check, d_slots, d_item_size);
+  else if (variant == 6)  // occupancy experiment: 5 wavefronts per CU
+    hipLaunchKernelGGL((lz4_compress_l2_kernel<0, false, 16384>), dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
+                       d_items, n_items, d_item_check, d_slots, d_item_size);
+  else  // occupancy experiment: 7 wavefronts per CU
+    hipLaunchKernelGGL((lz4_compress_l2_kernel<0, false, 6144>), dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
                        d_items, n_items, d_item_check, d_slots, d_item_size);
 }
 
