@@ -97,6 +97,8 @@ enum {
                                     2 = 1 + exact-window parse, 3 = 2 software-pipelined, 4 = 3 with the
                                     run loop on the vector ALU, 5 = 1 with the frame check fused in,
                                     6 / 7 = 1 at 5 / 7 wavefronts per CU (occupancy experiments) */
+  S3S_OPT_SNAPPY_VARIANT = 6,    /* tuning, identical output: 0 = general batch only, 1 (default) = exact
+                                    64-byte windows in front of it (several copies per round trip) */
   S3S_OPT_LZ4_DECODE_VARIANT = 5 /* tuning, identical output (Snappy: 0 = staged in LDS, else the
                                     VALU ring decoder): 0 = frame staged in LDS, 1 = decoded
                                     straight to global memory, 2 = 1 + 8 KiB LDS ring of recent

@@ -100,6 +100,10 @@ int s3s_set_option(s3s_ctx* ctx, int key, int64_t value) {
       if (value < 0 || value > 3) return fail(ctx, S3S_E_INVALID, "lz4 decode variant must be 0..3");
       ctx->lz4_decode_variant = (int)value;
       return S3S_OK;
+    case S3S_OPT_SNAPPY_VARIANT:
+      if (value < 0 || value > 1) return fail(ctx, S3S_E_INVALID, "snappy variant must be 0..1");
+      ctx->snappy_variant = (int)value;
+      return S3S_OK;
     case S3S_OPT_LZ4_VARIANT:
       if (value < 0 || value > 7) return fail(ctx, S3S_E_INVALID, "lz4 variant must be 0..7");
       ctx->lz4_variant = (int)value;
@@ -116,6 +120,7 @@ int64_t s3s_get_option(const s3s_ctx* ctx, int key) {
     case S3S_OPT_PROFILE: return ctx->profile;
     case S3S_OPT_LZ4_VARIANT: return ctx->lz4_variant;
     case S3S_OPT_LZ4_DECODE_VARIANT: return ctx->lz4_decode_variant;
+    case S3S_OPT_SNAPPY_VARIANT: return ctx->snappy_variant;
   }
   return S3S_E_INVALID;
 }
@@ -262,7 +267,7 @@ int s3s_compress_map_output_device(s3s_ctx* ctx, int codec, int checksum_algo,
                           ctx->lz4_variant, ctx->stream, ctx->profile ? ctx->ev_hash : nullptr);
     else
       launch_snappy_compress(d_src, dev<Item>(ctx, B_ITEMS), n_items, dev<uint8_t>(ctx, B_SLOTS),
-                             slot_stride, dev<uint32_t>(ctx, B_ITEM_SIZE), ctx->stream);
+                             slot_stride, dev<uint32_t>(ctx, B_ITEM_SIZE), ctx->snappy_variant, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     record(ctx, 1);
     launch_scan_items(dev<Item>(ctx, B_ITEMS), dev<uint32_t>(ctx, B_ITEM_SIZE), n_items,

@@ -36,6 +36,7 @@ struct s3s_ctx {
   int profile = 0;
   int lz4_variant = 1;
   int lz4_decode_variant = 3;
+  int snappy_variant = 1;
   s3s::DevBuf buf[s3s::B_COUNT];
   void* h_stage = nullptr;  // pinned
   size_t h_stage_cap = 0;

@@ -56,7 +56,7 @@ bool snappy_compress_available();
 //   slot_stride: bytes between slots (a raw snappy block can be larger than its chunk)
 void launch_snappy_compress(const uint8_t* d_src, const Item* d_items, int32_t n_items,
                             uint8_t* d_slots, int64_t slot_stride, uint32_t* d_item_size,
-                            hipStream_t st);
+                            int variant, hipStream_t st);  // variant 0: batch only, 1: exact windows first
 // exclusive scan of item sizes + partition index extraction
 void launch_scan_items(const Item* d_items, const uint32_t* d_item_size, int32_t n_items,
                        int64_t* d_item_off, const int32_t* d_part_first, int32_t n_parts,

@@ -18,6 +18,21 @@
 //   * after a copy: insert ip-1, probe ip (probe index 0), then the search restarts at ip+1;
 //   * element encoding: literal tags with 1-2 length bytes, 2- and 3-byte copies, long matches
 //     are split into 64/60-byte copies.
+//
+// In front of the batch sits the EXACT WINDOW path (tests/model/snappy_window_model.cpp is its
+// lock-step CPU model).  Shuffle rows are match-dense (a 32 KiB block of wide rows holds ~3500
+// copies of ~8 bytes), and the batch finds one copy per memory round trip.  The window path cuts
+// the fragment into aligned 64-byte windows, lane i <-> position 64k+i, and prepares a whole
+// window with one table read and ONE memory round trip:
+//     cp   = T[h]                 table candidate of every lane (nothing of the window is in T yet)
+//     grp  = lane shares its hash with another live lane (two speculative store passes, rolled back)
+//     fl   = number of equal bytes at p / cp (68 bytes of each loaded speculatively), em = fl >= 4
+// The probes a run makes are a fixed pattern of the distance d to the run's base (d <= 33 every
+// byte, 35..65 every 2nd, 68..98 every 3rd), so all runs of a window are resolved with scalar mask
+// arithmetic: first event lane of the run; a grp lane's true candidate is the highest kept lane
+// below it with the same hash (its bytes are in the window's registers), else cp.  K collects
+// what the sequential code inserts (probes, and ip-1 after every copy); the highest kept lane of
+// every hash commits with one store at the end of the window.
 #include "s3s_internal.h"
 
 namespace s3s {
@@ -125,9 +140,55 @@ __device__ __forceinline__ int sn_emit_copy(uint8_t* out, int op, int offset, in
   return op + 3;
 }
 
+// FindMatchLength(candidate + 4 + extra, ip + 4 + extra, ip_end), 256 bytes per round; the first
+// `extra` bytes are known to be equal.  Returns the total number of bytes beyond the first four.
+__device__ __forceinline__ int sn_find_match(const uint8_t* in, int ip0, int cand, int len, int last4,
+                                             int extra, int lane) {
+  for (;;) {
+    const int avail = len - (ip0 + 4 + extra);
+    if (avail <= 0) break;
+    // the match may run to the very last byte: a lane whose dword would cross the end reads the
+    // last dword of the chunk instead and drops the bytes in front of its own position
+    const int fpi = ip0 + 4 + extra + 4 * lane;
+    const int fp = fpi < last4 ? fpi : last4;
+    uint32_t x = sn_rd32(in, fp) ^ sn_rd32(in, fp - (ip0 - cand));
+    const int over = fpi - fp;
+    x = over >= 4 ? 0u : (x >> (8 * over));
+    const uint64_t D = __ballot(x != 0u);
+    int got = 4 * kWave;
+    if (D) {
+      const int f = __builtin_ctzll(D);
+      const uint32_t xf = __builtin_amdgcn_readlane(x, f);
+      got = 4 * f + (__builtin_ctz(xf) >> 3);
+    }
+    got = got < avail ? got : avail;
+    extra += got;
+    if (got < 4 * kWave) break;
+  }
+  return extra;
+}
+
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 
+__device__ __forceinline__ uint4 sn_ld16(const uint8_t* base, int pos) {
+  uint4 x;
+  __builtin_memcpy(&x, base + pos, 16);  // unaligned global_load_dwordx4
+  return x;
+}
+
+// index of the first non-zero byte of x (16 if none)
+__device__ __forceinline__ int sn_first_diff16(uint4 x) {
+  int r = 16;
+  r = x.w ? 12 + (__builtin_ctz(x.w) >> 3) : r;
+  r = x.z ? 8 + (__builtin_ctz(x.z) >> 3) : r;
+  r = x.y ? 4 + (__builtin_ctz(x.y) >> 3) : r;
+  r = x.x ? (__builtin_ctz(x.x) >> 3) : r;
+  return r;
+}
+
 // The parse of one fragment (chunk <= 32 KiB).  Returns the number of bytes written.
+// kWin: exact windows in front of the general batch (header comment).
+template <bool kWin>
 __device__ int snappy_compress_wave(const uint8_t* in, lds_u16* table, int len, uint8_t* out, int lane) {
   volatile lds_u16* T = table;
   int op = 0;
@@ -147,7 +208,175 @@ __device__ int snappy_compress_wave(const uint8_t* in, lds_u16* table, int len, 
   if (len >= kSnInputMargin) {
     const int ip_limit = len - kSnInputMargin;
     int rbase = 0, u0 = 1;  // run base and first probe index of the next batch
+    // windows: far enough from the end that no probe of a window meets ip_limit and the
+    // speculative 68-byte loads stay inside the fragment
+    const int fast_limit = len - 192;
+    int kn = -1, kp = -1;     // window bases whose dwords are held in vn / vp
+    uint32_t vn = 0, vp = 0;  // dwords of the next and of the previous window
+    bool finished = false;
     for (;;) {
+      if constexpr (kWin) {
+        // position of probe u0 (closed form of sn_Q for u0 <= 60)
+        const int q0 = u0 <= 33 ? u0 : (u0 <= 49 ? 2 * u0 - 33 : 3 * u0 - 82);
+        const int wbase = (rbase + q0) & ~63;
+        if (u0 <= 60 && wbase + 63 - rbase <= 98 && wbase <= fast_limit) {
+          // ================= window preparation (vector work, lane = position) ====================
+          const int p = wbase + lane;
+          const uint32_t v = (kn == wbase) ? vn : sn_rd32(in, p);
+          if (kp != wbase - 64) vp = sn_rd32(in, wbase >= 64 ? p - 64 : p);
+          vn = sn_rd32(in, p + 64);
+          kn = wbase + 64;
+          const uint32_t h = (v * 0x1e35a7bdu) >> shift;
+          const int rs0 = rbase + q0 - wbase;
+          const bool live = lane >= rs0;
+          const uint32_t cp = T[h];
+          // 68 bytes at the position and at its table candidate, one round trip
+          const uint4 b0 = sn_ld16(in, (int)cp), b1 = sn_ld16(in, (int)cp + 16);
+          const uint4 b2 = sn_ld16(in, (int)cp + 32), b3 = sn_ld16(in, (int)cp + 48);
+          const uint32_t b4 = sn_rd32(in, (int)cp + 64);
+          const uint4 a0 = sn_ld16(in, p), a1 = sn_ld16(in, p + 16);
+          const uint4 a2 = sn_ld16(in, p + 32), a3 = sn_ld16(in, p + 48);
+          // duplicate-hash groups among the live lanes: two speculative store passes, rolled back
+          // (lanes of a group of >= 2 either lose pass 1 or see pass 2's winner)
+          bool grp = false;
+          if (live) {
+            T[h] = (uint16_t)p;
+            const uint32_t r1 = T[h];
+            const bool lost1 = r1 != (uint32_t)p;
+            if (lost1) T[h] = (uint16_t)p;
+            const uint32_t r2 = T[h];
+            grp = lost1 || (r2 != (uint32_t)p);
+            if (r2 == (uint32_t)p) T[h] = (uint16_t)cp;  // the slot's current owner restores it
+          }
+          // runs entering the window probe a fixed pattern of the distance to their base
+          const int dd = p - rbase;
+          const bool isprobe = live && (dd <= 33 || (dd <= 65 ? (dd & 1) != 0 : (dd >= 68 && (dd + 1) % 3 == 0)));
+          uint64_t runmask = __ballot(isprobe);
+          // equal bytes at p / cp: 0..68
+          const int f0 = sn_first_diff16(make_uint4(a0.x ^ b0.x, a0.y ^ b0.y, a0.z ^ b0.z, a0.w ^ b0.w));
+          const int f1 = sn_first_diff16(make_uint4(a1.x ^ b1.x, a1.y ^ b1.y, a1.z ^ b1.z, a1.w ^ b1.w));
+          const int f2 = sn_first_diff16(make_uint4(a2.x ^ b2.x, a2.y ^ b2.y, a2.z ^ b2.z, a2.w ^ b2.w));
+          const int f3 = sn_first_diff16(make_uint4(a3.x ^ b3.x, a3.y ^ b3.y, a3.z ^ b3.z, a3.w ^ b3.w));
+          const uint32_t x4 = vn ^ b4;  // the dword at p + 64 is the next window's own dword
+          const int f4 = x4 ? (__builtin_ctz(x4) >> 3) : 4;
+          int fl = 64 + f4;
+          fl = f3 < 16 ? 48 + f3 : fl;
+          fl = f2 < 16 ? 32 + f2 : fl;
+          fl = f1 < 16 ? 16 + f1 : fl;
+          fl = f0 < 16 ? f0 : fl;
+          const bool em = live && fl >= 4;
+          // per-lane record: [15:0] table candidate, [22:16] equal bytes beyond the first four (64 =
+          // at least), [29] candidate matches, [31] member of a duplicate-hash group
+          const uint32_t info = cp | ((uint32_t)(em ? fl - 4 : 0) << 16) | (em ? 0x20000000u : 0u) | (grp ? 0x80000000u : 0u);
+          asm volatile("" : "+v"(vn));  // landed: keep later uses from draining the in-order vmcnt queue
+          const uint64_t Ecp = __ballot(em);
+          const uint64_t Dp = __ballot(grp);
+          uint64_t ED = Ecp | Dp;
+          // ================= runs (scalar work) =====================================================
+          const uint64_t PM = 0xAAAAAAAA00000000ull | ((1ull << 34) - 1ull);  // d: 0..33, 35, 37, .., 63
+          uint64_t K = 0;  // lanes the sequential code inserts: probes, and ip-1 after every copy
+          int rt = u0, pend_q = -1;
+          for (;;) {
+            const uint64_t cm = ED & runmask;
+            if (cm == 0ull) {  // the run leaves the window without a match
+              K |= runmask;
+              u0 = rt + __popcll(runmask);
+              break;
+            }
+            const int m = __builtin_ctzll(cm);
+            const uint64_t bit = 1ull << m;
+            const uint32_t inf = __builtin_amdgcn_readlane(info, m);
+            const int ip0 = wbase + m;
+            int cand = (int)(inf & 0xffffu);
+            int extra = (int)((inf >> 16) & 0x7fu);
+            bool capped = extra >= 64;
+            if (__builtin_expect((int)inf < 0, 0)) {
+              // ---- another live lane has the same hash: the candidate may be inside the window ----
+              bool is_match = (inf & 0x20000000u) != 0u;
+              const uint32_t hv = __builtin_amdgcn_readlane(h, m);
+              const uint64_t dk = __ballot(h == hv) & (bit - 1ull) & (K | runmask);
+              if (dk) {
+                const int d = 63 - __builtin_clzll(dk);
+                is_match = __builtin_amdgcn_readlane(v, d) == __builtin_amdgcn_readlane(v, m);
+                if (is_match) {
+                  // bytes behind both positions are in the registers of this and the next window
+                  const int oa = d + 4 + lane, ob = m + 4 + lane;
+                  const uint32_t a_lo = __shfl(v, oa & 63), a_hi = __shfl(vn, oa & 63);
+                  const uint32_t b_lo = __shfl(v, ob & 63), b_hi = __shfl(vn, ob & 63);
+                  const uint32_t ba = (oa < 64 ? a_lo : a_hi) & 0xffu, bb = (ob < 64 ? b_lo : b_hi) & 0xffu;
+                  const uint64_t E = __ballot(ba != bb || ob > 127);
+                  extra = E ? __builtin_ctzll(E) : 64;
+                  capped = m + 4 + extra > 127 || extra >= 64;
+                  cand = wbase + d;
+                }
+              }
+              if (!is_match) {
+                ED &= ~bit;  // a plain no-match probe: the run goes on behind it
+                continue;
+              }
+            }
+            if (__builtin_expect(capped, 0)) extra = sn_find_match(in, ip0, cand, len, last4, extra, lane);
+            K |= runmask & ((bit << 1) - 1ull);
+            const int lit = ip0 - next_emit, offset = ip0 - cand, matched = 4 + extra;
+            if (__builtin_expect(lit <= 60 && next_emit >= wbase - 64 && matched <= 64, 1)) {
+              // literal tag | literals | copy in ONE store: every literal is the low byte of a lane's
+              // dword of this or the previous window; otherwise idle lanes carry the tag bytes
+              const bool two = matched < 12 && offset < 2048;
+              const int hdr = lit > 0 ? 1 : 0;
+              const int total = hdr + lit + (two ? 2 : 3);
+              const uint32_t c0 = two ? (uint32_t)(1 + ((matched - 4) << 2) + ((offset >> 8) << 5))
+                                      : (uint32_t)(2 + ((matched - 1) << 2));
+              const uint32_t c1 = (uint32_t)offset;
+              const int rel = (lane - next_emit) & 63;
+              const int k = rel - lit;  // 0: literal tag (if any), then the copy bytes
+              const int j = k - hdr;
+              uint32_t bv = ((next_emit + rel < wbase) ? vp : v) & 0xffu;
+              int idx = 1 + rel;
+              if (k >= 0) {
+                idx = (k == 0) ? 0 : lit + k;
+                bv = (j < 0) ? (uint32_t)((lit - 1) << 2) : (j == 0 ? c0 : (j == 1 ? c1 : (uint32_t)offset >> 8));
+              }
+              if (rel < total) out[op + idx] = (uint8_t)bv;
+              op += total;
+            } else {
+              if (lit > 0) op = sn_emit_literal(out, op, in, next_emit, lit, lane);
+              op = sn_emit_copy(out, op, offset, matched, extra < 8, lane);
+            }
+            const int ipe = ip0 + matched;
+            next_emit = ipe;
+            if (__builtin_expect(ipe >= ip_limit, 0)) {
+              finished = true;
+              break;
+            }
+            const int q = ipe - 1 - wbase;  // table[Hash(ip - 1)] = ip - 1
+            if (q < kWave) K |= 1ull << q;
+            else pend_q = ipe - 1;
+            rbase = ipe;
+            u0 = 0;
+            if (ipe >= wbase + kWave) break;
+            rt = 0;
+            runmask = PM << (ipe - wbase);
+          }
+          if (finished) break;
+          // ================= commit: the highest kept lane of every hash writes ====================
+          uint64_t Wm = K, sus = K & Dp;
+          while (sus) {
+            const int i = __builtin_ctzll(sus);
+            sus &= sus - 1ull;
+            const uint32_t hv = __builtin_amdgcn_readlane(h, i);
+            if (__ballot(h == hv) & K & ~((2ull << i) - 1ull)) Wm &= ~(1ull << i);
+          }
+          if ((Wm >> lane) & 1ull) T[h] = (uint16_t)p;
+          if (pend_q >= 0) {
+            const uint32_t vq = pend_q < wbase + 2 * kWave ? __builtin_amdgcn_readlane(vn, pend_q - wbase - kWave)
+                                                          : sn_rd32(in, pend_q);
+            T[(vq * 0x1e35a7bdu) >> shift] = (uint16_t)pend_q;
+          }
+          vp = v;
+          kp = wbase;
+          continue;
+        }
+      }
       // ---- one batch: lane i evaluates probe u0+i of the current run ------------------------------
       int nl = kWave;               // lanes offered
       if (u0 <= 1) nl = 34 - u0;    // the consecutive part of a fresh run needs no schedule lookup
@@ -204,29 +433,7 @@ __device__ int snappy_compress_wave(const uint8_t* in, lds_u16* table, int len, 
       const int ip0 = (int)__builtin_amdgcn_readlane((uint32_t)pos, m);
       const int cand = adj ? (int)__builtin_amdgcn_readlane((uint32_t)pos, m - 1)
                            : (int)__builtin_amdgcn_readlane(c, m);
-      // FindMatchLength(candidate + 4, ip + 4, ip_end): 256 bytes per round
-      int extra = 0;
-      for (;;) {
-        const int avail = len - (ip0 + 4 + extra);
-        if (avail <= 0) break;
-        // the match may run to the very last byte: a lane whose dword would cross the end reads the
-        // last dword of the chunk instead and drops the bytes in front of its own position
-        const int fpi = ip0 + 4 + extra + 4 * lane;
-        const int fp = fpi < last4 ? fpi : last4;
-        uint32_t x = sn_rd32(in, fp) ^ sn_rd32(in, fp - (ip0 - cand));
-        const int over = fpi - fp;
-        x = over >= 4 ? 0u : (x >> (8 * over));
-        const uint64_t D = __ballot(x != 0u);
-        int got = 4 * kWave;
-        if (D) {
-          const int f = __builtin_ctzll(D);
-          const uint32_t xf = __builtin_amdgcn_readlane(x, f);
-          got = 4 * f + (__builtin_ctz(xf) >> 3);
-        }
-        got = got < avail ? got : avail;
-        extra += got;
-        if (got < 4 * kWave) break;
-      }
+      const int extra = sn_find_match(in, ip0, cand, len, last4, 0, lane);
       if (ip0 > next_emit) op = sn_emit_literal(out, op, in, next_emit, ip0 - next_emit, lane);
       const int matched = 4 + extra;
       op = sn_emit_copy(out, op, ip0 - cand, matched, extra < 8, lane);
@@ -242,6 +449,7 @@ __device__ int snappy_compress_wave(const uint8_t* in, lds_u16* table, int len, 
   return op;
 }
 
+template <bool kWin>
 __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
     const uint8_t* __restrict__ src, const Item* __restrict__ items, int32_t n_items,
     uint8_t* __restrict__ slots, int64_t slot_stride, uint32_t* __restrict__ item_size) {
@@ -261,7 +469,7 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
   }
   __syncthreads();
   uint8_t* slot = slots + (size_t)item.chunk * (size_t)slot_stride;
-  const int clen = snappy_compress_wave(src + item.src_off, (lds_u16*)table, item.len, slot + kSlotHeader, lane);
+  const int clen = snappy_compress_wave<kWin>(src + item.src_off, (lds_u16*)table, item.len, slot + kSlotHeader, lane);
   // SnappyOutputStream.dumpOutput(): i32 BE compressed length in front of the raw block
   if (lane < 4) slot[kSlotHeader - 4 + lane] = (uint8_t)((uint32_t)clen >> (8 * (3 - lane)));
   if (lane == 0) item_size[it] = 4u + (uint32_t)clen;
@@ -273,10 +481,14 @@ bool snappy_compress_available() { return true; }
 
 void launch_snappy_compress(const uint8_t* d_src, const Item* d_items, int32_t n_items,
                             uint8_t* d_slots, int64_t slot_stride, uint32_t* d_item_size,
-                            hipStream_t st) {
+                            int variant, hipStream_t st) {
   if (n_items <= 0) return;
-  hipLaunchKernelGGL(snappy_compress_kernel, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src, d_items,
-                     n_items, d_slots, slot_stride, d_item_size);
+  if (variant == 0)
+    hipLaunchKernelGGL(snappy_compress_kernel<false>, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
+                       d_items, n_items, d_slots, slot_stride, d_item_size);
+  else
+    hipLaunchKernelGGL(snappy_compress_kernel<true>, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
+                       d_items, n_items, d_slots, slot_stride, d_item_size);
 }
 
 }  // namespace s3s

@@ -14,6 +14,7 @@ OPT_LZ4_BLOCK_SIZE, OPT_SNAPPY_BLOCK_SIZE, OPT_PROFILE = 1, 2, 3
 STAGE_TOTAL, STAGE_CODEC, STAGE_ASSEMBLE, STAGE_CHECKSUM, STAGE_DISCOVER, STAGE_HASH = 0, 1, 2, 3, 4, 5
 OPT_LZ4_VARIANT = 4
 OPT_LZ4_DECODE_VARIANT = 5
+OPT_SNAPPY_VARIANT = 6
 
 E_INVALID, E_CAPACITY, E_BAD_FRAME, E_CHECKSUM, E_HIP, E_UNSUPPORTED, E_NOMEM = -1, -2, -3, -4, -5, -6, -7
 _ERR_NAMES = {

@@ -12,13 +12,16 @@ SNAPPY = 2
 ADLER, CRC = 1, 2
 
 
-@pytest.fixture(params=[0, 3], ids=["block-in-lds", "ring-valu"], autouse=True)
-def decode_variant(request, gpu_codec):
-    """Every test runs against both Snappy decoders (S3S_OPT_LZ4_DECODE_VARIANT: 0 / non-zero)."""
-    default = gpu_codec.get_option(5)
-    gpu_codec.set_option(5, request.param)
+@pytest.fixture(params=[(0, 0), (3, 1)], ids=["batch+block-in-lds", "window+ring-valu"], autouse=True)
+def variants(request, gpu_codec):
+    """Every test runs against both Snappy decoders (S3S_OPT_LZ4_DECODE_VARIANT: 0 / non-zero) and
+    both compressor paths (S3S_OPT_SNAPPY_VARIANT: 0 general batch only / 1 exact windows first)."""
+    d_dec, d_cmp = gpu_codec.get_option(5), gpu_codec.get_option(6)
+    gpu_codec.set_option(5, request.param[0])
+    gpu_codec.set_option(6, request.param[1])
     yield request.param
-    gpu_codec.set_option(5, default)
+    gpu_codec.set_option(5, d_dec)
+    gpu_codec.set_option(6, d_cmp)
 
 
 def _check(gpu_codec, oracle, algo, data, offsets, block_size=32768):

@@ -1,0 +1,39 @@
+"""Snappy compress probe: device-resident throughput of both compressor variants on the wide-row
+and the TeraSort workloads (single stream, stage times)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "spark-s3-shuffle_amd")); sys.path.insert(0, ROOT)
+import numpy as np, torch
+import s3shuffle
+from s3shuffle import datagen
+
+def main():
+    size = int(sys.argv[1]) if len(sys.argv) > 1 else (128 << 20)
+    variants = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1]
+    dev = torch.device("cuda:0")
+    torch.zeros(1, device=dev)
+    c = s3shuffle.Codec(0)
+    c.set_option(3, 1)
+    for kind in ("tpcds", "terasort"):
+        data, offs = (datagen.tpcds_wide_map_output(size, 200, seed=5) if kind == "tpcds"
+                      else datagen.terasort_map_output(size, 200, seed=2))
+        d_src = torch.from_numpy(data).to(dev)
+        cap = c.max_compressed_size(2, offs)
+        d_dst = torch.empty(cap, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        ref = None
+        for variant in variants:
+            c.set_option(6, variant)
+            for it in range(3):
+                t = time.perf_counter()
+                total, index, sums = c.compress_map_output_device(2, 1, d_src.data_ptr(), offs, d_dst.data_ptr(), cap)
+                dt = time.perf_counter() - t
+            img = d_dst[:total].cpu().numpy().copy()
+            same = "" if ref is None else f" identical_to_first={bool(np.array_equal(img, ref))}"
+            if ref is None:
+                ref = img
+            print(f"{kind} snappy variant={variant}: U={data.size} C={total} ratio={data.size/total:.2f} wall={dt*1e3:.2f} ms "
+                  f"-> {data.size/dt/1e9:.1f} GB/s | codec={c.stage_ms(1):.2f} ms{same}", flush=True)
+
+if __name__ == "__main__":
+    main()
