@@ -41,6 +41,7 @@ WORKLOADS = {
     # name: (generator, partitions, codec, checksum)
     "terasort-10g-200p-lz4": ("terasort", 200, "lz4", "adler32"),     # configs[1]  (N=1 headline)
     "tpcds-wide-100g-200p-snappy": ("tpcds", 200, "snappy", "adler32"),   # configs[2]
+    "tpcds-wide-100g-200p-lz4": ("tpcds", 200, "lz4", "adler32"),         # configs[2] rows under the default codec
     "terasort-100g-2000p-lz4-crc32": ("terasort", 2000, "lz4", "crc32"),  # configs[3]
     "skew-1part-lz4": ("skew", 1, "lz4", "adler32"),                  # configs[4] (use --direction decompress)
 }
@@ -286,6 +287,11 @@ def main():
         u_all, c_all = u_rank, c_rank
 
     if rank == 0:
+        lz4_parse = None
+        if codec_name == "lz4" and not decompress:
+            setting = codecs[0].get_option(s3shuffle.codec.OPT_LZ4_VARIANT)
+            used = sorted({int(c.get_option(s3shuffle.codec.OPT_LZ4_VARIANT_USED)) for c in codecs})
+            lz4_parse = {"setting": "auto" if setting == 9 else int(setting), "ran_in_last_call": used}
         value = u_all * args.steps / elapsed / 1e9
         launches = max(stage["launches"], 1)
         codec_ms = stage["codec"] / launches          # the LZ4 block-compress kernel alone
@@ -325,6 +331,7 @@ def main():
                 "compression_ratio": round(u_all / max(c_all, 1), 4),
                 "sharding": "mapId % nGPU, no data-path collective",
                 "task_threads_per_gpu": n_threads,
+                "lz4_parse_variant": lz4_parse,
                 "inputs": "resident in HBM before the timed region; index/checksums returned to host per map task",
             },
             "roofline": {

@@ -47,6 +47,8 @@ s3s_ctx* s3s_create(int device_ordinal, int64_t scratch_bytes) {
   for (auto& ev : ctx->ev)
     if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipEventCreate(&ctx->ev_hash)) != hipSuccess) return bail("hipEventCreate", e);
+  for (auto& ev : ctx->ev_auto)
+    if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
   // constant tables for the checksum kernels
   const size_t tb = checksum_tables_bytes();
   std::vector<uint8_t> host_tabs(tb);
@@ -71,6 +73,8 @@ void s3s_destroy(s3s_ctx* ctx) {
   for (auto& ev : ctx->ev)
     if (ev) hipEventDestroy(ev);
   if (ctx->ev_hash) hipEventDestroy(ctx->ev_hash);
+  for (auto& ev : ctx->ev_auto)
+    if (ev) hipEventDestroy(ev);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -105,8 +109,10 @@ int s3s_set_option(s3s_ctx* ctx, int key, int64_t value) {
       ctx->snappy_variant = (int)value;
       return S3S_OK;
     case S3S_OPT_LZ4_VARIANT:
-      if (value < 0 || value > 7) return fail(ctx, S3S_E_INVALID, "lz4 variant must be 0..7");
+      if (value < 0 || value > 9 || value == 8) return fail(ctx, S3S_E_INVALID, "lz4 variant must be 0..7 or 9 (auto)");
       ctx->lz4_variant = (int)value;
+      ctx->auto_samples[0] = ctx->auto_samples[1] = 0;
+      ctx->auto_tick = 0;
       return S3S_OK;
   }
   return fail(ctx, S3S_E_INVALID, "unknown option %d", key);
@@ -119,6 +125,7 @@ int64_t s3s_get_option(const s3s_ctx* ctx, int key) {
     case S3S_OPT_SNAPPY_BLOCK_SIZE: return ctx->snappy_block;
     case S3S_OPT_PROFILE: return ctx->profile;
     case S3S_OPT_LZ4_VARIANT: return ctx->lz4_variant;
+    case S3S_OPT_LZ4_VARIANT_USED: return ctx->lz4_variant_used;
     case S3S_OPT_LZ4_DECODE_VARIANT: return ctx->lz4_decode_variant;
     case S3S_OPT_SNAPPY_VARIANT: return ctx->snappy_variant;
   }
@@ -234,6 +241,9 @@ int s3s_compress_map_output_device(s3s_ctx* ctx, int codec, int checksum_algo,
   if ((rc = ensure(ctx, B_STATUS, 16))) return rc;
   HIP_TRY(ctx, hipMemsetAsync(ctx->buf[B_STATUS].p, 0, 16, ctx->stream));
   record(ctx, 0);
+  bool auto_timed = false;
+  int auto_which = 0;
+  constexpr int64_t kAutoMinBytes = 4 << 20;
 
   if (codec == S3S_CODEC_NONE) {
     // spark.shuffle.compress=false: the partition bytes are the stream
@@ -261,11 +271,26 @@ int s3s_compress_map_output_device(s3s_ctx* ctx, int codec, int checksum_algo,
     HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_PART_FIRST].p, h_pf, pf_bytes, hipMemcpyHostToDevice, ctx->stream));
     // the snappy stream header has a constant size; seed item_size for every item kind the
     // codec kernel does not write
-    if (codec == S3S_CODEC_LZ4)
+    if (codec == S3S_CODEC_LZ4) {
+      int variant = ctx->lz4_variant;
+      if (variant == 9) {  // auto: run the parse that has been faster on this context's data
+        auto_which = ctx->auto_choice;
+        if (total_u >= kAutoMinBytes) {  // large enough for the kernel time to mean something
+          auto_timed = true;
+          if (ctx->auto_samples[0] < 2 || ctx->auto_samples[1] < 2)
+            auto_which = ctx->auto_samples[0] <= ctx->auto_samples[1] ? 0 : 1;  // 1, 2, 1, 2
+          else if (++ctx->auto_tick % 32 == 0)
+            auto_which = 1 - ctx->auto_choice;  // keep the other one's figure fresh
+        }
+        variant = auto_which ? 2 : 1;
+        if (auto_timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_auto[0], ctx->stream));
+      }
+      ctx->lz4_variant_used = variant;
       launch_lz4_compress(d_src, dev<Item>(ctx, B_ITEMS), n_items, dev<uint32_t>(ctx, B_ITEM_CHECK),
                           dev<uint8_t>(ctx, B_SLOTS), dev<uint32_t>(ctx, B_ITEM_SIZE),
-                          ctx->lz4_variant, ctx->stream, ctx->profile ? ctx->ev_hash : nullptr);
-    else
+                          variant, ctx->stream, ctx->profile ? ctx->ev_hash : nullptr);
+      if (auto_timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_auto[1], ctx->stream));
+    } else
       launch_snappy_compress(d_src, dev<Item>(ctx, B_ITEMS), n_items, dev<uint8_t>(ctx, B_SLOTS),
                              slot_stride, dev<uint32_t>(ctx, B_ITEM_SIZE), ctx->snappy_variant, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
@@ -290,6 +315,19 @@ int s3s_compress_map_output_device(s3s_ctx* ctx, int codec, int checksum_algo,
     HIP_TRY(ctx, hipMemcpyAsync(h_sums, ctx->buf[B_SUMS].p, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(h_status, ctx->buf[B_STATUS].p, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (auto_timed) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ctx->ev_auto[0], ctx->ev_auto[1]) == hipSuccess && ms > 0) {
+      const double rate = (double)ms / ((double)total_u / 1048576.0);
+      double& r = ctx->auto_ms_per_mib[auto_which];
+      // first samples: keep the best (the very first call runs on cold clocks); later: smooth
+      r = ctx->auto_samples[auto_which] == 0 ? rate
+          : (ctx->auto_samples[auto_which] < 2 ? (rate < r ? rate : r) : 0.5 * r + 0.5 * rate);
+      ctx->auto_samples[auto_which]++;
+      if (ctx->auto_samples[0] >= 2 && ctx->auto_samples[1] >= 2)
+        ctx->auto_choice = ctx->auto_ms_per_mib[1] < ctx->auto_ms_per_mib[0] ? 1 : 0;
+    }
+  }
   if (ctx->profile) {
     float ms = 0;
     hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]); ctx->stage_ms[S3S_STAGE_TOTAL] = ms;

@@ -34,7 +34,16 @@ struct s3s_ctx {
   int64_t lz4_block = 32768;
   int64_t snappy_block = 32768;
   int profile = 0;
-  int lz4_variant = 1;
+  int lz4_variant = 9;  // 9 = auto: the context times variants 1 and 2 on its own calls (below)
+  // auto-tuning state (S3S_OPT_LZ4_VARIANT = 9): index 0 = variant 1 (general batch), 1 = variant 2
+  // (exact windows).  Shuffle data of one stage has one schema, so the faster parse for a
+  // context's first map outputs stays the faster one; every 32nd large call re-measures the other.
+  int auto_choice = 1;
+  int auto_samples[2] = {0, 0};
+  int auto_tick = 0;
+  double auto_ms_per_mib[2] = {0, 0};
+  int lz4_variant_used = 0;  // the parse the last LZ4 compress call ran (S3S_OPT_LZ4_VARIANT_USED)
+  hipEvent_t ev_auto[2] = {nullptr, nullptr};
   int lz4_decode_variant = 3;
   int snappy_variant = 1;
   s3s::DevBuf buf[s3s::B_COUNT];

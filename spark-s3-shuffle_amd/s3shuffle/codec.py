@@ -15,6 +15,7 @@ STAGE_TOTAL, STAGE_CODEC, STAGE_ASSEMBLE, STAGE_CHECKSUM, STAGE_DISCOVER, STAGE_
 OPT_LZ4_VARIANT = 4
 OPT_LZ4_DECODE_VARIANT = 5
 OPT_SNAPPY_VARIANT = 6
+OPT_LZ4_VARIANT_USED = 7
 
 E_INVALID, E_CAPACITY, E_BAD_FRAME, E_CHECKSUM, E_HIP, E_UNSUPPORTED, E_NOMEM = -1, -2, -3, -4, -5, -6, -7
 _ERR_NAMES = {

@@ -11,12 +11,31 @@ LZ4, SNAPPY, NONE = 1, 2, 0
 ADLER, CRC = 1, 2
 
 
-@pytest.fixture(params=[0, 1, 2], ids=["chunk-in-lds", "chunk-in-l2", "window"], autouse=True)
+@pytest.fixture(params=[0, 1, 2, 9], ids=["chunk-in-lds", "chunk-in-l2", "window", "auto"], autouse=True)
 def lz4_variant(request, gpu_codec):
-    """Every test runs against both placements of the chunk bytes (S3S_OPT_LZ4_VARIANT)."""
+    """Every test runs against both placements of the chunk bytes and both parses
+    (S3S_OPT_LZ4_VARIANT; 9 = the default, self-tuning choice between 1 and 2)."""
     gpu_codec.set_option(4, request.param)
     yield request.param
-    gpu_codec.set_option(4, 1)
+    gpu_codec.set_option(4, 9)
+
+
+def test_auto_variant_settles_and_stays_bit_exact(gpu_codec, oracle, lz4_variant):
+    """Auto mode times variants 1 and 2 on the context's first large map outputs (1, 2, 1, 2), then
+    runs the faster one; the bytes never depend on the choice."""
+    if lz4_variant != 9:
+        pytest.skip("auto mode only")
+    from s3shuffle import datagen
+
+    d, o = datagen.tpcds_wide_map_output(6 << 20, 20, seed=11)
+    want = oracle.compress_map_output(LZ4, ADLER, d, o)
+    used = []
+    for _ in range(6):
+        img, index, sums = gpu_codec.compress_map_output(LZ4, ADLER, d, o)
+        assert np.array_equal(img, want[0]) and np.array_equal(index, want[1]) and np.array_equal(sums, want[2])
+        used.append(gpu_codec.get_option(7))
+    assert used[:4] == [1, 2, 1, 2], used
+    assert used[4] == used[5] and used[4] in (1, 2), used
 
 
 def _check(gpu_codec, oracle, codec, algo, data, offsets, block_size=32768):

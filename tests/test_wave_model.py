@@ -112,3 +112,40 @@ def test_window_model_matches_oracle(oracle):
                     assert want.size >= d.size
                 else:
                     assert np.array_equal(out[:m], want), (kind, n, la)
+
+
+def test_snappy_window_model_matches_oracle(oracle):
+    """Exact-window Snappy parse (tests/model/snappy_window_model.cpp): windows + general batches,
+    under adversarial same-address store winners, against the oracle; and the window path must carry
+    nearly all copies on the wide-row workload (that is what it is for)."""
+    from s3shuffle import datagen
+
+    src = os.path.join(HERE, "model", "snappy_window_model.cpp")
+    so = os.path.join(HERE, "model", "libsnappy_window_model.so")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src], check=True)
+    L = ctypes.CDLL(so)
+    L.snappy_window_model_compress.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                               ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p]
+
+    def run(d, mode, seed, stats=None):
+        out = np.empty(32 + d.size + d.size // 6 + 64, np.uint8)
+        n = L.snappy_window_model_compress(d.ctypes.data, d.size, out.ctypes.data, mode, seed, 1,
+                                           stats.ctypes.data if stats is not None else None)
+        return out[:n]
+
+    for kind in range(corpus.N_KINDS):
+        rng = np.random.default_rng(500 + kind)
+        for n in [0, 1, 14, 15, 16, 64, 65, 130, 191, 192, 193, 255, 256, 257, 300, 1000, 4096, 20000, 32768]:
+            if kind == 6 and n > 6000:
+                continue
+            d = corpus.chunk_corpus(kind, n, rng)
+            want = oracle.snappy_compress_block(d)
+            for mode in (0, 1, 2):
+                assert np.array_equal(run(d, mode, n), want), (kind, n, mode)
+    d, _ = datagen.tpcds_wide_map_output(1 << 19, 8, 5)
+    st = np.zeros(8, np.int64)
+    for k in range(0, d.size - 32768, 32768):
+        blk = np.ascontiguousarray(d[k:k + 32768])
+        assert np.array_equal(run(blk, 2, k, st), oracle.snappy_compress_block(blk))
+    assert st[2] > 20 * st[3] and st[1] > 0  # copies found in windows >> copies found by batches
