@@ -93,14 +93,15 @@ enum {
                                     to 1024) */
   S3S_OPT_PROFILE = 3,           /* 1: record per-stage HIP-event timings (s3s_stage_ms) */
   S3S_OPT_LZ4_VARIANT = 4,       /* tuning, identical output: 0 = chunk staged in LDS (3 wavefronts per CU),
-                                    1 = chunk read through L1/L2, table-only LDS (10 per CU; default),
-                                    2 = 1 + exact-window parse, 3 = 2 software-pipelined, 4 = 3 with the
-                                    run loop on the vector ALU, 5 = 1 with the frame check fused in,
-                                    6 / 7 = 1 at 5 / 7 wavefronts per CU (occupancy experiments),
-                                    9 (default) = auto: which of 1 and 2 is faster depends on the data
-                                    (windows win on match-dense rows, batches when a sequence spans a
-                                    window or more), so the context times both on its first large map
-                                    outputs, keeps the faster and re-measures the other every 32nd call */
+                                    1 = chunk read through L1/L2, table-only LDS (10 per CU), general batch
+                                    only, 2 (default) = 1 + exact-window parse in front of the batch
+                                    (several sequences per memory round trip: 1.5x on match-dense rows,
+                                    0.92x on TeraSort records single-stream, 0.98x with two task threads),
+                                    3 = 2 software-pipelined, 4 = 3 with the run loop on the vector ALU,
+                                    5 = 1 with the frame check fused in, 6 / 7 = 1 at 5 / 7 wavefronts per
+                                    CU (occupancy experiments), 9 = auto: the context times 1 and 2 on its
+                                    first large map outputs (1, 2, 1, 2), keeps the faster and re-measures
+                                    the other every 32nd call */
   S3S_OPT_LZ4_VARIANT_USED = 7,  /* read-only: the parse (1 or 2 under auto) the last LZ4 compress call ran */
   S3S_OPT_SNAPPY_VARIANT = 6,    /* tuning, identical output: 0 = general batch only, 1 (default) = exact
                                     64-byte windows in front of it (several copies per round trip) */

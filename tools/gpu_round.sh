@@ -16,6 +16,8 @@ timeout 300 python bench.py --no-cpu-baseline --workload skew-1part-lz4 --map-mi
 timeout 300 python bench.py --no-cpu-baseline --direction decompress > $O/bench_decompress.json 2>> $O/bench.err
 timeout 600 python bench.py --workload tpcds-wide-100g-200p-snappy --verify > $O/bench_snappy.json 2>> $O/bench.err
 timeout 300 python bench.py --no-cpu-baseline --workload tpcds-wide-100g-200p-snappy --direction decompress > $O/bench_snappy_decompress.json 2>> $O/bench.err
+timeout 600 python bench.py --workload tpcds-wide-100g-200p-lz4 --verify > $O/bench_tpcds_lz4.json 2>> $O/bench.err
+timeout 300 python bench.py --no-cpu-baseline --lz4-variant 1 > $O/bench_lz4_variant1.json 2>> $O/bench.err
 BENCH="python $R/bench.py --no-cpu-baseline"
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace -o t -- $BENCH > $O/trace.log 2>&1
