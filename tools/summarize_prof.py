@@ -54,6 +54,6 @@ for k, c in out["pmc"].items():
     if k.startswith("lz4_compress") and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         t = {"kernel": k, "lz4_compress_hbm_bytes_per_launch": int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024),
              "fetch_kb": c["FETCH_SIZE"], "write_kb": c["WRITE_SIZE"],
-             "xxh32_fetch_kb (calibration: input read once)": out["pmc"].get("xxh32_items_kernel", {}).get("FETCH_SIZE")}
+             "xxh32_fetch_kb (calibration: input read once)": (out["pmc"].get("xxh32_items_wave_kernel") or out["pmc"].get("xxh32_items_kernel", {})).get("FETCH_SIZE")}
         json.dump(t, open(os.path.join(root, "traffic.json"), "w"), indent=1)
         print("== traffic", t)
