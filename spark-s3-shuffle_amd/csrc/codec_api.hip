@@ -79,6 +79,17 @@ void s3s_destroy(s3s_ctx* ctx) {
   delete ctx;
 }
 
+void* s3s_host_alloc(int64_t bytes) {
+  if (bytes <= 0) return nullptr;
+  void* p = nullptr;
+  if (hipHostMalloc(&p, (size_t)bytes, hipHostMallocPortable) != hipSuccess) return nullptr;
+  return p;
+}
+
+void s3s_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
 const char* s3s_last_error(const s3s_ctx* ctx) { return ctx ? ctx->err : g_create_error; }
 
 int s3s_set_option(s3s_ctx* ctx, int key, int64_t value) {

@@ -6,7 +6,9 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace s3shuffle {
@@ -37,21 +39,6 @@ void rm_rf(const std::string& path) {
   }
   ::closedir(d);
   ::rmdir(path.c_str());
-}
-
-s3s_ctx* make_ctx(const S3ShuffleDispatcher& d, int device) {
-  s3s_ctx* c = s3s_create(device, 0);
-  if (!c) throw IOException(std::string("s3s_create failed: ") + s3s_last_error(nullptr));
-  const Conf& cf = d.conf();
-  if (cf.compress) {
-    const int key = cf.codec == "snappy" ? S3S_OPT_SNAPPY_BLOCK_SIZE : S3S_OPT_LZ4_BLOCK_SIZE;
-    if (s3s_set_option(c, key, cf.blockSize) != S3S_OK) {
-      const std::string msg = s3s_last_error(c);
-      s3s_destroy(c);
-      throw IOException(msg);
-    }
-  }
-  return c;
 }
 
 }  // namespace
@@ -219,7 +206,8 @@ S3ShuffleMapOutputWriter::S3ShuffleMapOutputWriter(const S3ShuffleDispatcher& d,
     : d_(d), shuffleId_(shuffleId), mapId_(mapId), numPartitions_(numPartitions), srcOffsets_((size_t)numPartitions + 1, 0) {}
 
 S3ShuffleMapOutputWriter::~S3ShuffleMapOutputWriter() {
-  if (ctx_) s3s_destroy(ctx_);
+  PinnedPool::process().release(stage_);
+  releaseContext(d_, d_.deviceForMap(mapId_), ctx_);
 }
 
 void S3ShuffleMapOutputWriter::getPartitionWriter(int reducePartitionId) {
@@ -229,43 +217,60 @@ void S3ShuffleMapOutputWriter::getPartitionWriter(int reducePartitionId) {
     throw std::runtime_error("Precondition: Invalid partition id.");  // :71-73
   closePartition();
   // partitions skipped over stay empty
-  for (int p = lastPartitionWriterId_ + 1; p <= reducePartitionId; p++) srcOffsets_[(size_t)p] = (int64_t)staging_.size();
+  for (int p = lastPartitionWriterId_ + 1; p <= reducePartitionId; p++) srcOffsets_[(size_t)p] = stageLen_;
   lastPartitionWriterId_ = reducePartitionId;
   streamClosed_ = false;
 }
 
 void S3ShuffleMapOutputWriter::write(const void* bytes, size_t len) {
   if (streamClosed_ || lastPartitionWriterId_ < 0) throw IOException("Partition writer stream is closed.");  // :183-184
-  const uint8_t* b = static_cast<const uint8_t*>(bytes);
-  staging_.insert(staging_.end(), b, b + len);
+  // the task's serialized bytes go straight into page-locked staging (what the JVM shim exposes as a
+  // direct ByteBuffer); it grows by doubling inside the process-wide pool
+  if (stageLen_ + (int64_t)len > stageCap_) {
+    int64_t cap = std::max<int64_t>(stageCap_ * 2, 4ll << 20);
+    while (cap < stageLen_ + (int64_t)len) cap *= 2;
+    uint8_t* bigger = PinnedPool::process().acquire(cap);
+    if (stageLen_) memcpy(bigger, stage_, (size_t)stageLen_);
+    PinnedPool::process().release(stage_);
+    stage_ = bigger;
+    stageCap_ = cap;
+  }
+  memcpy(stage_ + stageLen_, bytes, len);
+  stageLen_ += (int64_t)len;
 }
 
 int64_t S3ShuffleMapOutputWriter::getNumBytesWritten() const {
   if (lastPartitionWriterId_ < 0) return 0;
-  return (int64_t)staging_.size() - srcOffsets_[(size_t)lastPartitionWriterId_];
+  return stageLen_ - srcOffsets_[(size_t)lastPartitionWriterId_];
 }
 
 void S3ShuffleMapOutputWriter::closePartition() { streamClosed_ = true; }
 
 std::vector<int64_t> S3ShuffleMapOutputWriter::commitAllPartitions() {
   if (committed_) throw std::runtime_error("commitAllPartitions called twice");
+  const bool timing = getenv("S3SH_TIMING") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  const auto t0 = now();
   closePartition();
-  for (int p = lastPartitionWriterId_ + 1; p <= numPartitions_; p++) srcOffsets_[(size_t)p] = (int64_t)staging_.size();
+  for (int p = lastPartitionWriterId_ + 1; p <= numPartitions_; p++) srcOffsets_[(size_t)p] = stageLen_;
   const int codec = d_.codecId(), algo = d_.checksumId();
-  if (!ctx_) ctx_ = make_ctx(d_, d_.deviceForMap(mapId_));
+  if (!ctx_) ctx_ = acquireContext(d_, d_.deviceForMap(mapId_));
   const int64_t cap = s3s_max_compressed_size(ctx_, codec, srcOffsets_.data(), numPartitions_);
   if (cap < 0) throw std::runtime_error("Precondition: invalid partition offsets");
-  std::vector<uint8_t> data((size_t)cap + 1);
+  struct PinnedOut {  // the .data image, page-locked: D2H is plain DMA, then one write to the store
+    uint8_t* p;
+    ~PinnedOut() { PinnedPool::process().release(p); }
+  } data{PinnedPool::process().acquire(cap + 1)};
   std::vector<int64_t> index((size_t)numPartitions_ + 1, 0), sums((size_t)std::max(numPartitions_, 1), 0);
   int64_t total = 0;
-  const int rc = s3s_compress_map_output(ctx_, codec, algo, staging_.data(), srcOffsets_.data(), numPartitions_,
-                                         data.data(), cap, index.data(), algo == S3S_CHECKSUM_NONE ? nullptr : sums.data(),
-                                         &total);
+  const int rc = s3s_compress_map_output(ctx_, codec, algo, stage_, srcOffsets_.data(), numPartitions_, data.p, cap,
+                                         index.data(), algo == S3S_CHECKSUM_NONE ? nullptr : sums.data(), &total);
   if (rc != S3S_OK) throw IOException(std::string("s3s_compress_map_output: ") + s3s_last_error(ctx_));
+  const auto t1 = now();
   std::vector<int64_t> partitionLengths((size_t)numPartitions_);
   for (int p = 0; p < numPartitions_; p++) partitionLengths[(size_t)p] = index[(size_t)p + 1] - index[(size_t)p];
   // the .data object: one block per map task, partitions in ascending order (:43-49, :58)
-  if (total > 0 || d_.conf().alwaysCreateIndex) d_.createBlock(BlockId::ShuffleDataBlockId(shuffleId_, mapId_), data.data(), (size_t)total);
+  if (total > 0 || d_.conf().alwaysCreateIndex) d_.createBlock(BlockId::ShuffleDataBlockId(shuffleId_, mapId_), data.p, (size_t)total);
   // index and checksum (:111-116)
   if (total > 0 || d_.conf().alwaysCreateIndex) {
     if (numPartitions_ > 0) S3ShuffleHelper::writePartitionLengths(d_, shuffleId_, mapId_, partitionLengths);
@@ -275,14 +280,21 @@ std::vector<int64_t> S3ShuffleMapOutputWriter::commitAllPartitions() {
     }
   }
   committed_ = true;
-  staging_.clear();
-  staging_.shrink_to_fit();
+  if (timing)
+    fprintf(stderr, "[s3sh] map %lld: %lld B staged, compress call %.2f ms, store writes %.2f ms\n", (long long)mapId_,
+            (long long)stageLen_, std::chrono::duration<double, std::milli>(t1 - t0).count(),
+            std::chrono::duration<double, std::milli>(now() - t1).count());
+  PinnedPool::process().release(stage_);
+  stage_ = nullptr;
+  stageCap_ = stageLen_ = 0;
   return partitionLengths;
 }
 
 void S3ShuffleMapOutputWriter::abort() {
   // the reference closes its streams (:120-134); nothing has reached the store before commit here
-  staging_.clear();
+  PinnedPool::process().release(stage_);
+  stage_ = nullptr;
+  stageCap_ = stageLen_ = 0;
   streamClosed_ = true;
   committed_ = true;
 }
@@ -292,13 +304,11 @@ S3ShuffleReader::S3ShuffleReader(const S3ShuffleDispatcher& d, int shuffleId, in
                                  bool doBatchFetch)
     : d_(d), shuffleId_(shuffleId), start_(startPartition), end_(endPartition), batch_(doBatchFetch) {}
 
-S3ShuffleReader::~S3ShuffleReader() {
-  if (ctx_) s3s_destroy(ctx_);
-}
+S3ShuffleReader::~S3ShuffleReader() { releaseContext(d_, ctxDevice_, ctx_); }
 
-std::vector<FetchedBlock> S3ShuffleReader::read() {
-  std::vector<FetchedBlock> out;
-  const int codec = d_.codecId(), algo = d_.checksumId();
+std::vector<BlockRequest> S3ShuffleReader::blockRequests() const {
+  std::vector<BlockRequest> reqs;
+  const int algo = d_.checksumId();
   // computeShuffleBlocks with useBlockManager=false: list the .index objects (S3ShuffleReader.scala:182-195)
   for (const BlockId& idx : d_.listShuffleIndices(shuffleId_)) {
     const std::vector<int64_t> lengths = S3ShuffleHelper::getPartitionLengths(d_, shuffleId_, idx.mapId);
@@ -311,30 +321,63 @@ std::vector<FetchedBlock> S3ShuffleReader::read() {
       for (int r = start_; r < end_; r++) ranges.emplace_back(r, r + 1);
     for (const auto& rg : ranges) {
       const int r0 = rg.first, r1 = rg.second;
-      const int64_t startPosition = lengths[(size_t)r0], maxBytes = lengths[(size_t)r1] - lengths[(size_t)r0];
-      if (maxBytes == 0) continue;  // S3ShuffleReader.scala:91-93 filters empty blocks
-      FetchedBlock fb{batch_ && r1 - r0 > 1 ? BlockId::ShuffleBlockBatchId(shuffleId_, idx.mapId, r0, r1)
-                                             : BlockId::ShuffleBlockId(shuffleId_, idx.mapId, r0),
-                      {}};
-      const std::vector<uint8_t> comp = d_.readBlockRange(BlockId::ShuffleDataBlockId(shuffleId_, idx.mapId), startPosition, maxBytes);
-      std::vector<int64_t> rel((size_t)(r1 - r0) + 1);
-      for (int r = r0; r <= r1; r++) rel[(size_t)(r - r0)] = lengths[(size_t)r] - startPosition;
-      if (!ctx_) ctx_ = make_ctx(d_, d_.deviceForMap(idx.mapId));
-      int64_t decoded = 0;
-      if (s3s_decompressed_size(ctx_, codec, comp.data(), (int64_t)comp.size(), &decoded) != S3S_OK)
-        throw IOException("Stream is corrupted");
-      fb.bytes.resize((size_t)decoded);
-      int64_t out_len = 0;
-      int32_t bad = -1;
-      const int rc = s3s_decompress_range(ctx_, codec, algo, comp.data(), (int64_t)comp.size(), rel.data(),
-                                          algo == S3S_CHECKSUM_NONE ? nullptr : sums.data() + r0, r1 - r0,
-                                          fb.bytes.data(), decoded, &out_len, &bad);
-      if (rc == S3S_E_CHECKSUM) throw SparkException("Invalid checksum detected for " + fb.id.name());  // S3ChecksumValidationStream.scala:72-74
-      if (rc == S3S_E_BAD_FRAME) throw IOException("Stream is corrupted");
-      if (rc != S3S_OK) throw IOException(std::string("s3s_decompress_range: ") + s3s_last_error(ctx_));
-      fb.bytes.resize((size_t)out_len);
-      out.push_back(std::move(fb));
+      BlockRequest rq;
+      rq.startPosition = lengths[(size_t)r0];
+      rq.maxBytes = lengths[(size_t)r1] - lengths[(size_t)r0];
+      if (rq.maxBytes == 0) continue;  // S3ShuffleReader.scala:91-93 filters empty blocks
+      rq.id = batch_ && r1 - r0 > 1 ? BlockId::ShuffleBlockBatchId(shuffleId_, idx.mapId, r0, r1)
+                                    : BlockId::ShuffleBlockId(shuffleId_, idx.mapId, r0);
+      rq.dataBlock = BlockId::ShuffleDataBlockId(shuffleId_, idx.mapId);
+      rq.rel.resize((size_t)(r1 - r0) + 1);
+      for (int r = r0; r <= r1; r++) rq.rel[(size_t)(r - r0)] = lengths[(size_t)r] - rq.startPosition;
+      if (algo != S3S_CHECKSUM_NONE) rq.sums.assign(sums.begin() + r0, sums.begin() + r1);
+      rq.device = d_.deviceForMap(idx.mapId);
+      reqs.push_back(std::move(rq));
     }
+  }
+  return reqs;
+}
+
+std::vector<FetchedBlock> S3ShuffleReader::read() {
+  std::vector<FetchedBlock> out;
+  S3BufferedPrefetchIterator it(d_, blockRequests());
+  while (it.hasNext()) {
+    PrefetchedBlock b = it.next();
+    out.push_back(FetchedBlock{b.id, std::vector<uint8_t>(b.data, b.data + b.size)});
+    it.release(b);
+  }
+  // completion order is not deterministic (neither is the reference's); callers of read() get map order
+  std::sort(out.begin(), out.end(), [](const FetchedBlock& a, const FetchedBlock& b) {
+    return a.id.mapId != b.id.mapId ? a.id.mapId < b.id.mapId : a.id.reduceId < b.id.reduceId;
+  });
+  return out;
+}
+
+std::vector<FetchedBlock> S3ShuffleReader::readSequential() {
+  std::vector<FetchedBlock> out;
+  const int codec = d_.codecId(), algo = d_.checksumId();
+  for (const BlockRequest& rq : blockRequests()) {
+    FetchedBlock fb{rq.id, {}};
+    const std::vector<uint8_t> comp = d_.readBlockRange(rq.dataBlock, rq.startPosition, rq.maxBytes);
+    if (ctx_ && ctxDevice_ != rq.device) {
+      releaseContext(d_, ctxDevice_, ctx_);
+      ctx_ = nullptr;
+    }
+    if (!ctx_) ctx_ = acquireContext(d_, ctxDevice_ = rq.device);
+    int64_t decoded = 0;
+    if (s3s_decompressed_size(ctx_, codec, comp.data(), (int64_t)comp.size(), &decoded) != S3S_OK)
+      throw IOException("Stream is corrupted");
+    fb.bytes.resize((size_t)decoded);
+    int64_t out_len = 0;
+    int32_t bad = -1;
+    const int rc = s3s_decompress_range(ctx_, codec, algo, comp.data(), (int64_t)comp.size(), rq.rel.data(),
+                                        (algo == S3S_CHECKSUM_NONE || rq.sums.empty()) ? nullptr : rq.sums.data(),
+                                        (int32_t)rq.rel.size() - 1, fb.bytes.data(), decoded, &out_len, &bad);
+    if (rc == S3S_E_CHECKSUM) throw SparkException("Invalid checksum detected for " + fb.id.name());  // S3ChecksumValidationStream.scala:72-74
+    if (rc == S3S_E_BAD_FRAME) throw IOException("Stream is corrupted");
+    if (rc != S3S_OK) throw IOException(std::string("s3s_decompress_range: ") + s3s_last_error(ctx_));
+    fb.bytes.resize((size_t)out_len);
+    out.push_back(std::move(fb));
   }
   return out;
 }
@@ -453,6 +496,60 @@ void* s3sh_reader_read(void* d, int shuffleId, int startPartition, int endPartit
     r = new s3sh_read_result{rd.read()};
   });
   return rc == 0 ? r : nullptr;
+}
+void* s3sh_reader_read_sequential(void* d, int shuffleId, int startPartition, int endPartition, int doBatchFetch) {
+  s3sh_read_result* r = nullptr;
+  const int rc = guarded([&] {
+    S3ShuffleReader rd(*static_cast<S3ShuffleDispatcher*>(d), shuffleId, startPartition, endPartition, doBatchFetch != 0);
+    r = new s3sh_read_result{rd.readSequential()};
+  });
+  return rc == 0 ? r : nullptr;
+}
+// streams every block of the range through the prefetch pipeline WITHOUT copying it out (the consumer
+// touches one byte per page and releases): out[0] blocks, [1] compressed bytes, [2] decoded bytes,
+// [3] pinned high-water (compressed), [4] pinned high-water (decoded), [5] microseconds waiting in next()
+int s3sh_reader_consume_prefetched(void* d, int shuffleId, int startPartition, int endPartition, int doBatchFetch,
+                                   long long* out) {
+  return guarded([&] {
+    const S3ShuffleDispatcher& disp = *static_cast<S3ShuffleDispatcher*>(d);
+    S3ShuffleReader rd(disp, shuffleId, startPartition, endPartition, doBatchFetch != 0);
+    S3BufferedPrefetchIterator it(disp, rd.blockRequests());
+    unsigned acc = 0;
+    while (it.hasNext()) {
+      PrefetchedBlock b = it.next();
+      for (int64_t i = 0; i < b.size; i += 4096) acc += b.data[i];
+      it.release(b);
+    }
+    const S3BufferedPrefetchIterator::Stats st = it.stats();
+    out[0] = st.blocks;
+    out[1] = st.compressedBytes;
+    out[2] = st.decodedBytes;
+    out[3] = st.compHighWater;
+    out[4] = st.decodedHighWater;
+    out[5] = (long long)(st.secondsWaiting * 1e6) + (acc & 0);
+  });
+}
+// the same without the pipeline: block after block on one context, pageable buffers (out[0] blocks, out[2] decoded bytes)
+int s3sh_reader_consume_sequential(void* d, int shuffleId, int startPartition, int endPartition, int doBatchFetch,
+                                   long long* out) {
+  return guarded([&] {
+    S3ShuffleReader rd(*static_cast<S3ShuffleDispatcher*>(d), shuffleId, startPartition, endPartition, doBatchFetch != 0);
+    const std::vector<FetchedBlock> blocks = rd.readSequential();
+    out[0] = (long long)blocks.size();
+    out[2] = 0;
+    for (const FetchedBlock& b : blocks) out[2] += (long long)b.bytes.size();
+  });
+}
+void s3sh_release_caches() {
+  releaseContextCache();
+  releasePinnedCache();
+}
+// prefetch / staging knobs of an existing dispatcher (spark.shuffle.s3.maxBufferSizeTask, .maxConcurrencyTask,
+// .gpu.decodeThreads, .gpu.maxDecodedBufferSizeTask); values <= 0 keep the current setting
+void s3sh_dispatcher_set_prefetch(void* d, long long maxBufferSizeTask, int maxConcurrencyTask, int gpuDecodeThreads,
+                                  long long gpuMaxDecodedBufferSizeTask) {
+  static_cast<S3ShuffleDispatcher*>(d)->setPrefetch(maxBufferSizeTask, maxConcurrencyTask, gpuDecodeThreads,
+                                                     gpuMaxDecodedBufferSizeTask);
 }
 int s3sh_result_count(void* r) { return (int)static_cast<s3sh_read_result*>(r)->blocks.size(); }
 long long s3sh_result_block_len(void* r, int i) { return (long long)static_cast<s3sh_read_result*>(r)->blocks[(size_t)i].bytes.size(); }

@@ -21,10 +21,23 @@
 //                            + S3ShuffleBlockStream.scala:36-40,73-93 + S3ChecksumValidationStream
 //                            .scala:54-86 — block (or batch) -> byte range -> verify + decode
 //                            through s3s_decompress_range.
+//   S3BufferedPrefetchIterator storage/S3BufferedPrefetchIterator.scala:16-200 + S3BufferedInputStreamAdaptor
+//                            .scala:7-60 — the staging step in front of the decode
+//                            kernel: up to maxConcurrencyTask fetch threads fill per-block buffers under the
+//                            maxBufferSizeTask budget, the consumer takes blocks as they complete and gives the
+//                            memory back when it closes the stream.  Here the buffers are PAGE-LOCKED
+//                            (s3s_host_alloc, pooled), fetch -> H2D -> verify+decode -> D2H of different blocks
+//                            overlap on separate contexts (HIP streams), and what the consumer receives is the
+//                            DECODED block in pinned memory (s3shuffle_prefetch.cpp).
 #pragma once
+#include <condition_variable>
 #include <cstdint>
+#include <deque>
+#include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/s3shuffle_codec.h"
@@ -65,6 +78,10 @@ struct Conf {
   std::string codec = "lz4";                 // spark.io.compression.codec
   int blockSize = 32768;                     // spark.io.compression.{lz4,snappy}.blockSize
   int numGpus = 0;                           // spark.shuffle.s3.gpu.devices (0 = all visible)
+  int64_t maxBufferSizeTask = 128ll << 20;   // spark.shuffle.s3.maxBufferSizeTask: prefetch budget (compressed bytes)
+  int maxConcurrencyTask = 10;               // spark.shuffle.s3.maxConcurrencyTask: fetch threads per task
+  int gpuDecodeThreads = 2;                  // spark.shuffle.s3.gpu.decodeThreads: contexts (streams) decoding per task
+  int64_t gpuMaxDecodedBufferSizeTask = 512ll << 20;  // spark.shuffle.s3.gpu.maxDecodedBufferSizeTask (pinned, decoded)
 };
 
 class S3ShuffleDispatcher {
@@ -76,12 +93,19 @@ class S3ShuffleDispatcher {
   void createBlock(const BlockId& id, const void* data, size_t n) const;
   std::vector<uint8_t> readBlock(const BlockId& id) const;
   std::vector<uint8_t> readBlockRange(const BlockId& id, int64_t pos, int64_t n) const;
+  void readBlockRangeInto(const BlockId& id, int64_t pos, int64_t n, uint8_t* dst) const;  // positioned readFully
   int64_t blockLength(const BlockId& id) const;  // -1 if missing
   void removeShuffle(int shuffleId) const;
   void removeRoot() const;
   int codecId() const;      // S3S_CODEC_*
   int checksumId() const;   // S3S_CHECKSUM_*; throws UnsupportedOperationException-like for unknown names
   int deviceForMap(int64_t mapId) const;
+  void setPrefetch(int64_t maxBufferSizeTask, int maxConcurrencyTask, int gpuDecodeThreads, int64_t gpuMaxDecodedBufferSizeTask) {
+    if (maxBufferSizeTask > 0) conf_.maxBufferSizeTask = maxBufferSizeTask;
+    if (maxConcurrencyTask > 0) conf_.maxConcurrencyTask = maxConcurrencyTask;
+    if (gpuDecodeThreads > 0) conf_.gpuDecodeThreads = gpuDecodeThreads;
+    if (gpuMaxDecodedBufferSizeTask > 0) conf_.gpuMaxDecodedBufferSizeTask = gpuMaxDecodedBufferSizeTask;
+  }
 
  private:
   Conf conf_;
@@ -122,7 +146,8 @@ class S3ShuffleMapOutputWriter {
   int numPartitions_;
   int lastPartitionWriterId_ = -1;
   bool streamClosed_ = true, committed_ = false;
-  std::vector<uint8_t> staging_;
+  uint8_t* stage_ = nullptr;  // page-locked, from PinnedPool::process()
+  int64_t stageCap_ = 0, stageLen_ = 0;
   std::vector<int64_t> srcOffsets_;  // numPartitions + 1
   s3s_ctx* ctx_ = nullptr;
 };
@@ -132,6 +157,98 @@ struct FetchedBlock {
   std::vector<uint8_t> bytes;  // decoded (decompressed) serialized records of the block
 };
 
+// ---- page-locked staging memory, pooled (hipHostMalloc costs milliseconds: never per block) ------------
+class PinnedPool {
+ public:
+  // blocking: acquire() waits for the budget (prefetch pipeline); otherwise the budget only bounds the cache
+  explicit PinnedPool(int64_t budgetBytes, bool blocking = true);
+  ~PinnedPool();
+  PinnedPool(const PinnedPool&) = delete;
+  // blocks until `bytes` fit under the budget; a request larger than the whole budget is served once
+  // nothing else is in use (the reference clamps its buffer to maxBufferSize instead and streams the
+  // rest, S3BufferedPrefetchIterator.scala:127 — a GPU block has to be resident as a whole)
+  uint8_t* acquire(int64_t bytes);
+  void release(uint8_t* p);
+  void cancel();  // waiting and future acquire() calls throw IOException (pipeline teardown)
+  int64_t inUse() const;
+  int64_t highWater() const;
+  static PinnedPool& process();  // map-side staging: unbounded, non-blocking view of the process-wide cache
+
+ private:
+  mutable std::mutex mu_;
+  std::condition_variable cv_;
+  int64_t budget_, inUse_ = 0, high_ = 0;
+  bool cancelled_ = false, blocking_ = true;
+  std::map<uint8_t*, int64_t> used_, reserved_;  // buffer -> its real capacity / what it counts for
+};
+
+// codec contexts (stream + device workspace) recycled across tasks, keyed by device and codec settings;
+// acquire never blocks (a new context is created when none is idle)
+s3s_ctx* acquireContext(const S3ShuffleDispatcher& d, int device);
+void releaseContext(const S3ShuffleDispatcher& d, int device, s3s_ctx* ctx);
+void releaseContextCache();  // destroys the idle contexts (executor shutdown)
+void releasePinnedCache();   // frees the idle page-locked buffers
+
+// one S3ShuffleBlockStream: the byte range of a block (or batch) inside a map output's .data object
+// (S3ShuffleBlockIterator.scala:37-42) plus what the decode needs
+struct BlockRequest {
+  BlockId id;
+  BlockId dataBlock;
+  int64_t startPosition = 0, maxBytes = 0;
+  std::vector<int64_t> rel;   // .index slice relative to startPosition, r1 - r0 + 1 entries
+  std::vector<int64_t> sums;  // reference checksums of the range (empty = validation off)
+  int device = 0;
+};
+
+struct PrefetchedBlock {
+  BlockId id;
+  const uint8_t* data = nullptr;  // decoded bytes in page-locked memory, valid until release()
+  int64_t size = 0;
+};
+
+class S3BufferedPrefetchIterator {
+ public:
+  S3BufferedPrefetchIterator(const S3ShuffleDispatcher& d, std::vector<BlockRequest> requests);
+  ~S3BufferedPrefetchIterator();
+  bool hasNext();
+  // the next completed block, in completion order; throws what the block's fetch / verify / decode
+  // raised (SparkException "Invalid checksum detected for ...", IOException "Stream is corrupted")
+  PrefetchedBlock next();
+  void release(PrefetchedBlock& b);  // ≙ closing the stream: returns the memory (onCloseStream, :96-100)
+  struct Stats {
+    int64_t blocks = 0, compressedBytes = 0, decodedBytes = 0;
+    double secondsWaiting = 0;  // consumer blocked in next()
+    int64_t compHighWater = 0, decodedHighWater = 0;
+  };
+  Stats stats() const;
+
+ private:
+  struct Fetched {
+    size_t req;
+    uint8_t* comp;
+  };
+  struct Done {
+    size_t req;
+    uint8_t* out;
+    int64_t len;
+    int errKind;  // 0 ok, 1 SparkException, 2 IOException
+    std::string err;
+  };
+  void fetchLoop();
+  void decodeLoop();
+  const S3ShuffleDispatcher& d_;
+  std::vector<BlockRequest> reqs_;
+  PinnedPool comp_, dec_;
+  mutable std::mutex mu_;
+  std::condition_variable cvFetched_, cvDone_;
+  std::deque<Fetched> fetched_;
+  std::deque<Done> done_;
+  size_t nextReq_ = 0, fetchersLeft_ = 0, delivered_ = 0;
+  bool stop_ = false;
+  std::vector<std::thread> threads_;
+  Stats stats_;
+};
+
 class S3ShuffleReader {
  public:
   // reads partitions [startPartition, endPartition) of every map output of the shuffle; with
@@ -139,13 +256,20 @@ class S3ShuffleReader {
   S3ShuffleReader(const S3ShuffleDispatcher& d, int shuffleId, int startPartition, int endPartition,
                   bool doBatchFetch);
   ~S3ShuffleReader();
+  // all blocks, decoded, ordered by (mapId, reduceId); runs on the prefetch pipeline
   std::vector<FetchedBlock> read();
+  // the same blocks fetched and decoded one after the other on one context with pageable buffers
+  // (the round-1 path; kept as the baseline the pipeline is measured against)
+  std::vector<FetchedBlock> readSequential();
+  // the S3ShuffleBlockStream list of this reader (computeShuffleBlocks + S3ShuffleBlockIterator)
+  std::vector<BlockRequest> blockRequests() const;
 
  private:
   const S3ShuffleDispatcher& d_;
   int shuffleId_, start_, end_;
   bool batch_;
   s3s_ctx* ctx_ = nullptr;
+  int ctxDevice_ = 0;
 };
 
 }  // namespace s3shuffle

@@ -15,6 +15,7 @@ from .codec import (  # noqa: F401
     CODEC_SNAPPY,
     Codec,
     CodecError,
+    PinnedBuffer,
     device_count,
     library_path,
     load_library,

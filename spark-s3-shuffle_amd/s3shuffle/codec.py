@@ -96,6 +96,9 @@ def load_library() -> ctypes.CDLL:
     lib.s3s_decompress_range.argtypes = dec_args
     lib.s3s_decompress_range_device.argtypes = dec_args
     lib.s3s_decompressed_size.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int64, c_i64p]
+    lib.s3s_host_alloc.restype = vp
+    lib.s3s_host_alloc.argtypes = [ctypes.c_int64]
+    lib.s3s_host_free.argtypes = [vp]
     _LIB = lib
     return lib
 
@@ -172,14 +175,19 @@ class Codec:
 
     # ---- map side ----------------------------------------------------------------------------
     def compress_map_output(self, codec: int, checksum: int, src: np.ndarray, src_offsets,
-                            dst_capacity: Optional[int] = None
+                            dst_capacity: Optional[int] = None, out: Optional[np.ndarray] = None
                             ) -> Tuple[np.ndarray, np.ndarray, Optional[np.ndarray]]:
-        """Host buffers in/out.  Returns (data image, index[N+1], checksums[N] or None)."""
+        """Host buffers in/out.  Returns (data image, index[N+1], checksums[N] or None).
+        `out`: caller-owned destination (e.g. a pinned_buffer) instead of a fresh numpy array."""
         src = np.ascontiguousarray(src, dtype=np.uint8)
         offs = _i64(src_offsets)
         n = len(offs) - 1
         cap = self.max_compressed_size(codec, offs) if dst_capacity is None else int(dst_capacity)
-        dst = np.empty(max(cap, 1), dtype=np.uint8)
+        if out is not None:
+            cap = min(cap, out.size) if dst_capacity is None else cap
+            dst = out
+        else:
+            dst = np.empty(max(cap, 1), dtype=np.uint8)
         index = np.zeros(n + 1, dtype=np.int64)
         sums = np.zeros(max(n, 1), dtype=np.int64)
         total = ctypes.c_int64(0)
@@ -229,13 +237,18 @@ class Codec:
         return int(out.value)
 
     def decompress_range(self, codec: int, checksum: int, comp: np.ndarray, part_offsets,
-                         ref_checksums=None, dst_capacity: Optional[int] = None) -> np.ndarray:
+                         ref_checksums=None, dst_capacity: Optional[int] = None,
+                         out: Optional[np.ndarray] = None) -> np.ndarray:
         comp = np.ascontiguousarray(comp, dtype=np.uint8)
         offs = _i64(part_offsets)
         n = len(offs) - 1
         refs = _i64(ref_checksums) if ref_checksums is not None else None
-        cap = self.decompressed_size(codec, comp) if dst_capacity is None else int(dst_capacity)
-        dst = np.empty(max(cap, 1), dtype=np.uint8)
+        if out is not None:
+            cap = out.size if dst_capacity is None else int(dst_capacity)
+            dst = out
+        else:
+            cap = self.decompressed_size(codec, comp) if dst_capacity is None else int(dst_capacity)
+            dst = np.empty(max(cap, 1), dtype=np.uint8)
         out_len = ctypes.c_int64(0)
         bad = ctypes.c_int32(-1)
         rc = self._lib.s3s_decompress_range(
@@ -258,3 +271,36 @@ class Codec:
             ctypes.byref(out_len), ctypes.byref(bad))
         self._check(rc, bad.value)
         return int(out_len.value)
+
+
+
+class PinnedBuffer:
+    """Page-locked host memory from s3s_host_alloc (what the JVM shim would wrap with
+    NewDirectByteBuffer).  `.array` is a uint8 view; the host-buffer entry points move it with
+    plain DMA.  Keep the object alive while views of `.array` are in use; `free()` is explicit."""
+
+    def __init__(self, nbytes: int):
+        self._lib = load_library()
+        self.nbytes = max(int(nbytes), 1)
+        self.ptr = self._lib.s3s_host_alloc(self.nbytes)
+        if not self.ptr:
+            raise MemoryError(f"s3s_host_alloc({self.nbytes}) failed")
+        self.array = np.frombuffer((ctypes.c_uint8 * self.nbytes).from_address(self.ptr), dtype=np.uint8)
+
+    def free(self) -> None:
+        if self.ptr:
+            self.array = None
+            self._lib.s3s_host_free(ctypes.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.free()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass

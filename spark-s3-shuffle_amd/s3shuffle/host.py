@@ -56,6 +56,11 @@ def _lib():
         L.s3sh_writer_abort.argtypes = [vp]
         L.s3sh_reader_read.restype = vp
         L.s3sh_reader_read.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.s3sh_reader_read_sequential.restype = vp
+        L.s3sh_reader_read_sequential.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.s3sh_reader_consume_prefetched.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
+        L.s3sh_reader_consume_sequential.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
+        L.s3sh_dispatcher_set_prefetch.argtypes = [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_longlong]
         L.s3sh_result_count.argtypes = [vp]
         L.s3sh_result_block_len.restype = ctypes.c_longlong
         L.s3sh_result_block_len.argtypes = [vp, ctypes.c_int]
@@ -112,6 +117,13 @@ class Dispatcher:
         _check(_lib().s3sh_read_block_as_array(self._h, kind, shuffle_id, map_id, out.ctypes.data, out.size, ctypes.byref(n)))
         return out[: n.value].copy()
 
+    def set_prefetch(self, max_buffer_size_task: int = 0, max_concurrency_task: int = 0, gpu_decode_threads: int = 0,
+                     gpu_max_decoded_buffer_size_task: int = 0):
+        """spark.shuffle.s3.maxBufferSizeTask / .maxConcurrencyTask / .gpu.decodeThreads /
+        .gpu.maxDecodedBufferSizeTask (0 keeps the current value)."""
+        _lib().s3sh_dispatcher_set_prefetch(self._h, max_buffer_size_task, max_concurrency_task, gpu_decode_threads,
+                                            gpu_max_decoded_buffer_size_task)
+
     def remove_shuffle(self, shuffle_id: int):
         _check(_lib().s3sh_remove_shuffle(self._h, shuffle_id))
 
@@ -155,11 +167,38 @@ class MapOutputWriter:
             self._h = None
 
 
+def consume_prefetched(dispatcher: Dispatcher, shuffle_id: int, start_partition: int, end_partition: int,
+                       do_batch_fetch: bool) -> dict:
+    """Streams the range through S3BufferedPrefetchIterator without copying the blocks out."""
+    out = np.zeros(8, np.int64)
+    _check(_lib().s3sh_reader_consume_prefetched(dispatcher._h, shuffle_id, start_partition, end_partition,
+                                                 int(do_batch_fetch), out.ctypes.data))
+    return {"blocks": int(out[0]), "compressed_bytes": int(out[1]), "decoded_bytes": int(out[2]),
+            "pinned_high_water_compressed": int(out[3]), "pinned_high_water_decoded": int(out[4]),
+            "seconds_waiting": out[5] / 1e6}
+
+
+def consume_sequential(dispatcher: Dispatcher, shuffle_id: int, start_partition: int, end_partition: int,
+                       do_batch_fetch: bool) -> dict:
+    """The same range block after block on one context with pageable buffers (the baseline)."""
+    out = np.zeros(8, np.int64)
+    _check(_lib().s3sh_reader_consume_sequential(dispatcher._h, shuffle_id, start_partition, end_partition,
+                                                 int(do_batch_fetch), out.ctypes.data))
+    return {"blocks": int(out[0]), "decoded_bytes": int(out[2])}
+
+
+def release_caches():
+    """Destroys the idle codec contexts and frees the idle page-locked buffers of the process."""
+    _lib().s3sh_release_caches()
+
+
 def read_shuffle(dispatcher: Dispatcher, shuffle_id: int, start_partition: int, end_partition: int,
-                 do_batch_fetch: bool) -> List[Tuple[str, int, int, int, np.ndarray]]:
-    """S3ShuffleReader.read(): [(block name, mapId, r0, r1, decoded bytes)]."""
+                 do_batch_fetch: bool, sequential: bool = False) -> List[Tuple[str, int, int, int, np.ndarray]]:
+    """S3ShuffleReader.read(): [(block name, mapId, r0, r1, decoded bytes)], through the prefetch
+    pipeline (default) or block after block on one context (sequential=True)."""
     L = _lib()
-    r = L.s3sh_reader_read(dispatcher._h, shuffle_id, start_partition, end_partition, int(do_batch_fetch))
+    fn = L.s3sh_reader_read_sequential if sequential else L.s3sh_reader_read
+    r = fn(dispatcher._h, shuffle_id, start_partition, end_partition, int(do_batch_fetch))
     if not r:
         msg = L.s3sh_last_error().decode()
         if msg.startswith("SparkException"):

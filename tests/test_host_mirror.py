@@ -200,3 +200,74 @@ def test_invalid_checksum_is_a_spark_exception(gpu_codec, root):
             host.read_shuffle(d, 0, p, p + 1, False)
     d.remove_root()
     d.close()
+
+
+# ---- S3BufferedPrefetchIterator: pinned staging + overlapped fetch / decode ----------
+def _write_terasort_maps(d, n_maps, map_bytes, n_parts, seed=2):
+    from s3shuffle import datagen, host
+
+    inputs = []
+    for m in range(n_maps):
+        data, offs = datagen.terasort_map_output(map_bytes, n_parts, seed=seed, map_id=m)
+        w = host.MapOutputWriter(d, 0, m, n_parts)
+        for p in range(n_parts):
+            if offs[p + 1] > offs[p]:
+                w.get_partition_writer(p)
+                w.write(data[offs[p]:offs[p + 1]])
+        w.commit_all_partitions()
+        w.close()
+        inputs.append((data, offs))
+    return inputs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [False, True], ids=["single-blocks", "batch-fetch"])
+def test_prefetch_pipeline_equals_sequential_reader(gpu_codec, root, batch):
+    """read() (fetch threads -> pinned buffers -> decode contexts -> pinned output) returns exactly what the
+    one-context sequential reader returns, also under budgets far smaller than the data (a block larger
+    than the whole budget runs alone) and with more fetch threads than blocks."""
+    from s3shuffle import host
+
+    d = host.Dispatcher(root)
+    n_parts = 12
+    inputs = _write_terasort_maps(d, 6, 3 << 20, n_parts)
+    want = host.read_shuffle(d, 0, 2, 9, batch, sequential=True)
+    assert len(want) == (6 if batch else 6 * 7)
+    for (budget, fetchers, decoders, dec_budget) in [(0, 0, 0, 0), (1 << 20, 3, 1, 1 << 20), (64 << 20, 16, 3, 2 << 20)]:
+        d.set_prefetch(budget, fetchers, decoders, dec_budget)
+        got = host.read_shuffle(d, 0, 2, 9, batch)
+        assert [g[:4] for g in got] == [w[:4] for w in want]
+        for g, w in zip(got, want):
+            assert np.array_equal(g[4], w[4]), g[0]
+    # and the decoded bytes are the task's input
+    for name, m, r0, r1, b in want:
+        data, offs = inputs[m]
+        assert np.array_equal(b, data[offs[r0]:offs[r1]])
+    st = host.consume_prefetched(d, 0, 0, n_parts, True)
+    assert st["blocks"] == 6 and st["decoded_bytes"] == sum(x[0].size for x in inputs)
+    assert st["pinned_high_water_decoded"] > 0 and st["compressed_bytes"] < st["decoded_bytes"]
+    d.remove_root()
+    d.close()
+
+
+@pytest.mark.gpu
+def test_prefetch_pipeline_propagates_block_errors(gpu_codec, root):
+    """A corrupted block surfaces from next() with the reference's exception (S3ChecksumValidationStream
+    .scala:72-74), the other blocks still decode, and the pipeline shuts down cleanly mid-stream."""
+    from s3shuffle import host
+
+    d = host.Dispatcher(root)
+    _write_terasort_maps(d, 4, 1 << 20, 5)
+    path = d.get_path(host.KIND_DATA, 0, 2)
+    raw = bytearray(open(path, "rb").read())
+    raw[len(raw) // 3] ^= 0x01
+    open(path, "wb").write(bytes(raw))
+    with pytest.raises(host.SparkException, match=r"Invalid checksum detected for shuffle_0_2_"):
+        host.read_shuffle(d, 0, 0, 5, False)
+    with pytest.raises(host.SparkException, match=r"Invalid checksum detected for shuffle_0_2_0_5"):
+        host.consume_prefetched(d, 0, 0, 5, True)
+    os.remove(d.get_path(host.KIND_DATA, 0, 1))
+    with pytest.raises((host.IOException, host.SparkException)):
+        host.read_shuffle(d, 0, 0, 5, True)
+    d.remove_root()
+    d.close()
