@@ -6,6 +6,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -13,6 +14,8 @@
 
 namespace s3shuffle {
 namespace {
+
+std::atomic<int64_t> g_lastStaged{0};  // bytes the latest committed map task had staged
 
 bool ends_with(const std::string& s, const std::string& suf) {
   return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0;
@@ -227,7 +230,9 @@ void S3ShuffleMapOutputWriter::write(const void* bytes, size_t len) {
   // the task's serialized bytes go straight into page-locked staging (what the JVM shim exposes as a
   // direct ByteBuffer); it grows by doubling inside the process-wide pool
   if (stageLen_ + (int64_t)len > stageCap_) {
-    int64_t cap = std::max<int64_t>(stageCap_ * 2, 4ll << 20);
+    // first buffer: what the previous map task of this process staged (tasks of a stage are alike), so the
+    // steady state never re-grows; otherwise double
+    int64_t cap = std::max<int64_t>(stageCap_ * 2, std::max<int64_t>(4ll << 20, g_lastStaged.load(std::memory_order_relaxed)));
     while (cap < stageLen_ + (int64_t)len) cap *= 2;
     uint8_t* bigger = PinnedPool::process().acquire(cap);
     if (stageLen_) memcpy(bigger, stage_, (size_t)stageLen_);
@@ -280,6 +285,7 @@ std::vector<int64_t> S3ShuffleMapOutputWriter::commitAllPartitions() {
     }
   }
   committed_ = true;
+  g_lastStaged.store(stageLen_, std::memory_order_relaxed);
   if (timing)
     fprintf(stderr, "[s3sh] map %lld: %lld B staged, compress call %.2f ms, store writes %.2f ms\n", (long long)mapId_,
             (long long)stageLen_, std::chrono::duration<double, std::milli>(t1 - t0).count(),

@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 
 #include "s3shuffle_host.h"
@@ -57,12 +58,19 @@ class PinnedCache {
         return b.first;
       }
     }
-    void* p = s3s_host_alloc(cap);
-    if (!p) {  // make room and retry once
-      trim(0);
+    void* p = nullptr;
+    if (pinned_) {
       p = s3s_host_alloc(cap);
+      if (!p) {  // make room and retry once
+        trim(0);
+        p = s3s_host_alloc(cap);
+      }
+      // with a GPU present a buffer that cannot be page-locked is an error, never a silent 5x slowdown
+      if (!p) throw IOException("s3s_host_alloc(" + std::to_string(cap) + ") failed");
+    } else {
+      p = ::malloc((size_t)cap);
+      if (!p) throw IOException("out of memory");
     }
-    if (!p) throw IOException("s3s_host_alloc(" + std::to_string(cap) + ") failed");
     *got = cap;
     return static_cast<uint8_t*>(p);
   }
@@ -86,10 +94,17 @@ class PinnedCache {
         idle_.erase(big);
       }
     }
-    for (uint8_t* p : drop) s3s_host_free(p);
+    for (uint8_t* p : drop) freeOne(p);
   }
 
  private:
+  void freeOne(uint8_t* p) {
+    if (pinned_) s3s_host_free(p);
+    else ::free(p);
+  }
+  // no HIP device at all (a CPU-only box running the host-logic tests): nothing can be compressed there
+  // anyway — s3s_create fails loudly — so staging is plain memory instead of an error before the error
+  const bool pinned_ = s3s_device_count() > 0;
   std::mutex mu_;
   std::vector<std::pair<uint8_t*, int64_t>> idle_;
   int64_t idleBytes_ = 0;
