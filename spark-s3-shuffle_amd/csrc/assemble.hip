@@ -14,39 +14,41 @@
 namespace s3s {
 namespace {
 
-constexpr int kScanThreads = 1024;
-
-__global__ __launch_bounds__(kScanThreads) void scan_items_kernel(
-    const uint32_t* __restrict__ item_size, int32_t n_items, int64_t* __restrict__ item_off,
+// Exclusive scan of the item sizes + partition index.  ONE wavefront and NO LDS on purpose: the codec
+// kernels of the other task threads book all 160 KiB of every CU's LDS (10 x 16 KiB tables), and a
+// workgroup that needs even a few bytes of it waits for one of their ~1 ms chunks to finish (the
+// 1024-thread LDS version of this kernel took 9 us alone and 234 us on average next to a second
+// stream, profiles/r01d).  256 items per step (4 per lane), carried in a register.
+__global__ __launch_bounds__(kWave) void scan_items_kernel(
+    const uint32_t* __restrict__ item_size, int32_t n_items, int64_t* item_off,
     const int32_t* __restrict__ part_first, int32_t n_parts, int64_t* __restrict__ index) {
-  __shared__ int64_t wave_sum[kScanThreads / kWave];
-  __shared__ int64_t carry;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) carry = 0;
-  __syncthreads();
-  // tiles of kScanThreads items, carried sequentially (n_items is ~1 per 32 KiB of input)
-  for (int32_t tile = 0; tile < n_items; tile += kScanThreads) {
-    const int32_t i = tile + tid;
-    const int64_t x = i < n_items ? (int64_t)(item_size[i] & ~kRawFlag) : 0;
-    int64_t inc = x;  // inclusive scan within the wave
+  const int lane = threadIdx.x;
+  int64_t carry = 0;
+  for (int32_t tile = 0; tile < n_items; tile += 4 * kWave) {
+    const int32_t i0 = tile + 4 * lane;
+    int64_t x[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) x[k] = i0 + k < n_items ? (int64_t)(item_size[i0 + k] & ~kRawFlag) : 0;
+    const int64_t mine = x[0] + x[1] + x[2] + x[3];
+    int64_t inc = mine;  // inclusive scan of the lane sums
 #pragma unroll
     for (int d = 1; d < kWave; d <<= 1) {
       const int64_t y = __shfl_up(inc, d);
       if (lane >= d) inc += y;
     }
-    if (lane == kWave - 1) wave_sum[wave] = inc;
-    __syncthreads();
-    int64_t before = carry;
-    for (int wv = 0; wv < wave; wv++) before += wave_sum[wv];
-    if (i < n_items) item_off[i] = before + inc - x;
-    __syncthreads();
-    if (tid == kScanThreads - 1) carry = before + inc;
-    __syncthreads();
+    int64_t off = carry + inc - mine;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (i0 + k < n_items) item_off[i0 + k] = off;
+      off += x[k];
+    }
+    carry += __shfl(inc, kWave - 1);
   }
-  if (tid == 0) item_off[n_items] = carry;
-  __syncthreads();
+  if (lane == 0) item_off[n_items] = carry;
+  __threadfence();  // the index pass below reads what this wavefront just wrote
   // partition index: offset of the partition's first item (== total for trailing empties)
-  for (int32_t p = tid; p <= n_parts; p += kScanThreads) index[p] = item_off[part_first[p]];
+  for (int32_t p = lane; p <= n_parts; p += kWave)
+    index[p] = __builtin_nontemporal_load(&item_off[part_first[p]]);
 }
 
 constexpr int kGatherThreads = 256;
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(kGatherThreads) void gather_items_kernel(
 void launch_scan_items(const Item*, const uint32_t* d_item_size, int32_t n_items,
                        int64_t* d_item_off, const int32_t* d_part_first, int32_t n_parts,
                        int64_t* d_index, hipStream_t st) {
-  hipLaunchKernelGGL(scan_items_kernel, dim3(1), dim3(kScanThreads), 0, st, d_item_size, n_items,
+  hipLaunchKernelGGL(scan_items_kernel, dim3(1), dim3(kWave), 0, st, d_item_size, n_items,
                      d_item_off, d_part_first, n_parts, d_index);
 }
 

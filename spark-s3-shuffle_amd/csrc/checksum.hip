@@ -151,13 +151,21 @@ __global__ __launch_bounds__(kThreads) void checksum_segments_kernel(
   }
   uint32_t* out = partial + 4 * (size_t)b;
   if (ALGO == S3S_CHECKSUM_ADLER32) {
-    const uint32_t A = block_reduce_add(v0, scratch);  // <= 255*16384, no overflow
-    const uint32_t B = block_reduce_add(v1, scratch);  // <= 256*65520
-    if (tid == 0) {
-      out[0] = A % kAdlerMod;
-      out[1] = B % kAdlerMod;
-      out[2] = (uint32_t)seg_len;
+    // NO LDS in the Adler32 instantiation (the default algorithm): next to another task thread's codec
+    // kernel every byte of LDS is booked, and a workgroup that asks for 16 bytes of it waits for a
+    // ~1 ms chunk to finish.  Wavefront sums go to the zero-initialised partial with atomics; the
+    // combine kernel applies the modulus.  A <= 255*16384, B <= 256*65520: no overflow.
+    uint32_t A = v0, B = v1;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      A += __shfl_xor(A, d);
+      B += __shfl_xor(B, d);
     }
+    if ((tid & 63) == 0) {
+      atomicAdd(&out[0], A);
+      atomicAdd(&out[1], B);
+    }
+    if (tid == 0) out[2] = (uint32_t)seg_len;
   } else {
     const uint32_t c = block_reduce_xor(v0, scratch);
     if (tid == 0) {
@@ -180,15 +188,20 @@ __global__ __launch_bounds__(kThreads) void checksum_combine_kernel(
   const int64_t nseg = (plen + kChecksumSegBytes - 1) / kChecksumSegBytes;
   const uint32_t* part = partial + 4 * (size_t)seg_start[p];
   if (ALGO == S3S_CHECKSUM_ADLER32) {
+    // one wavefront per partition, no LDS (see checksum_segments_kernel)
     uint32_t sa = 0, sb = 0;
-    for (int64_t s = tid; s < nseg; s += kThreads) {
-      const uint32_t A = part[4 * s], B = part[4 * s + 1], len = part[4 * s + 2];
+    for (int64_t s = tid; s < nseg; s += kWave) {
+      const uint32_t A = part[4 * s] % kAdlerMod, B = part[4 * s + 1] % kAdlerMod, len = part[4 * s + 2];
       const int64_t after = plen - (s * kChecksumSegBytes + len);
       sa = (sa + A) % kAdlerMod;
       sb = (uint32_t)((sb + B + (uint64_t)A * (uint64_t)(after % kAdlerMod)) % kAdlerMod);
     }
-    const uint32_t a = block_reduce_add(sa, scratch);
-    const uint32_t b = block_reduce_add(sb, scratch);
+    uint32_t a = sa, b = sb;  // 64 values < 65521 each: no overflow
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      a += __shfl_xor(a, d);
+      b += __shfl_xor(b, d);
+    }
     if (tid == 0) {
       const uint32_t fa = (1u + a) % kAdlerMod;
       const uint32_t fb = (uint32_t)(((uint64_t)(plen % kAdlerMod) + b) % kAdlerMod);
@@ -254,11 +267,13 @@ void launch_checksum_with_tables(int algo, const uint8_t* d_data, const int64_t*
   if (n <= 0) return;
   const Tables* tabs = static_cast<const Tables*>(d_tables);
   if (algo == S3S_CHECKSUM_ADLER32) {
-    if (total_segs > 0)
+    if (total_segs > 0) {
+      (void)hipMemsetAsync(d_partial, 0, 16 * (size_t)total_segs, st);  // wavefront sums are added atomically
       hipLaunchKernelGGL(checksum_segments_kernel<S3S_CHECKSUM_ADLER32>, dim3((unsigned)total_segs),
                          dim3(kThreads), 0, st, d_data, d_offsets, n, d_seg_start, tabs, d_partial);
+    }
     hipLaunchKernelGGL(checksum_combine_kernel<S3S_CHECKSUM_ADLER32>, dim3((unsigned)n),
-                       dim3(kThreads), 0, st, d_offsets, n, d_seg_start, tabs, d_partial, d_out);
+                       dim3(kWave), 0, st, d_offsets, n, d_seg_start, tabs, d_partial, d_out);
   } else {
     if (total_segs > 0)
       hipLaunchKernelGGL(checksum_segments_kernel<S3S_CHECKSUM_CRC32>, dim3((unsigned)total_segs),

@@ -200,35 +200,34 @@ __global__ __launch_bounds__(kWave) void tile_emit_kernel(
     atomicExch(status, S3S_E_BAD_FRAME);
 }
 
-// generic single-workgroup exclusive scan of uint32 -> int64 (n+1 outputs)
-constexpr int kScanThreads = 1024;
-__global__ __launch_bounds__(kScanThreads) void scan_u32_kernel(const uint32_t* __restrict__ in,
-                                                               int64_t n,
-                                                               int64_t* __restrict__ out) {
-  __shared__ int64_t wave_sum[kScanThreads / kWave];
-  __shared__ int64_t carry;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) carry = 0;
-  __syncthreads();
-  for (int64_t tile = 0; tile < n; tile += kScanThreads) {
-    const int64_t i = tile + tid;
-    const int64_t x = i < n ? (int64_t)in[i] : 0;
-    int64_t inc = x;
+// generic exclusive scan of uint32 -> int64 (n+1 outputs): ONE wavefront, NO LDS — the decode kernels of
+// the other task threads book the whole LDS of every CU (20 x 8 KiB rings), and a workgroup that needs
+// any of it waits for one of their frames to finish (see scan_items_kernel in assemble.hip)
+__global__ __launch_bounds__(kWave) void scan_u32_kernel(const uint32_t* __restrict__ in, int64_t n,
+                                                         int64_t* __restrict__ out) {
+  const int lane = threadIdx.x;
+  int64_t carry = 0;
+  for (int64_t tile = 0; tile < n; tile += 4 * kWave) {
+    const int64_t i0 = tile + 4 * lane;
+    int64_t x[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) x[k] = i0 + k < n ? (int64_t)in[i0 + k] : 0;
+    const int64_t mine = x[0] + x[1] + x[2] + x[3];
+    int64_t inc = mine;
 #pragma unroll
     for (int d = 1; d < kWave; d <<= 1) {
       const int64_t y = __shfl_up(inc, d);
       if (lane >= d) inc += y;
     }
-    if (lane == kWave - 1) wave_sum[wave] = inc;
-    __syncthreads();
-    int64_t before = carry;
-    for (int wv = 0; wv < wave; wv++) before += wave_sum[wv];
-    if (i < n) out[i] = before + inc - x;
-    __syncthreads();
-    if (tid == kScanThreads - 1) carry = before + inc;
-    __syncthreads();
+    int64_t off = carry + inc - mine;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (i0 + k < n) out[i0 + k] = off;
+      off += x[k];
+    }
+    carry += __shfl(inc, kWave - 1);
   }
-  if (tid == 0) out[n] = carry;
+  if (lane == 0) out[n] = carry;
 }
 
 // ---- frame decode ----------------------------------------------------------------------------
@@ -1342,7 +1341,7 @@ void launch_lz4_discover(const uint8_t* d_comp, int64_t comp_len, int32_t n_tile
                      comp_len, n_tiles, d_spec_entry, d_spec_exit, d_spec_count);
   hipLaunchKernelGGL(tile_resolve_kernel, dim3(1), dim3(kWave), 0, st, d_comp, comp_len, n_tiles,
                      d_spec_entry, d_spec_exit, d_spec_count, d_true_entry, d_status);
-  hipLaunchKernelGGL(scan_u32_kernel, dim3(1), dim3(kScanThreads), 0, st,
+  hipLaunchKernelGGL(scan_u32_kernel, dim3(1), dim3(kWave), 0, st,
                      reinterpret_cast<const uint32_t*>(d_spec_count), (int64_t)n_tiles, d_frame_base);
 }
 
@@ -1354,12 +1353,12 @@ void launch_lz4_emit_frames(const uint8_t* d_comp, int64_t comp_len, int32_t n_t
   hipLaunchKernelGGL(tile_emit_kernel, dim3((unsigned)((n_tiles + kWave - 1) / kWave)), dim3(kWave),
                      0, st, d_comp, comp_len, n_tiles, d_true_entry, d_frame_base, d_frames,
                      d_frame_orig, d_status);
-  hipLaunchKernelGGL(scan_u32_kernel, dim3(1), dim3(kScanThreads), 0, st, d_frame_orig, n_frames,
+  hipLaunchKernelGGL(scan_u32_kernel, dim3(1), dim3(kWave), 0, st, d_frame_orig, n_frames,
                      d_frame_out);
 }
 
 void launch_scan_u32(const uint32_t* d_in, int64_t n, int64_t* d_out, hipStream_t st) {
-  hipLaunchKernelGGL(scan_u32_kernel, dim3(1), dim3(kScanThreads), 0, st, d_in, n, d_out);
+  hipLaunchKernelGGL(scan_u32_kernel, dim3(1), dim3(kWave), 0, st, d_in, n, d_out);
 }
 
 void launch_lz4_decompress(const uint8_t* d_comp, const Frame* d_frames, int32_t n_frames,
