@@ -943,14 +943,19 @@ __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t*
           DBG_ADD(3, tw4 - tw3);
           if (exit_kind == 1) break;
           // ================= commit: the highest kept lane of every hash group writes ==================
-          uint64_t Wm = K, sus = K & Dp;
-          while (sus) {
-            const int i = __builtin_ctzll(sus);
-            sus &= sus - 1ull;
-            const uint32_t hv = __builtin_amdgcn_readlane(h, i);
-            if (__ballot(h == hv) & K & ~((2ull << i) - 1ull)) Wm &= ~(1ull << i);
+          // All kept lanes store at once; which lane wins a same-address store is the hardware's choice, so
+          // the lanes read back and every kept lane that finds a LOWER position in its slot stores again,
+          // until none does (the owner only moves up: at most group-size rounds, one or two in practice).
+          // This replaces a scalar loop over the kept group lanes (~10 SALU each, dozens per window).
+          const bool kept = ((K >> lane) & 1ull) != 0ull;
+          if (kept) T[h] = (uint16_t)p;
+          if (K & Dp) {
+            for (;;) {
+              const bool redo = kept && (uint32_t)T[h] < (uint32_t)p;
+              if (!__ballot(redo)) break;
+              if (redo) T[h] = (uint16_t)p;
+            }
           }
-          if ((Wm >> lane) & 1ull) T[h] = (uint16_t)p;
           if (pend_q >= 0) {
             const uint32_t vq = pend_q < wbase + 2 * kWave
                                     ? __builtin_amdgcn_readlane(vn, pend_q - wbase - kWave)
