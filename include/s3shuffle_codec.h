@@ -185,6 +185,28 @@ int s3s_decompress_range_device(s3s_ctx* ctx, int codec, int checksum_algo,
                                 const int64_t* part_offsets, const int64_t* ref_checksums,
                                 int32_t nparts, uint8_t* d_dst, int64_t dst_capacity,
                                 int64_t* out_len, int32_t* out_bad_partition);
+/* Multi-spill map tasks.  When a map task spilled N times, Spark's merge hands every partition to the
+ * partition writer as the concatenation of N independently written pieces, and on the JVM each piece is
+ * one COMPLETE codec stream (LZ4Block end frame / Snappy stream header included) — see the writers that
+ * feed shuffle/S3ShuffleMapOutputWriter.scala:67-83 and the pre-merged spill file of
+ * shuffle/S3SingleSpillShuffleMapOutputWriter.scala:24-64.  To keep the `.data` object byte-identical
+ * the shim passes the piece boundaries: seg_offsets[0..n_segs] delimit the pieces in src (ascending,
+ * contiguous), part_first_seg[0..n] (part_first_seg[0] = 0, part_first_seg[n] = n_segs) assigns them to
+ * the n partitions.  Every non-empty piece becomes one stream; index and checksums stay per partition.
+ * With one piece per partition this is exactly s3s_compress_map_output.                               */
+int64_t s3s_max_compressed_size_segments(const s3s_ctx* ctx, int codec, const int64_t* seg_offsets,
+                                         int32_t n_segs);
+int s3s_compress_map_output_segments(s3s_ctx* ctx, int codec, int checksum_algo, const uint8_t* src,
+                                     const int64_t* seg_offsets, int32_t n_segs,
+                                     const int32_t* part_first_seg, int32_t n, uint8_t* dst,
+                                     int64_t dst_capacity, int64_t* out_index, int64_t* out_checksums,
+                                     int64_t* out_total);
+int s3s_compress_map_output_segments_device(s3s_ctx* ctx, int codec, int checksum_algo,
+                                            const uint8_t* d_src, const int64_t* seg_offsets,
+                                            int32_t n_segs, const int32_t* part_first_seg, int32_t n,
+                                            uint8_t* d_dst, int64_t dst_capacity, int64_t* out_index,
+                                            int64_t* out_checksums, int64_t* out_total);
+
 /* Page-locked host staging memory for the host-buffer entry points (no reference counterpart:
  * it replaces the heap byte[] of storage/S3BufferedInputStreamAdaptor.scala:13-19 — one
  * BufferedInputStream of min(maxBufferSizeTask, block length) bytes per prefetched block — and of

@@ -164,13 +164,19 @@ int64_t s3s_max_compressed_size(const s3s_ctx* ctx, int codec, const int64_t* sr
   return total;
 }
 
-int s3s_compress_map_output_device(s3s_ctx* ctx, int codec, int checksum_algo,
-                                   const uint8_t* d_src, const int64_t* src_offsets, int32_t n,
-                                   uint8_t* d_dst, int64_t dst_capacity, int64_t* out_index,
-                                   int64_t* out_checksums, int64_t* out_total) {
+// The map-side path.  Partition p is made of the segments [pfs[p], pfs[p+1]) of seg_offsets (ns segments in
+// all, contiguous in d_src); every non-empty segment becomes one complete codec stream.
+static int compress_core(s3s_ctx* ctx, int codec, int checksum_algo, const uint8_t* d_src,
+                         const int64_t* seg_offsets, int32_t ns, const int32_t* pfs, int32_t n,
+                         uint8_t* d_dst, int64_t dst_capacity, int64_t* out_index,
+                         int64_t* out_checksums, int64_t* out_total) {
   if (!ctx) return S3S_E_INVALID;
   ctx->err[0] = 0;
-  if (n < 0 || !src_offsets || !out_index) return fail(ctx, S3S_E_INVALID, "null offsets/index or negative partition count");
+  if (n < 0 || ns < 0 || !seg_offsets || !pfs || !out_index)
+    return fail(ctx, S3S_E_INVALID, "null offsets/index or negative partition count");
+  if (pfs[0] != 0 || pfs[n] != ns) return fail(ctx, S3S_E_INVALID, "part_first_seg must start at 0 and end at n_segs");
+  for (int32_t p = 0; p < n; p++)
+    if (pfs[p + 1] < pfs[p]) return fail(ctx, S3S_E_INVALID, "part_first_seg not monotonic at %d", p);
   if (codec != S3S_CODEC_NONE && codec != S3S_CODEC_LZ4 && codec != S3S_CODEC_SNAPPY)
     return fail(ctx, S3S_E_INVALID, "unknown codec %d", codec);
   if (checksum_algo != S3S_CHECKSUM_NONE && checksum_algo != S3S_CHECKSUM_ADLER32 &&
@@ -178,23 +184,23 @@ int s3s_compress_map_output_device(s3s_ctx* ctx, int codec, int checksum_algo,
     return fail(ctx, S3S_E_INVALID, "unknown checksum algorithm %d", checksum_algo);
   if (checksum_algo != S3S_CHECKSUM_NONE && !out_checksums)
     return fail(ctx, S3S_E_INVALID, "out_checksums is null but a checksum algorithm is selected");
-  for (int32_t p = 0; p < n; p++)
-    if (src_offsets[p + 1] < src_offsets[p]) return fail(ctx, S3S_E_INVALID, "src_offsets not monotonic at %d", p);
+  for (int32_t g = 0; g < ns; g++)
+    if (seg_offsets[g + 1] < seg_offsets[g]) return fail(ctx, S3S_E_INVALID, "offsets not monotonic at %d", g);
   if (dst_capacity < 0) return fail(ctx, S3S_E_INVALID, "negative dst_capacity");
   if (codec == S3S_CODEC_SNAPPY && !snappy_compress_available())
     return fail(ctx, S3S_E_UNSUPPORTED, "snappy compression is not available in this build");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
 
   const int64_t bs = effective_block(ctx, codec);
-  const int64_t total_u = n > 0 ? src_offsets[n] - src_offsets[0] : 0;
+  const int64_t total_u = ns > 0 ? seg_offsets[ns] - seg_offsets[0] : 0;
   if ((total_u > 0 && !d_src) || (!d_dst && dst_capacity > 0)) return fail(ctx, S3S_E_INVALID, "null data pointer");
   const int level = codec == S3S_CODEC_LZ4 ? lz4_level(bs) : 0;
 
   // ---- plan (host): items in .data order, first item per partition, checksum segment slots ---
   int64_t n_items64 = 0, n_chunks64 = 0;
   if (codec != S3S_CODEC_NONE) {
-    for (int32_t p = 0; p < n; p++) {
-      const int64_t u = src_offsets[p + 1] - src_offsets[p];
+    for (int32_t g = 0; g < ns; g++) {
+      const int64_t u = seg_offsets[g + 1] - seg_offsets[g];
       if (u > 0) {
         const int64_t ch = (u + bs - 1) / bs;
         n_chunks64 += ch;
@@ -227,21 +233,23 @@ int s3s_compress_map_output_device(s3s_ctx* ctx, int codec, int checksum_algo,
 
   {
     int32_t it = 0, ch = 0, seg = 0;
-    const int64_t base = n > 0 ? src_offsets[0] : 0;
-    (void)base;
     for (int32_t p = 0; p < n; p++) {
-      const int64_t u = src_offsets[p + 1] - src_offsets[p];
       h_pf[p] = it;
       h_seg[p] = seg;
-      seg += worst_segs(max_partition_size(codec, bs, u));
-      if (codec == S3S_CODEC_NONE || u <= 0) continue;
-      if (codec == S3S_CODEC_SNAPPY) h_items[it++] = Item{0, 0, kItemSnappyHeader, -1, p};
-      for (int64_t pos = 0; pos < u; pos += bs) {
-        const int32_t len = (int32_t)((u - pos) < bs ? (u - pos) : bs);
-        const int32_t kind = codec == S3S_CODEC_LZ4 ? (kItemLz4Chunk | (level << 8)) : kItemSnappyChunk;
-        h_items[it++] = Item{src_offsets[p] + pos, len, kind, ch++, p};
+      int64_t worst = 0;  // of the partition's compressed bytes: one stream per non-empty segment
+      for (int32_t g = pfs[p]; g < pfs[p + 1]; g++) {
+        const int64_t u = seg_offsets[g + 1] - seg_offsets[g];
+        worst += max_partition_size(codec, bs, u);
+        if (codec == S3S_CODEC_NONE || u <= 0) continue;
+        if (codec == S3S_CODEC_SNAPPY) h_items[it++] = Item{0, 0, kItemSnappyHeader, -1, p};
+        for (int64_t pos = 0; pos < u; pos += bs) {
+          const int32_t len = (int32_t)((u - pos) < bs ? (u - pos) : bs);
+          const int32_t kind = codec == S3S_CODEC_LZ4 ? (kItemLz4Chunk | (level << 8)) : kItemSnappyChunk;
+          h_items[it++] = Item{seg_offsets[g] + pos, len, kind, ch++, p};
+        }
+        if (codec == S3S_CODEC_LZ4) h_items[it++] = Item{0, 0, kItemLz4End | (level << 8), -1, p};
       }
-      if (codec == S3S_CODEC_LZ4) h_items[it++] = Item{0, 0, kItemLz4End | (level << 8), -1, p};
+      seg += worst_segs(worst);
     }
     h_pf[n] = it;
     h_seg[n] = seg;
@@ -260,8 +268,8 @@ int s3s_compress_map_output_device(s3s_ctx* ctx, int codec, int checksum_algo,
     // spark.shuffle.compress=false: the partition bytes are the stream
     if (total_u > dst_capacity) return fail(ctx, S3S_E_CAPACITY, "dst_capacity %lld < %lld", (long long)dst_capacity, (long long)total_u);
     if (total_u > 0)
-      HIP_TRY(ctx, hipMemcpyAsync(d_dst, d_src + src_offsets[0], (size_t)total_u, hipMemcpyDeviceToDevice, ctx->stream));
-    for (int32_t p = 0; p <= n; p++) h_idx[p] = n > 0 ? src_offsets[p] - src_offsets[0] : 0;
+      HIP_TRY(ctx, hipMemcpyAsync(d_dst, d_src + seg_offsets[0], (size_t)total_u, hipMemcpyDeviceToDevice, ctx->stream));
+    for (int32_t p = 0; p <= n; p++) h_idx[p] = ns > 0 ? seg_offsets[pfs[p]] - seg_offsets[0] : 0;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_INDEX].p, h_idx, idx_bytes, hipMemcpyHostToDevice, ctx->stream));
     record(ctx, 1);
     record(ctx, 2);
@@ -358,6 +366,67 @@ int s3s_compress_map_output_device(s3s_ctx* ctx, int codec, int checksum_algo,
     return fail(ctx, S3S_E_CAPACITY, "dst_capacity %lld too small for %lld output bytes",
                 (long long)dst_capacity, (long long)h_idx[n]);
   if (checksum_algo != S3S_CHECKSUM_NONE && n > 0) memcpy(out_checksums, h_sums, sizeof(int64_t) * (size_t)n);
+  return S3S_OK;
+}
+
+int s3s_compress_map_output_device(s3s_ctx* ctx, int codec, int checksum_algo,
+                                   const uint8_t* d_src, const int64_t* src_offsets, int32_t n,
+                                   uint8_t* d_dst, int64_t dst_capacity, int64_t* out_index,
+                                   int64_t* out_checksums, int64_t* out_total) {
+  if (!ctx) return S3S_E_INVALID;
+  if (n < 0 || !src_offsets) {
+    ctx->err[0] = 0;
+    return fail(ctx, S3S_E_INVALID, "null offsets/index or negative partition count");
+  }
+  std::vector<int32_t> pfs((size_t)n + 1);  // one segment per partition
+  for (int32_t p = 0; p <= n; p++) pfs[(size_t)p] = p;
+  return compress_core(ctx, codec, checksum_algo, d_src, src_offsets, n, pfs.data(), n, d_dst, dst_capacity,
+                       out_index, out_checksums, out_total);
+}
+
+int64_t s3s_max_compressed_size_segments(const s3s_ctx* ctx, int codec, const int64_t* seg_offsets, int32_t n_segs) {
+  return s3s_max_compressed_size(ctx, codec, seg_offsets, n_segs);  // a bound per stream, summed
+}
+
+int s3s_compress_map_output_segments_device(s3s_ctx* ctx, int codec, int checksum_algo, const uint8_t* d_src,
+                                            const int64_t* seg_offsets, int32_t n_segs,
+                                            const int32_t* part_first_seg, int32_t n, uint8_t* d_dst,
+                                            int64_t dst_capacity, int64_t* out_index, int64_t* out_checksums,
+                                            int64_t* out_total) {
+  return compress_core(ctx, codec, checksum_algo, d_src, seg_offsets, n_segs, part_first_seg, n, d_dst,
+                       dst_capacity, out_index, out_checksums, out_total);
+}
+
+int s3s_compress_map_output_segments(s3s_ctx* ctx, int codec, int checksum_algo, const uint8_t* src,
+                                     const int64_t* seg_offsets, int32_t n_segs, const int32_t* part_first_seg,
+                                     int32_t n, uint8_t* dst, int64_t dst_capacity, int64_t* out_index,
+                                     int64_t* out_checksums, int64_t* out_total) {
+  if (!ctx) return S3S_E_INVALID;
+  ctx->err[0] = 0;
+  if (n < 0 || n_segs < 0 || !seg_offsets || !part_first_seg)
+    return fail(ctx, S3S_E_INVALID, "null offsets or negative partition / segment count");
+  for (int32_t g = 0; g < n_segs; g++)
+    if (seg_offsets[g + 1] < seg_offsets[g]) return fail(ctx, S3S_E_INVALID, "offsets not monotonic at %d", g);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int64_t first = n_segs > 0 ? seg_offsets[0] : 0;
+  const int64_t total_u = n_segs > 0 ? seg_offsets[n_segs] - first : 0;
+  const int64_t bound = s3s_max_compressed_size(ctx, codec, seg_offsets, n_segs);
+  if (bound < 0) return fail(ctx, S3S_E_INVALID, "invalid codec or offsets");
+  if ((total_u > 0 && !src) || (dst_capacity > 0 && !dst) || dst_capacity < 0) return fail(ctx, S3S_E_INVALID, "null/invalid host buffer");
+  const int64_t dcap = dst_capacity < bound ? dst_capacity : bound;
+  int rc;
+  if ((rc = ensure(ctx, B_SRC, (size_t)total_u + 64))) return rc;
+  if ((rc = ensure(ctx, B_DST, (size_t)dcap + 64))) return rc;
+  if (total_u > 0)
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_SRC].p, src + first, (size_t)total_u, hipMemcpyHostToDevice, ctx->stream));
+  std::vector<int64_t> rebased((size_t)n_segs + 1);
+  for (int32_t g = 0; g <= n_segs; g++) rebased[(size_t)g] = seg_offsets[g] - first;
+  int64_t total = 0;
+  rc = compress_core(ctx, codec, checksum_algo, dev<uint8_t>(ctx, B_SRC), rebased.data(), n_segs, part_first_seg, n,
+                     dev<uint8_t>(ctx, B_DST), dcap, out_index, out_checksums, &total);
+  if (out_total) *out_total = total;
+  if (rc != S3S_OK) return rc;
+  if (total > 0) HIP_TRY(ctx, hipMemcpy(dst, ctx->buf[B_DST].p, (size_t)total, hipMemcpyDeviceToHost));
   return S3S_OK;
 }
 

@@ -251,6 +251,13 @@ int64_t S3ShuffleMapOutputWriter::getNumBytesWritten() const {
 
 void S3ShuffleMapOutputWriter::closePartition() { streamClosed_ = true; }
 
+void S3ShuffleMapOutputWriter::markSegment() {
+  if (streamClosed_ || lastPartitionWriterId_ < 0) throw IOException("Partition writer stream is closed.");
+  if (cuts_.empty()) cuts_.resize((size_t)numPartitions_);
+  std::vector<int64_t>& c = cuts_[(size_t)lastPartitionWriterId_];
+  if (stageLen_ > srcOffsets_[(size_t)lastPartitionWriterId_] && (c.empty() || c.back() != stageLen_)) c.push_back(stageLen_);
+}
+
 std::vector<int64_t> S3ShuffleMapOutputWriter::commitAllPartitions() {
   if (committed_) throw std::runtime_error("commitAllPartitions called twice");
   const bool timing = getenv("S3SH_TIMING") != nullptr;
@@ -260,7 +267,22 @@ std::vector<int64_t> S3ShuffleMapOutputWriter::commitAllPartitions() {
   for (int p = lastPartitionWriterId_ + 1; p <= numPartitions_; p++) srcOffsets_[(size_t)p] = stageLen_;
   const int codec = d_.codecId(), algo = d_.checksumId();
   if (!ctx_) ctx_ = acquireContext(d_, d_.deviceForMap(mapId_));
-  const int64_t cap = s3s_max_compressed_size(ctx_, codec, srcOffsets_.data(), numPartitions_);
+  // multi-spill merge (markSegment): one stream per piece
+  std::vector<int64_t> segOffsets;
+  std::vector<int32_t> partFirstSeg;
+  if (!cuts_.empty()) {
+    partFirstSeg.assign((size_t)numPartitions_ + 1, 0);
+    for (int p = 0; p < numPartitions_; p++) {
+      partFirstSeg[(size_t)p] = (int32_t)segOffsets.size();
+      segOffsets.push_back(srcOffsets_[(size_t)p]);
+      for (int64_t c : cuts_[(size_t)p])
+        if (c > segOffsets.back() && c < srcOffsets_[(size_t)p + 1]) segOffsets.push_back(c);
+    }
+    partFirstSeg[(size_t)numPartitions_] = (int32_t)segOffsets.size();
+    segOffsets.push_back(srcOffsets_[(size_t)numPartitions_]);
+  }
+  const int64_t cap = cuts_.empty() ? s3s_max_compressed_size(ctx_, codec, srcOffsets_.data(), numPartitions_)
+                                    : s3s_max_compressed_size_segments(ctx_, codec, segOffsets.data(), (int32_t)segOffsets.size() - 1);
   if (cap < 0) throw std::runtime_error("Precondition: invalid partition offsets");
   struct PinnedOut {  // the .data image, page-locked: D2H is plain DMA, then one write to the store
     uint8_t* p;
@@ -268,8 +290,15 @@ std::vector<int64_t> S3ShuffleMapOutputWriter::commitAllPartitions() {
   } data{PinnedPool::process().acquire(cap + 1)};
   std::vector<int64_t> index((size_t)numPartitions_ + 1, 0), sums((size_t)std::max(numPartitions_, 1), 0);
   int64_t total = 0;
-  const int rc = s3s_compress_map_output(ctx_, codec, algo, stage_, srcOffsets_.data(), numPartitions_, data.p, cap,
-                                         index.data(), algo == S3S_CHECKSUM_NONE ? nullptr : sums.data(), &total);
+  int rc;
+  if (cuts_.empty()) {
+    rc = s3s_compress_map_output(ctx_, codec, algo, stage_, srcOffsets_.data(), numPartitions_, data.p, cap,
+                                 index.data(), algo == S3S_CHECKSUM_NONE ? nullptr : sums.data(), &total);
+  } else {
+    rc = s3s_compress_map_output_segments(ctx_, codec, algo, stage_, segOffsets.data(), (int32_t)segOffsets.size() - 1,
+                                          partFirstSeg.data(), numPartitions_, data.p, cap, index.data(),
+                                          algo == S3S_CHECKSUM_NONE ? nullptr : sums.data(), &total);
+  }
   if (rc != S3S_OK) throw IOException(std::string("s3s_compress_map_output: ") + s3s_last_error(ctx_));
   const auto t1 = now();
   std::vector<int64_t> partitionLengths((size_t)numPartitions_);
@@ -476,6 +505,9 @@ int s3sh_writer_get_partition_writer(void* w, int reducePartitionId) {
 }
 int s3sh_writer_write(void* w, const void* bytes, long long len) {
   return guarded([&] { static_cast<S3ShuffleMapOutputWriter*>(w)->write(bytes, (size_t)len); });
+}
+int s3sh_writer_mark_segment(void* w) {
+  return guarded([&] { static_cast<S3ShuffleMapOutputWriter*>(w)->markSegment(); });
 }
 int s3sh_writer_close_partition(void* w) {
   return guarded([&] { static_cast<S3ShuffleMapOutputWriter*>(w)->closePartition(); });

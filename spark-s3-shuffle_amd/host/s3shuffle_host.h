@@ -135,6 +135,12 @@ class S3ShuffleMapOutputWriter {
   int64_t getNumBytesWritten() const;  // of the current partition (uncompressed: what the task wrote)
   // closes the current partition stream; commitAllPartitions closes the last one implicitly
   void closePartition();
+  // multi-spill merge: the bytes written to the current partition so far are one spill's piece, the next
+  // write starts another.  On the JVM every piece is a complete codec stream (the merge copies the spill
+  // files' partition ranges verbatim), so a merge that knows its spill boundaries calls this between
+  // pieces and the stored object stays byte-identical (s3s_compress_map_output_segments).  Optional: without
+  // it a partition is one stream, which every reader decodes to the same records.
+  void markSegment();
   // returns partitionLengths (compressed bytes per partition), like MapOutputCommitMessage.of(...)
   std::vector<int64_t> commitAllPartitions();
   void abort();
@@ -149,6 +155,7 @@ class S3ShuffleMapOutputWriter {
   uint8_t* stage_ = nullptr;  // page-locked, from PinnedPool::process()
   int64_t stageCap_ = 0, stageLen_ = 0;
   std::vector<int64_t> srcOffsets_;  // numPartitions + 1
+  std::vector<std::vector<int64_t>> cuts_;  // per partition: piece boundaries inside it (absolute staging offsets)
   s3s_ctx* ctx_ = nullptr;
 };
 

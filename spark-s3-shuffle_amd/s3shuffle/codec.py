@@ -96,6 +96,13 @@ def load_library() -> ctypes.CDLL:
     lib.s3s_decompress_range.argtypes = dec_args
     lib.s3s_decompress_range_device.argtypes = dec_args
     lib.s3s_decompressed_size.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int64, c_i64p]
+    c_i32p = ctypes.POINTER(ctypes.c_int32)
+    lib.s3s_max_compressed_size_segments.restype = ctypes.c_int64
+    lib.s3s_max_compressed_size_segments.argtypes = [vp, ctypes.c_int, c_i64p, ctypes.c_int32]
+    seg_args = [vp, ctypes.c_int, ctypes.c_int, vp, c_i64p, ctypes.c_int32, c_i32p, ctypes.c_int32, vp,
+                ctypes.c_int64, c_i64p, c_i64p, c_i64p]
+    lib.s3s_compress_map_output_segments.argtypes = seg_args
+    lib.s3s_compress_map_output_segments_device.argtypes = seg_args
     lib.s3s_host_alloc.restype = vp
     lib.s3s_host_alloc.argtypes = [ctypes.c_int64]
     lib.s3s_host_free.argtypes = [vp]
@@ -194,6 +201,28 @@ class Codec:
         rc = self._lib.s3s_compress_map_output(
             self._h, codec, checksum, src.ctypes.data, _p64(offs), n, dst.ctypes.data, cap,
             _p64(index), _p64(sums) if checksum != CHECKSUM_NONE else None, ctypes.byref(total))
+        self._check(rc)
+        return dst[: total.value], index, (sums[:n] if checksum != CHECKSUM_NONE else None)
+
+    def compress_map_output_segments(self, codec: int, checksum: int, src: np.ndarray, seg_offsets,
+                                     part_first_seg) -> Tuple[np.ndarray, np.ndarray, Optional[np.ndarray]]:
+        """Multi-spill map task: partition p = pieces [part_first_seg[p], part_first_seg[p+1]) of
+        seg_offsets, one complete codec stream per non-empty piece (host buffers)."""
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        segs = _i64(seg_offsets)
+        pfs = np.ascontiguousarray(part_first_seg, dtype=np.int32)
+        ns, n = len(segs) - 1, len(pfs) - 1
+        cap = int(self._lib.s3s_max_compressed_size_segments(self._h, codec, _p64(segs), ns))
+        if cap < 0:
+            self._check(cap)
+        dst = np.empty(max(cap, 1), dtype=np.uint8)
+        index = np.zeros(n + 1, dtype=np.int64)
+        sums = np.zeros(max(n, 1), dtype=np.int64)
+        total = ctypes.c_int64(0)
+        rc = self._lib.s3s_compress_map_output_segments(
+            self._h, codec, checksum, src.ctypes.data, _p64(segs), ns,
+            pfs.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), n, dst.ctypes.data, cap, _p64(index),
+            _p64(sums) if checksum != CHECKSUM_NONE else None, ctypes.byref(total))
         self._check(rc)
         return dst[: total.value], index, (sums[:n] if checksum != CHECKSUM_NONE else None)
 

@@ -50,6 +50,7 @@ def _lib():
         L.s3sh_writer_get_partition_writer.argtypes = [vp, ctypes.c_int]
         L.s3sh_writer_write.argtypes = [vp, vp, ctypes.c_longlong]
         L.s3sh_writer_close_partition.argtypes = [vp]
+        L.s3sh_writer_mark_segment.argtypes = [vp]
         L.s3sh_writer_num_bytes_written.restype = ctypes.c_longlong
         L.s3sh_writer_num_bytes_written.argtypes = [vp]
         L.s3sh_writer_commit.argtypes = [vp, vp]
@@ -146,6 +147,10 @@ class MapOutputWriter:
     def write(self, data):
         a = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray)) else data, dtype=np.uint8)
         _check(_lib().s3sh_writer_write(self._h, a.ctypes.data, a.size))
+
+    def mark_segment(self):
+        """Multi-spill merge: what was written to the current partition so far is one spill's piece."""
+        _check(_lib().s3sh_writer_mark_segment(self._h))
 
     def close_partition(self):
         _check(_lib().s3sh_writer_close_partition(self._h))

@@ -197,3 +197,50 @@ def test_contexts_are_concurrent_and_independent(oracle):
     [t.start() for t in ths]
     [t.join() for t in ths]
     assert not errors, errors
+
+
+@pytest.mark.parametrize("codec", [LZ4, SNAPPY, NONE])
+def test_multi_spill_segments_are_one_stream_per_piece(gpu_codec, oracle, codec, lz4_variant):
+    """SURVEY §8 caveat 5: after N spills every partition reaches the writer as N pieces, and on the JVM each
+    piece is a complete codec stream.  s3s_compress_map_output_segments must produce exactly that object:
+    per partition the concatenation of oracle.compress_stream(piece) for its non-empty pieces, the index
+    and the checksums per partition — and the reader must decode it back (concatenated streams)."""
+    if lz4_variant not in (2, 9):
+        pytest.skip("one LZ4 variant is enough here")
+    rng = np.random.default_rng(41 + codec)
+    n_parts, n_spills = 9, 3
+    pieces, part_first = [], [0]
+    for p in range(n_parts):
+        for sp in range(n_spills):
+            kind = int(rng.integers(0, corpus.N_KINDS))
+            n = int(rng.choice([0, 0, 1, 13, 700, 32768, 40000, 90000]))
+            if kind == 6:
+                n = min(n, 5000)
+            if p == 4:
+                n = 0  # a partition that is empty in every spill
+            pieces.append(corpus.chunk_corpus(kind, n, rng))
+        part_first.append(len(pieces))
+    seg_offsets = np.zeros(len(pieces) + 1, np.int64)
+    np.cumsum([x.size for x in pieces], out=seg_offsets[1:])
+    data = np.concatenate(pieces) if seg_offsets[-1] else np.zeros(0, np.uint8)
+    img, index, sums = gpu_codec.compress_map_output_segments(codec, ADLER, data, seg_offsets, part_first)
+    want_parts = []
+    for p in range(n_parts):
+        streams = [oracle.compress_stream(codec, x) if codec != NONE else x
+                   for x in pieces[part_first[p]:part_first[p + 1]] if x.size]
+        want_parts.append(np.concatenate(streams) if streams else np.zeros(0, np.uint8))
+    want_index = np.zeros(n_parts + 1, np.int64)
+    np.cumsum([w.size for w in want_parts], out=want_index[1:])
+    assert np.array_equal(index, want_index)
+    assert np.array_equal(img, np.concatenate(want_parts))
+    assert [int(x) for x in sums] == [oracle.checksum(ADLER, w) for w in want_parts]
+    assert index[5] == index[4]  # the empty partition
+    back = gpu_codec.decompress_range(codec, ADLER, img, index, sums)
+    assert np.array_equal(back, data)
+    # one piece per partition is the plain entry point
+    offs = seg_offsets[np.array(part_first)]
+    a = gpu_codec.compress_map_output_segments(codec, CRC, data, offs, np.arange(n_parts + 1))
+    b = gpu_codec.compress_map_output(codec, CRC, data, offs)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    with pytest.raises(Exception):
+        gpu_codec.compress_map_output_segments(codec, ADLER, data, seg_offsets, [0, 2, 1, len(pieces)])

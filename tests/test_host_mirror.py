@@ -271,3 +271,40 @@ def test_prefetch_pipeline_propagates_block_errors(gpu_codec, root):
         host.read_shuffle(d, 0, 0, 5, True)
     d.remove_root()
     d.close()
+
+
+@pytest.mark.gpu
+def test_multi_spill_merge_keeps_one_stream_per_piece(gpu_codec, oracle, root):
+    """A merge that knows its spill boundaries marks them (markSegment): the stored .data object is then the
+    JVM's — per partition one complete LZ4Block stream per spill piece — and reads back to the same records."""
+    from s3shuffle import host
+
+    rng = np.random.default_rng(77)
+    d = host.Dispatcher(root)
+    n_parts, n_spills = 5, 3
+    w = host.MapOutputWriter(d, 0, 0, n_parts)
+    want, plain = [], []
+    for p in range(n_parts):
+        if p == 2:
+            want.append(b"")
+            plain.append(np.zeros(0, np.uint8))
+            continue  # never written: stays empty
+        w.get_partition_writer(p)
+        streams, raw = [], []
+        for sp in range(n_spills):
+            piece = rng.integers(0, 7, int(rng.integers(0, 70_000)), dtype=np.uint8)
+            if piece.size:
+                w.write(piece)
+                streams.append(oracle.compress_stream(1, piece).tobytes())
+                raw.append(piece)
+            w.mark_segment()
+        want.append(b"".join(streams))
+        plain.append(np.concatenate(raw) if raw else np.zeros(0, np.uint8))
+    lengths = w.commit_all_partitions()
+    w.close()
+    assert [int(x) for x in lengths] == [len(x) for x in want]
+    assert open(d.get_path(host.KIND_DATA, 0, 0), "rb").read() == b"".join(want)
+    got = host.read_shuffle(d, 0, 0, n_parts, True)
+    assert len(got) == 1 and np.array_equal(got[0][4], np.concatenate(plain))
+    d.remove_root()
+    d.close()
