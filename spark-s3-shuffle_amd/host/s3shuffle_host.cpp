@@ -334,6 +334,58 @@ void S3ShuffleMapOutputWriter::abort() {
   committed_ = true;
 }
 
+std::vector<int64_t> S3SingleSpillShuffleMapOutputWriter::transferMapSpillFile(const std::string& mapSpillFile,
+                                                                                const std::vector<int64_t>& partitionLengths,
+                                                                                const std::vector<int64_t>& /*checksums*/) {
+  const int n = (int)partitionLengths.size();
+  std::vector<int64_t> offs((size_t)n + 1, 0);
+  for (int p = 0; p < n; p++) {
+    if (partitionLengths[(size_t)p] < 0) throw std::runtime_error("Precondition: negative partition length");
+    offs[(size_t)p + 1] = offs[(size_t)p] + partitionLengths[(size_t)p];
+  }
+  const int64_t bytes = offs[(size_t)n];
+  struct Pinned {
+    uint8_t* p;
+    ~Pinned() { PinnedPool::process().release(p); }
+  };
+  Pinned in{PinnedPool::process().acquire(bytes + 1)};
+  {
+    FILE* f = fopen(mapSpillFile.c_str(), "rb");
+    if (!f) throw IOException("cannot open " + mapSpillFile);
+    const size_t got = bytes ? fread(in.p, 1, (size_t)bytes, f) : 0;
+    const bool more = fgetc(f) != EOF;
+    fclose(f);
+    if ((int64_t)got != bytes || more) throw IOException("spill file length does not match partitionLengths: " + mapSpillFile);
+  }
+  const int codec = d_.codecId(), algo = d_.checksumId();
+  const int device = d_.deviceForMap(mapId_);
+  s3s_ctx* ctx = acquireContext(d_, device);
+  struct CtxGuard {
+    const S3ShuffleDispatcher& d;
+    int device;
+    s3s_ctx* c;
+    ~CtxGuard() { releaseContext(d, device, c); }
+  } guard{d_, device, ctx};
+  const int64_t cap = s3s_max_compressed_size(ctx, codec, offs.data(), n);
+  if (cap < 0) throw std::runtime_error("Precondition: invalid partition lengths");
+  Pinned out{PinnedPool::process().acquire(cap + 1)};
+  std::vector<int64_t> index((size_t)n + 1, 0), sums((size_t)std::max(n, 1), 0);
+  int64_t total = 0;
+  const int rc = s3s_compress_map_output(ctx, codec, algo, in.p, offs.data(), n, out.p, cap, index.data(),
+                                         algo == S3S_CHECKSUM_NONE ? nullptr : sums.data(), &total);
+  if (rc != S3S_OK) throw IOException(std::string("s3s_compress_map_output: ") + s3s_last_error(ctx));
+  d_.createBlock(BlockId::ShuffleDataBlockId(shuffleId_, mapId_), out.p, (size_t)total);
+  std::vector<int64_t> lengths((size_t)n);
+  for (int p = 0; p < n; p++) lengths[(size_t)p] = index[(size_t)p + 1] - index[(size_t)p];
+  if (d_.conf().checksumEnabled) {  // :59-61
+    sums.resize((size_t)n);
+    S3ShuffleHelper::writeChecksum(d_, shuffleId_, mapId_, sums);
+  }
+  S3ShuffleHelper::writePartitionLengths(d_, shuffleId_, mapId_, lengths);  // :62, unconditional
+  ::remove(mapSpillFile.c_str());  // the reference moves the file (:41) or streams it out of the local dir
+  return lengths;
+}
+
 // ---- reduce side ---------------------------------------------------------------------------------------
 S3ShuffleReader::S3ShuffleReader(const S3ShuffleDispatcher& d, int shuffleId, int startPartition, int endPartition,
                                  bool doBatchFetch)
@@ -517,6 +569,15 @@ int s3sh_writer_commit(void* w, long long* outLengths) {
   return guarded([&] {
     const auto v = static_cast<S3ShuffleMapOutputWriter*>(w)->commitAllPartitions();
     for (size_t i = 0; i < v.size(); i++) outLengths[i] = v[i];
+  });
+}
+int s3sh_single_spill_transfer(void* d, int shuffleId, long long mapId, const char* spillFile, const long long* partitionLengths,
+                               int numPartitions, long long* outLengths) {
+  return guarded([&] {
+    S3SingleSpillShuffleMapOutputWriter w(*static_cast<S3ShuffleDispatcher*>(d), shuffleId, mapId);
+    std::vector<int64_t> pl(partitionLengths, partitionLengths + numPartitions);
+    const std::vector<int64_t> l = w.transferMapSpillFile(spillFile, pl, {});
+    for (size_t i = 0; i < l.size(); i++) outLengths[i] = l[i];
   });
 }
 int s3sh_writer_abort(void* w) {

@@ -17,6 +17,7 @@
 //                            iff checksumEnabled), abort.  With the GPU path on, partition
 //                            writers receive UNCOMPRESSED serialized bytes and commit runs
 //                            s3s_compress_map_output on device mapId % nGPU.
+//   S3SingleSpillShuffleMapOutputWriter  shuffle/S3SingleSpillShuffleMapOutputWriter.scala:18-64
 //   S3ShuffleReader          storage/S3ShuffleReader.scala:77-158 + S3ShuffleBlockIterator.scala:26-56
 //                            + S3ShuffleBlockStream.scala:36-40,73-93 + S3ChecksumValidationStream
 //                            .scala:54-86 — block (or batch) -> byte range -> verify + decode
@@ -157,6 +158,27 @@ class S3ShuffleMapOutputWriter {
   std::vector<int64_t> srcOffsets_;  // numPartitions + 1
   std::vector<std::vector<int64_t>> cuts_;  // per partition: piece boundaries inside it (absolute staging offsets)
   s3s_ctx* ctx_ = nullptr;
+};
+
+// shuffle/S3SingleSpillShuffleMapOutputWriter.scala:18-64: the map task produced exactly one spill file that
+// already has the final partition order; the reference moves / copies it into the store as the .data object
+// and writes .checksum (iff enabled) and then .index from the arrays Spark hands over.  With the GPU path on,
+// Spark-level compression is off, so the spill holds UNCOMPRESSED partitions: the file is read into
+// page-locked staging, compressed + checksummed on the GPU (offsets = running sum of partitionLengths) and
+// stored; .index / .checksum describe the COMPRESSED object (Spark's own arrays describe the spill and are
+// only used for the offsets).  Like the reference it always writes the index and consumes the spill file.
+class S3SingleSpillShuffleMapOutputWriter {
+ public:
+  S3SingleSpillShuffleMapOutputWriter(const S3ShuffleDispatcher& d, int shuffleId, int64_t mapId)
+      : d_(d), shuffleId_(shuffleId), mapId_(mapId) {}
+  // returns the compressed partition lengths (what .index holds)
+  std::vector<int64_t> transferMapSpillFile(const std::string& mapSpillFile, const std::vector<int64_t>& partitionLengths,
+                                            const std::vector<int64_t>& checksums);
+
+ private:
+  const S3ShuffleDispatcher& d_;
+  int shuffleId_;
+  int64_t mapId_;
 };
 
 struct FetchedBlock {

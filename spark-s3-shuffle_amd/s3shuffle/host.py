@@ -55,6 +55,7 @@ def _lib():
         L.s3sh_writer_num_bytes_written.argtypes = [vp]
         L.s3sh_writer_commit.argtypes = [vp, vp]
         L.s3sh_writer_abort.argtypes = [vp]
+        L.s3sh_single_spill_transfer.argtypes = [vp, ctypes.c_int, ctypes.c_longlong, ctypes.c_char_p, vp, ctypes.c_int, vp]
         L.s3sh_reader_read.restype = vp
         L.s3sh_reader_read.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         L.s3sh_reader_read_sequential.restype = vp
@@ -170,6 +171,17 @@ class MapOutputWriter:
         if self._h:
             _lib().s3sh_writer_destroy(self._h)
             self._h = None
+
+
+def transfer_map_spill_file(dispatcher: Dispatcher, shuffle_id: int, map_id: int, spill_file: str,
+                            partition_lengths) -> np.ndarray:
+    """S3SingleSpillShuffleMapOutputWriter.transferMapSpillFile: the (uncompressed) spill file becomes the
+    map output's .data / .checksum / .index; returns the compressed partition lengths."""
+    pl = np.ascontiguousarray(partition_lengths, dtype=np.int64)
+    out = np.zeros(max(pl.size, 1), np.int64)
+    _check(_lib().s3sh_single_spill_transfer(dispatcher._h, shuffle_id, map_id, spill_file.encode(), pl.ctypes.data,
+                                             pl.size, out.ctypes.data))
+    return out[: pl.size]
 
 
 def consume_prefetched(dispatcher: Dispatcher, shuffle_id: int, start_partition: int, end_partition: int,

@@ -308,3 +308,31 @@ def test_multi_spill_merge_keeps_one_stream_per_piece(gpu_codec, oracle, root):
     assert len(got) == 1 and np.array_equal(got[0][4], np.concatenate(plain))
     d.remove_root()
     d.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("codec", ["lz4", "snappy"])
+def test_single_spill_transfer(gpu_codec, oracle, root, tmp_path, codec):
+    """S3SingleSpillShuffleMapOutputWriter.transferMapSpillFile (:24-64): the spill file becomes the map output;
+    checksum (iff enabled) and index are always written; the spill file is consumed; objects match the oracle."""
+    from s3shuffle import datagen, host
+
+    d = host.Dispatcher(root, codec=codec)
+    data, offs = datagen.tpcds_wide_map_output(3 << 20, 11, seed=4)
+    spill = tmp_path / "spill_0.tmp"
+    spill.write_bytes(data.tobytes())
+    lengths = host.transfer_map_spill_file(d, 0, 6, str(spill), np.diff(offs))
+    assert not spill.exists()
+    img, index, sums = oracle.compress_map_output(1 if codec == "lz4" else 2, 1, data, offs)
+    assert np.array_equal(lengths, np.diff(index))
+    assert open(d.get_path(host.KIND_DATA, 0, 6), "rb").read() == img.tobytes()
+    assert open(d.get_path(host.KIND_INDEX, 0, 6), "rb").read() == oracle.longs_to_be(index)
+    assert open(d.get_path(host.KIND_CHECKSUM, 0, 6), "rb").read() == oracle.longs_to_be(sums)
+    got = host.read_shuffle(d, 0, 3, 8, True)
+    assert len(got) == 1 and np.array_equal(got[0][4], data[offs[3]:offs[8]])
+    bad = tmp_path / "spill_1.tmp"
+    bad.write_bytes(data.tobytes()[:-5])
+    with pytest.raises(host.IOException, match="does not match partitionLengths"):
+        host.transfer_map_spill_file(d, 0, 7, str(bad), np.diff(offs))
+    d.remove_root()
+    d.close()
