@@ -34,6 +34,10 @@ for p in (ROOT, os.path.join(ROOT, "spark-s3-shuffle_amd")):
 
 import numpy as np  # noqa: E402
 
+# executor environment of the GPU path: one hardware queue per task-thread stream instead of
+# the HIP default of 4 shared ones; read by libamdhip64 when it is loaded, i.e. before `import torch`
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
 HBM_COPY_CEILING_GBPS = 6290.0  # measured float4-copy ceiling, same guide
 
