@@ -336,3 +336,44 @@ def test_single_spill_transfer(gpu_codec, oracle, root, tmp_path, codec):
         host.transfer_map_spill_file(d, 0, 7, str(bad), np.diff(offs))
     d.remove_root()
     d.close()
+
+
+@pytest.mark.gpu
+def test_fold_by_key_zero_buffering(gpu_codec, root):
+    """S3ShuffleManagerTest 'foldByKey_zeroBuffering' (no bytes in flight): the prefetch budgets are one byte, so
+    every block is larger than the whole budget and runs alone through one fetch thread and one decode context."""
+    from s3shuffle import host
+
+    rng = np.random.default_rng(2)
+    maps = [(rng.integers(0, 1000, 30_000), rng.integers(0, 100, 30_000)) for _ in range(3)]
+    d = host.Dispatcher(root)
+    d.set_prefetch(1, 1, 1, 1)
+    d.close()
+    res, d = _run_job(root, maps, 4, {}, lambda k: k % 4, batch_fetch=False)
+    d.set_prefetch(1, 1, 1, 1)
+    got = np.zeros(1000, np.int64)
+    for p in range(4):
+        for b in host.read_shuffle(d, 0, p, p + 1, False):
+            kv = _unvarints(b[4])
+            np.add.at(got, kv[0::2], kv[1::2])
+    want = np.zeros(1000, np.int64)
+    for k, v in maps:
+        np.add.at(want, k, v)
+    assert np.array_equal(got, want)
+    d.remove_root()
+    d.close()
+
+
+@pytest.mark.gpu
+def test_force_sort_shuffle(gpu_codec, root):
+    """'forceSortShuffle': 3 maps x 10 000 (t, random) pairs range-partitioned on the value and sorted per
+    reduce partition give a globally non-decreasing sequence."""
+    rng = np.random.default_rng(8)
+    n = 10_000
+    maps = [(rng.integers(0, n, n), np.arange(m * n, (m + 1) * n)) for m in range(3)]  # key = the sort value
+    bounds = np.array([n // 3, 2 * n // 3])
+    res, d = _run_job(root, maps, 3, {}, lambda k: np.searchsorted(bounds, k, side="right"), batch_fetch=True)
+    merged = np.concatenate([np.sort(res[p][0]) for p in range(3)])
+    assert merged.size == 3 * n and (np.diff(merged) >= 0).all()
+    d.remove_root()
+    d.close()
