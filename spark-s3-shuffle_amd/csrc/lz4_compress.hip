@@ -217,6 +217,10 @@ __device__ __forceinline__ int extend_match(const Src& in, int ip0, int match0, 
 
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 
+#ifndef S3S_FAST_STEPS
+#define S3S_FAST_STEPS 5  // measured: 3 -> 45.3, 5 -> 45.4 GB/s (TeraSort, two task threads), 21.2 vs 20.6 on wide rows
+#endif
+
 // The parse.  Returns the compressed size, or -1 if it would exceed len.
 //
 // kFast adds the "exact window" path in front of the general batch (DESIGN.md §6,
@@ -266,6 +270,8 @@ __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t*
     const int pipe_limit = len - 448;  // pipelined windows prefetch up to 323 bytes ahead
     int kn = -1;         // first position of the window whose v is held in vn
     uint32_t vn = 0;
+    int kp = -2;         // first position of the window whose v is held in vp (kMode 1)
+    uint32_t vp = 0;
     bool force_general = false;
     for (;;) {
       if constexpr (kMode == 2) {
@@ -786,6 +792,7 @@ __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t*
           DBG_ADD(8, 1);
           const int p = wbase + lane;
           const uint32_t v = (kn == wbase) ? vn : in.rd32(p);
+          const bool vp_ok = kp == wbase - 64;  // vp holds the previous window's dwords (literals may start there)
           vn = in.rd32(p + 64);
           kn = wbase + 64;
           const uint32_t h = hash13(v);
@@ -813,7 +820,7 @@ __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t*
           // per-lane event record: [15:0] table candidate, [22:16] forward length 0..64,
           // [27:24] backward equal bytes 0..8 (8 = at least, 9 = unknown), [31] suspect lane (member of
           // a duplicate-hash group)
-          uint32_t info = grp ? 0x80000000u : 0u;
+          uint32_t info = grp ? 0x80000000u : 0u, info2 = 0u;
           if (em) {
             const int pa = p + kMinMatch, pb = (int)cp + kMinMatch;
             const uint4 a0 = in.ld16(pa), b0 = in.ld16(pb);
@@ -835,6 +842,9 @@ __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t*
               }
             }
             info = cp | ((uint32_t)fl << 16) | (be << 24) | (grp ? 0x80000000u : 0u);
+            // for the straight-line steps: backward bytes to take (0..8) and the longest literal run for which
+            // that count is exact (be < 8: any; be == 8: 8; unknown: 0)
+            info2 = (be <= 8u ? be : 0u) | ((be < 8u ? 0x7fffu : (be == 8u ? 8u : 0u)) << 4);
           }
           // vn (issued before every load above) has landed by now: pin it here, before the emit stores,
           // so that no later use has to drain the in-order vmcnt queue behind those stores
@@ -853,7 +863,77 @@ __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t*
           const int e0 = rs0 + 66 - t0;  // t0 <= 48  =>  e0 >= rs0 + 18
           int elim = e0 < kWave ? e0 : kWave;
           uint64_t runmask = e0 < kWave ? ((1ull << e0) - 1ull) : ~0ull;
-          for (;;) {
+          // ---- straight-line steps: up to three "plain" sequences (the first event of the run has its true candidate
+          // in the table, exact lengths, short-form encoding, literals in the registers of this or the previous
+          // window, not the end of the chunk) without the generic loop's control flow: ONE branch decides,
+          // everything else is arithmetic.  Anything else falls through to the generic loop below, which
+          // continues from whatever state the steps left.
+          constexpr int kFastSteps = S3S_FAST_STEPS;
+          bool left_window = false;
+          const int lit_floor = vp_ok ? wbase - 64 : wbase;  // literals must start at or after this position
+#pragma unroll
+          for (int step = 0; step < kFastSteps; step++) {
+            const uint64_t live_m = runmask & (~0ull << rs);
+            const uint64_t cm = ED & live_m;
+            if (cm == 0ull) break;  // no event left for this run: the generic loop's exit code handles it
+            const int m = __builtin_ctzll(cm);
+            const uint64_t bit = 1ull << m;
+            const uint32_t inf = __builtin_amdgcn_readlane(info, m);
+            const uint32_t inf2 = __builtin_amdgcn_readlane(info2, m);
+            // a duplicate-hash lane is plain iff no earlier kept lane of the window shares its hash
+            const uint32_t hv = __builtin_amdgcn_readlane(h, m);
+            const uint64_t dk = __ballot(h == hv) & (bit - 1ull) & (K | live_m);
+            const int ip0 = wbase + m;
+            const int mpos = (int)(inf & 0xffffu), fwd = (int)((inf >> 16) & 0x7fu);
+            const int nbmax = ip0 - anchor;
+            const int nbv = (int)(inf2 & 0xfu);
+            const int nb = nbv < nbmax ? nbv : nbmax;
+            const int lit = nbmax - nb, mcode = nb + fwd;
+            const int total = 3 + lit + (mcode >= 15 ? 1 : 0);
+            const int ipe = ip0 + kMinMatch + fwd;
+            // largest of the "how far beyond its limit" terms: <= 0 iff every condition holds
+            int over = fwd - 63;                                       // forward length capped
+            over = over > nbmax - (int)(inf2 >> 4) ? over : nbmax - (int)(inf2 >> 4);  // backward count not exact
+            over = over > lit_floor - anchor ? over : lit_floor - anchor;  // literals older than the registers
+            over = over > lit - 14 ? over : lit - 14;                  // literal length needs extra bytes
+            over = over > mcode - 269 ? over : mcode - 269;            // more than one match-length byte
+            over = over > ipe - mfl1 + 1 ? over : ipe - mfl1 + 1;      // end of the chunk
+            over = over > op + total - len ? over : op + total - len;  // would not fit: the frame is stored RAW
+            if ((Ecp & bit) == 0ull || dk != 0ull || over > 0) break;
+            DBG_ADD(9, 1);
+            K |= live_m & ((bit << 1) - 1ull);
+            {
+              const int offset = ip0 - mpos;
+              const int rel = (lane - anchor) & 63;
+              uint32_t bv = ((anchor + rel < wbase) ? vp : v) & 0xffu;
+              int idx = rel < lit ? 1 + rel : rel;
+              if (rel == lit) {
+                bv = (uint32_t)(lit << 4) | (uint32_t)(mcode < 15 ? mcode : 15);
+                idx = 0;
+              }
+              if (rel == lit + 1) bv = (uint32_t)offset;
+              if (rel == lit + 2) bv = (uint32_t)offset >> 8;
+              if (rel == lit + 3) bv = (uint32_t)(mcode - 15);
+              if (rel < total) out[op + idx] = (uint8_t)bv;
+            }
+            op += total;
+            anchor = ipe;
+            const int q = ipe - 2 - wbase;  // LZ4_putPosition(ip - 2)
+            K |= q < kWave ? (1ull << (q & 63)) : 0ull;
+            pend_q = q < kWave ? pend_q : q + wbase;
+            rs = ipe - wbase;  // (>= 64 when the match leaves the window: not used then)
+            rt = 0;
+            elim = kWave;
+            runmask = ~0ull;
+            if (ipe >= wbase + kWave) {
+              base = ipe;
+              t0 = 0;
+              left_window = true;
+              break;
+            }
+          }
+          exit_kind = 0;
+          if (!left_window) for (;;) {
             const uint64_t cm = ED & runmask & (~0ull << rs);
             if (cm == 0ull) {  // the run leaves the window (or its consecutive part) without a match
               K |= runmask & (~0ull << rs);
@@ -962,6 +1042,8 @@ __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t*
                                     : in.rd32(pend_q);
             T[hash13(vq)] = (uint16_t)pend_q;
           }
+          vp = v;
+          kp = wbase;
           force_general = exit_kind == 2;
           DBG_T(tw5);
           DBG_ADD(5, tw5 - tw4);
