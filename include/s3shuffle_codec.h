@@ -95,8 +95,9 @@ enum {
   S3S_OPT_LZ4_VARIANT = 4,       /* tuning, identical output: 0 = chunk staged in LDS (3 wavefronts per CU),
                                     1 = chunk read through L1/L2, table-only LDS (10 per CU), general batch
                                     only, 2 (default) = 1 + exact-window parse in front of the batch
-                                    (several sequences per memory round trip: 1.5x on match-dense rows,
-                                    0.92x on TeraSort records single-stream, 0.98x with two task threads),
+                                    (several sequences per memory round trip, plain sequences in straight-line
+                                    steps: 1.6x on match-dense rows, 0.97x on TeraSort records single-stream,
+                                    1.02x with two task threads),
                                     3 = 2 software-pipelined, 4 = 3 with the run loop on the vector ALU,
                                     5 = 1 with the frame check fused in, 6 / 7 = 1 at 5 / 7 wavefronts per
                                     CU (occupancy experiments), 9 = auto: the context times 1 and 2 on its
