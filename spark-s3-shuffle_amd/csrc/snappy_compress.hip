@@ -276,7 +276,63 @@ __device__ int snappy_compress_wave(const uint8_t* in, lds_u16* table, int len, 
           const uint64_t PM = 0xAAAAAAAA00000000ull | ((1ull << 34) - 1ull);  // d: 0..33, 35, 37, .., 63
           uint64_t K = 0;  // lanes the sequential code inserts: probes, and ip-1 after every copy
           int rt = u0, pend_q = -1;
-          for (;;) {
+          // ---- straight-line steps: up to six "plain" copies (the run's first event has its true candidate in the
+          // table with an exact length, one literal tag + one copy element, literals in the registers of this or the
+          // previous window, not the end of the fragment) without the generic loop's control flow: one branch
+          // decides, everything else is arithmetic.  Anything else falls through to the generic loop, which continues
+          // from whatever state the steps left (lz4_compress.hip does the same).
+          bool left_window = false;
+#pragma unroll
+          for (int step = 0; step < 6; step++) {
+            const uint64_t cm = ED & runmask;
+            if (cm == 0ull) break;
+            const int m = __builtin_ctzll(cm);
+            const uint64_t bit = 1ull << m;
+            const uint32_t inf = __builtin_amdgcn_readlane(info, m);
+            const uint32_t hv = __builtin_amdgcn_readlane(h, m);
+            const uint64_t dk = __ballot(h == hv) & (bit - 1ull) & (K | runmask);  // earlier kept lanes, same hash
+            const int ip0 = wbase + m;
+            const int cand = (int)(inf & 0xffffu), extra = (int)((inf >> 16) & 0x7fu);
+            const int lit = ip0 - next_emit, offset = ip0 - cand, matched = 4 + extra;
+            const int ipe = ip0 + matched;
+            int over = extra - 60;                                         // capped, or more than one copy element
+            over = over > lit - 60 ? over : lit - 60;                      // literal tag needs length bytes
+            over = over > wbase - 64 - next_emit ? over : wbase - 64 - next_emit;  // literals older than the registers
+            over = over > ipe - ip_limit + 1 ? over : ipe - ip_limit + 1;  // end of the fragment
+            if ((inf & 0x20000000u) == 0u || dk != 0ull || over > 0) break;
+            K |= runmask & ((bit << 1) - 1ull);
+            {
+              const bool two = matched < 12 && offset < 2048;
+              const int hdr = lit > 0 ? 1 : 0;
+              const int total = hdr + lit + (two ? 2 : 3);
+              const uint32_t c0 = two ? (uint32_t)(1 + ((matched - 4) << 2) + ((offset >> 8) << 5))
+                                      : (uint32_t)(2 + ((matched - 1) << 2));
+              const int rel = (lane - next_emit) & 63;
+              const int k = rel - lit;  // 0: literal tag (if any), then the copy bytes
+              const int j = k - hdr;
+              uint32_t bv = ((next_emit + rel < wbase) ? vp : v) & 0xffu;
+              int idx = 1 + rel;
+              if (k >= 0) {
+                idx = (k == 0) ? 0 : lit + k;
+                bv = (j < 0) ? (uint32_t)((lit - 1) << 2) : (j == 0 ? c0 : (j == 1 ? (uint32_t)offset : (uint32_t)offset >> 8));
+              }
+              if (rel < total) out[op + idx] = (uint8_t)bv;
+              op += total;
+            }
+            next_emit = ipe;
+            const int q = ipe - 1 - wbase;  // table[Hash(ip - 1)] = ip - 1
+            K |= q < kWave ? (1ull << (q & 63)) : 0ull;
+            pend_q = q < kWave ? pend_q : ipe - 1;
+            rbase = ipe;
+            u0 = 0;
+            rt = 0;
+            if (ipe >= wbase + kWave) {
+              left_window = true;
+              break;
+            }
+            runmask = PM << (ipe - wbase);
+          }
+          if (!left_window) for (;;) {
             const uint64_t cm = ED & runmask;
             if (cm == 0ull) {  // the run leaves the window without a match
               K |= runmask;
