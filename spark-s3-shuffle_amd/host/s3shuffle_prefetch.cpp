@@ -18,6 +18,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -410,3 +411,73 @@ S3BufferedPrefetchIterator::Stats S3BufferedPrefetchIterator::stats() const {
 }
 
 }  // namespace s3shuffle
+
+// ---- self-test of the staging pool (tests/test_host_mirror.py; runs on a CPU-only box too, where staging is
+// plain memory) ------------------------------------------------------------------------------------------------
+extern "C" int s3sh_pool_selftest() {
+  using namespace s3shuffle;
+  try {
+    // 1. budget accounting, reuse, high-water mark
+    {
+      PinnedPool pool(8 << 20);
+      uint8_t* a = pool.acquire(3 << 20);  // rounds to 4 MiB
+      uint8_t* b = pool.acquire(1 << 20);
+      if (!a || !b || pool.inUse() != (5 << 20)) return 1;
+      memset(a, 0xAB, 3 << 20);
+      pool.release(a);
+      uint8_t* c = pool.acquire(4 << 20);  // the released buffer comes back
+      if (pool.inUse() != (5 << 20) || pool.highWater() != (5 << 20)) return 2;
+      pool.release(b);
+      pool.release(c);
+      pool.release(c);  // double release is ignored
+      if (pool.inUse() != 0) return 3;
+    }
+    // 2. a waiter is released when memory comes back; a request larger than the budget runs alone
+    {
+      PinnedPool pool(2 << 20);
+      uint8_t* a = pool.acquire(2 << 20);
+      std::atomic<int> stage{0};
+      std::thread t([&] {
+        uint8_t* big = pool.acquire(16 << 20);  // > budget: waits until nothing else is in use
+        stage = 1;
+        pool.release(big);
+      });
+      std::this_thread::sleep_for(std::chrono::milliseconds(50));
+      if (stage != 0) return 4;  // must still be waiting
+      pool.release(a);
+      t.join();
+      if (stage != 1 || pool.inUse() != 0) return 5;
+    }
+    // 3. cancel wakes a waiter with an exception
+    {
+      PinnedPool pool(1 << 20);
+      uint8_t* a = pool.acquire(1 << 20);
+      std::atomic<int> threw{0};
+      std::thread t([&] {
+        try {
+          pool.acquire(1 << 20);
+        } catch (const IOException&) {
+          threw = 1;
+        }
+      });
+      std::this_thread::sleep_for(std::chrono::milliseconds(50));
+      pool.cancel();
+      t.join();
+      pool.release(a);
+      if (!threw) return 6;
+    }
+    // 4. the non-blocking process pool never waits
+    {
+      PinnedPool pool(1 << 20, /*blocking=*/false);
+      uint8_t* a = pool.acquire(4 << 20);
+      uint8_t* b = pool.acquire(4 << 20);
+      if (!a || !b) return 7;
+      pool.release(a);
+      pool.release(b);
+    }
+    releasePinnedCache();
+    return 0;
+  } catch (const std::exception&) {
+    return 100;
+  }
+}

@@ -60,6 +60,19 @@ def test_paths_and_index_format(codec_lib, root, tmp_path):
     d.close()
 
 
+def test_staging_pool_selftest(codec_lib):
+    """PinnedPool (host/s3shuffle_prefetch.cpp): budget accounting and reuse, a waiter released by a release, a
+    request larger than the budget running alone, cancel(), the non-blocking process pool.  On a CPU-only box the
+    pool hands out plain memory, so the logic is covered without a GPU."""
+    import ctypes
+
+    from s3shuffle import host
+
+    L = host._lib()
+    L.s3sh_pool_selftest.restype = ctypes.c_int
+    assert L.s3sh_pool_selftest() == 0
+
+
 def test_writer_preconditions(codec_lib, root):
     from s3shuffle import host
 
