@@ -68,6 +68,8 @@ def lib() -> ctypes.CDLL:
     L.s3o_mt_have_liblz4.restype = i32
     L.s3o_mt_compress_bench.restype = ctypes.c_double
     L.s3o_mt_compress_bench.argtypes = [i32, i32, i32, i32, vp, vp, ctypes.c_int32, i32, i32, vp]
+    L.s3o_mt_decompress_bench.restype = ctypes.c_double
+    L.s3o_mt_decompress_bench.argtypes = [i32, i32, i32, vp, i64, vp, vp, ctypes.c_int32, i64, i32, i32, vp]
     L.s3o_mt_stream_liblz4.restype = i64
     L.s3o_mt_stream_liblz4.argtypes = [vp, i64, i32, vp]
     _LIB = L
@@ -183,3 +185,16 @@ def mt_compress_bench(codec: int, checksum_algo: int, data, offsets, nthreads: i
     s = lib().s3o_mt_compress_bench(codec, checksum_algo, block_size, int(use_liblz4), d.ctypes.data,
                                     offs.ctypes.data, len(offs) - 1, nthreads, reps, ctypes.byref(total))
     return float(s), int(total.value)
+
+
+def mt_decompress_bench(codec: int, checksum_algo: int, comp, part_offsets, ref_checksums, decoded_size: int,
+                        nthreads: int, reps: int = 1, use_liblz4: bool = True) -> Tuple[float, int]:
+    """cpu_baseline (reduce side): `nthreads` tasks verify + decode the same fetched range. -> (seconds, bytes)"""
+    c = _u8(comp)
+    offs = _i64(part_offsets)
+    sums = _i64(ref_checksums) if ref_checksums is not None else None
+    out_len = ctypes.c_int64(0)
+    s = lib().s3o_mt_decompress_bench(codec, checksum_algo, int(use_liblz4), c.ctypes.data, c.size, offs.ctypes.data,
+                                      sums.ctypes.data if sums is not None else None, len(offs) - 1, int(decoded_size),
+                                      nthreads, reps, ctypes.byref(out_len))
+    return float(s), int(out_len.value)

@@ -146,3 +146,102 @@ int64_t s3o_mt_stream_liblz4(const uint8_t* src, int64_t ulen, int block_size, u
   if (!s3o_mt_have_liblz4()) return S3O_E_UNSUPPORTED;
   return stream_liblz4(src, ulen, block_size, dst);
 }
+
+/* ---- reduce side: verify + decompress, one fetched block range per thread ------------------------------- */
+typedef int (*lz4d_fn)(const char*, char*, int, int);
+static lz4d_fn g_lz4d = NULL;
+
+static int have_liblz4_decoder(void) {
+  if (g_lz4d) return 1;
+  void* h = dlopen("liblz4.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return 0;
+  g_lz4d = (lz4d_fn)dlsym(h, "LZ4_decompress_safe");
+  return g_lz4d != NULL;
+}
+
+/* LZ4BlockInputStream over concatenated streams with liblz4's decoder (what lz4-java's JNI instance calls) */
+static int64_t decode_liblz4(const uint8_t* c, int64_t n, uint8_t* dst, int64_t cap) {
+  int64_t ip = 0, op = 0;
+  while (ip < n) {
+    if (n - ip < 21 || memcmp(c + ip, "LZ4Block", 8) != 0) return S3O_E_BAD_FRAME;
+    const int token = c[ip + 8];
+    uint32_t clen = 0, olen = 0, check = 0;
+    for (int i = 0; i < 4; i++) {
+      clen |= (uint32_t)c[ip + 9 + i] << (8 * i);
+      olen |= (uint32_t)c[ip + 13 + i] << (8 * i);
+      check |= (uint32_t)c[ip + 17 + i] << (8 * i);
+    }
+    ip += 21;
+    if (olen == 0) continue; /* end frame of one stream: the next stream follows */
+    if (ip + clen > n || op + olen > cap) return S3O_E_BAD_FRAME;
+    if ((token & 0xF0) == 0x10) {
+      memcpy(dst + op, c + ip, olen);
+    } else if (g_lz4d((const char*)c + ip, (char*)dst + op, (int)clen, (int)olen) != (int)olen) {
+      return S3O_E_BAD_FRAME;
+    }
+    if ((s3o_xxh32(dst + op, olen, 0x9747b28cu) & 0x0FFFFFFFu) != check) return S3O_E_BAD_FRAME;
+    ip += clen;
+    op += olen;
+  }
+  return op;
+}
+
+typedef struct {
+  int codec, checksum, use_liblz4, reps, rc;
+  const uint8_t* comp;
+  int64_t comp_len;
+  const int64_t* offs;
+  const int64_t* sums;
+  int32_t nparts;
+  uint8_t* dst;
+  int64_t cap, out_len;
+} dtask_t;
+
+static void* run_dtask(void* arg) {
+  dtask_t* t = (dtask_t*)arg;
+  for (int r = 0; r < t->reps; r++) {
+    if (t->use_liblz4 && t->codec == S3O_CODEC_LZ4) {
+      t->rc = 0;
+      for (int32_t p = 0; p < t->nparts && t->checksum != S3O_CHECKSUM_NONE; p++) /* S3ChecksumValidationStream */
+        if (s3o_checksum(t->checksum, t->comp + t->offs[p], (size_t)(t->offs[p + 1] - t->offs[p])) != t->sums[p])
+          t->rc = S3O_E_CHECKSUM;
+      t->out_len = decode_liblz4(t->comp, t->comp_len, t->dst, t->cap);
+      if (t->out_len < 0) t->rc = (int)t->out_len;
+    } else {
+      int32_t bad = -1;
+      t->rc = s3o_decompress_range(t->codec, t->checksum, t->comp, t->comp_len, t->offs, t->sums, t->nparts, t->dst,
+                                   t->cap, &t->out_len, &bad);
+    }
+  }
+  return NULL;
+}
+
+/* `nthreads` reduce tasks in parallel, each verifying + decoding the same fetched range `reps` times into a
+ * private buffer; returns wall seconds (< 0 on error), *out_len = decoded bytes of one task. */
+double s3o_mt_decompress_bench(int codec, int checksum, int use_liblz4, const uint8_t* comp, int64_t comp_len,
+                               const int64_t* part_offsets, const int64_t* ref_checksums, int32_t nparts,
+                               int64_t dst_capacity, int nthreads, int reps, int64_t* out_len) {
+  if (use_liblz4 && !have_liblz4_decoder()) use_liblz4 = 0;
+  dtask_t* ts = (dtask_t*)calloc((size_t)nthreads, sizeof(dtask_t));
+  pthread_t* th = (pthread_t*)calloc((size_t)nthreads, sizeof(pthread_t));
+  for (int i = 0; i < nthreads; i++) {
+    ts[i] = (dtask_t){codec, checksum, use_liblz4, reps, 0, comp, comp_len, part_offsets, ref_checksums, nparts,
+                      (uint8_t*)malloc((size_t)dst_capacity + 64), dst_capacity, 0};
+    memset(ts[i].dst, 0, (size_t)dst_capacity);
+  }
+  struct timespec a, b;
+  clock_gettime(CLOCK_MONOTONIC, &a);
+  for (int i = 0; i < nthreads; i++) pthread_create(&th[i], NULL, run_dtask, &ts[i]);
+  for (int i = 0; i < nthreads; i++) pthread_join(th[i], NULL);
+  clock_gettime(CLOCK_MONOTONIC, &b);
+  if (out_len) *out_len = ts[0].out_len;
+  int rc = 0;
+  for (int i = 0; i < nthreads; i++) {
+    rc |= ts[i].rc;
+    free(ts[i].dst);
+  }
+  free(ts);
+  free(th);
+  const double s = (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
+  return rc ? -1.0 : s;
+}

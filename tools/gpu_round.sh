@@ -13,7 +13,7 @@ timeout 300 python bench.py --no-cpu-baseline --task-threads 2 > $O/bench_t2.jso
 timeout 300 python bench.py --no-cpu-baseline --workload terasort-100g-2000p-lz4-crc32 > $O/bench_2000p.json 2>> $O/bench.err
 timeout 300 python bench.py --no-cpu-baseline --workload skew-1part-lz4 --map-mib 1024 --maps-per-gpu 1 > $O/bench_skew1g.json 2>> $O/bench.err
 timeout 300 python bench.py --no-cpu-baseline --workload skew-1part-lz4 --map-mib 1024 --maps-per-gpu 1 --direction decompress > $O/bench_skew1g_decompress.json 2>> $O/bench.err
-timeout 300 python bench.py --no-cpu-baseline --direction decompress > $O/bench_decompress.json 2>> $O/bench.err
+timeout 400 python bench.py --direction decompress > $O/bench_decompress.json 2>> $O/bench.err
 timeout 600 python bench.py --workload tpcds-wide-100g-200p-snappy --verify > $O/bench_snappy.json 2>> $O/bench.err
 timeout 300 python bench.py --no-cpu-baseline --workload tpcds-wide-100g-200p-snappy --direction decompress > $O/bench_snappy_decompress.json 2>> $O/bench.err
 timeout 600 python bench.py --workload tpcds-wide-100g-200p-lz4 --verify > $O/bench_tpcds_lz4.json 2>> $O/bench.err
