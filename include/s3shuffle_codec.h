@@ -66,7 +66,7 @@
 extern "C" {
 #endif
 
-#define S3S_ABI_VERSION 1
+#define S3S_ABI_VERSION 2 /* 2: + segments entry points, page-locked staging, tuning options 6, 7 */
 
 /* spark.io.compression.codec (only when spark.shuffle.compress=true) */
 enum { S3S_CODEC_NONE = 0, S3S_CODEC_LZ4 = 1, S3S_CODEC_SNAPPY = 2 };
