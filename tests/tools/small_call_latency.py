@@ -1,8 +1,8 @@
 """Latency of one host-buffer call as a function of the map output size (the break-even a shim needs
 for `spark.shuffle.s3.gpu.minBytes`): GPU call vs the oracle's single-thread liblz4-equivalent on the
-same bytes.  usage: python tools/small_call_latency.py"""
+same bytes.  usage: python tests/tools/small_call_latency.py"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "spark-s3-shuffle_amd")); sys.path.insert(0, ROOT)
 import numpy as np
 import s3shuffle
