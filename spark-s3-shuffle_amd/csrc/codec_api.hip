@@ -120,7 +120,7 @@ int s3s_set_option(s3s_ctx* ctx, int key, int64_t value) {
       ctx->snappy_variant = (int)value;
       return S3S_OK;
     case S3S_OPT_LZ4_VARIANT:
-      if (value < 0 || value > 9 || value == 8) return fail(ctx, S3S_E_INVALID, "lz4 variant must be 0..7 or 9 (auto)");
+      if (value < 0 || value > 10 || value == 8) return fail(ctx, S3S_E_INVALID, "lz4 variant must be 0..7, 9 (auto) or 10");
       ctx->lz4_variant = (int)value;
       ctx->auto_samples[0] = ctx->auto_samples[1] = 0;
       ctx->auto_tick = 0;

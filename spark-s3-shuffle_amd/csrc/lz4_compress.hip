@@ -69,20 +69,21 @@ struct SrcLds {  // chunk staged in LDS
 struct SrcGlobal {  // chunk read in place (L1/L2)
   static constexpr bool kClamp = true;  // never read past the chunk: it may end the allocation
   const uint8_t* base;
+  // positions are never negative: the unsigned index lets hipcc address with saddr + 32-bit voffset
   __device__ __forceinline__ uint32_t rd32(int pos) const {
     uint32_t v;
-    __builtin_memcpy(&v, base + pos, 4);  // unaligned global_load_dword
+    __builtin_memcpy(&v, base + (uint32_t)pos, 4);  // unaligned global_load_dword
     return v;
   }
-  __device__ __forceinline__ uint32_t rd8(int pos) const { return base[pos]; }
+  __device__ __forceinline__ uint32_t rd8(int pos) const { return base[(uint32_t)pos]; }
   __device__ __forceinline__ uint4 ld16(int pos) const {
     uint4 x;
-    __builtin_memcpy(&x, base + pos, 16);  // unaligned global_load_dwordx4
+    __builtin_memcpy(&x, base + (uint32_t)pos, 16);  // unaligned global_load_dwordx4
     return x;
   }
   __device__ __forceinline__ uint2 ld8(int pos) const {
     uint2 x;
-    __builtin_memcpy(&x, base + pos, 8);
+    __builtin_memcpy(&x, base + (uint32_t)pos, 8);
     return x;
   }
 };
@@ -246,13 +247,13 @@ __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t*
   const int last4 = len - 4;
   int anchor = 0, op = 0;
 #ifdef S3S_LZ4_TIMING
-  unsigned long long dbg[16] = {0};
+  unsigned long long dbg[20] = {0};
   struct DbgFlush {
     unsigned long long* d;
     int lane;
     __device__ ~DbgFlush() {
       if (lane == 0)
-        for (int i = 0; i < 16; i++) atomicAdd(&g_lz4_dbg[i], d[i]);
+        for (int i = 0; i < 20; i++) atomicAdd(&g_lz4_dbg[i], d[i]);
     }
   } dbg_flush{dbg, lane};
 #endif
@@ -272,6 +273,8 @@ __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t*
     uint32_t vn = 0;
     int kp = -2;         // first position of the window whose v is held in vp (kMode 1)
     uint32_t vp = 0;
+    int pk = -1000;      // first position of the window whose stream bytes are held in pw0 (kMode 4)
+    uint4 pw0 = make_uint4(0, 0, 0, 0), pw1 = pw0, pw2 = pw0;
     bool force_general = false;
     for (;;) {
       if constexpr (kMode == 2) {
@@ -777,6 +780,273 @@ __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t*
           if (exit_kind == 1) break;
           if (pend_far >= 0) T[hash13(in.rd32(pend_far))] = (uint16_t)pend_far;  // LZ4_putPosition(ip - 2)
           force_general = exit_kind == 2;
+          continue;
+        }
+        force_general = false;
+      }
+      if constexpr (kMode == 4) {
+        // ===== lean exact windows (variant 10) =====================================================================
+        // Same resolution rules as kMode 1 (runs resolved with scalar mask arithmetic over K / ED), but the
+        // window is prepared with ONE memory round trip instead of three:
+        //   * every lane keeps the 16 bytes p-4 .. p+11 of its position for this window and the next two
+        //     (linear, issued two windows ahead: never waited for in steady state);
+        //   * after the table read each lane gathers the 16 bytes cp-4 .. cp+11 around its candidate; that one
+        //     load decides "candidate matches", the forward length up to 8 bytes beyond MINMATCH and the
+        //     backward count up to 4 — enough for the short matches of serialized rows; anything longer goes
+        //     to the cooperative extension (one more round trip per LONG sequence only);
+        //   * the duplicate-hash passes over the table run while that gather is in flight.
+        const int wbase = base & ~63;
+        if (!force_general && t0 <= 48 && wbase >= 64 && wbase <= fast_limit) {
+          if (put_pending) T[hash13(vput)] = (uint16_t)(base - 2);  // LZ4_putPosition(ip - 2)
+          put_pending = false;
+          have_pre = false;
+          DBG_T(t4a);
+          DBG_ADD(8, 1);
+          const int p = wbase + lane;
+          if (pk != wbase) {
+            if (pk + 64 == wbase) {
+              vp = pw0.y;
+              kp = pk;
+              pw0 = pw1;
+              pw1 = pw2;
+              pw2 = in.ld16(p + 124);
+            } else if (pk + 128 == wbase) {
+              vp = pw1.y;
+              kp = pk + 64;
+              pw0 = pw2;
+              pw1 = in.ld16(p + 60);
+              pw2 = in.ld16(p + 124);
+            } else {
+              pw0 = in.ld16(p - 4);
+              pw1 = in.ld16(p + 60);
+              pw2 = in.ld16(p + 124);
+            }
+            pk = wbase;
+          }
+          const bool vp_ok = kp == wbase - 64;  // vp holds the previous window's dwords (literals may start there)
+          const uint32_t v = pw0.y;
+          const uint32_t h = hash13(v);
+          const int rs0 = base - wbase;
+          const bool live = lane >= rs0;
+          const uint32_t cp = T[h];
+#ifdef S3S_LZ4_TIMING
+          asm volatile("" ::"v"(cp));
+#endif
+          DBG_T(t4b);
+          const bool near0 = cp < 4u;  // (also every empty slot: it reads as position 0)
+          const uint4 G = in.ld16(near0 ? 0 : (int)cp - 4);
+#ifdef S3S_G2_PREFETCH
+          // touch the candidate's next cache line too: a long match's cooperative extension then hits L1/L2
+          const int g2p = (int)cp + 64 + 60;
+          const uint32_t g2 = in.rd32(g2p < last4 ? g2p : last4);
+#endif
+          // duplicate-hash groups among the live lanes (two speculative store passes, rolled back) — while G flies
+          bool grp = false;
+          if (live) {
+            T[h] = (uint16_t)p;
+            const uint32_t r1 = T[h];
+            const bool lost1 = r1 != (uint32_t)p;
+            if (lost1) T[h] = (uint16_t)p;
+            const uint32_t r2 = T[h];
+            grp = lost1 || (r2 != (uint32_t)p);
+            if (r2 == (uint32_t)p) T[h] = (uint16_t)cp;  // the slot's current owner restores it
+          }
+#ifdef S3S_LZ4_TIMING
+          asm volatile("" ::"v"(grp));
+#endif
+          DBG_T(t4c0);
+#ifdef S3S_LZ4_TIMING
+          asm volatile("" ::"v"(G.x));
+#endif
+          DBG_T(t4c);
+          const uint32_t w = near0 ? __builtin_amdgcn_alignbyte(G.y, G.x, cp) : G.y;
+#ifdef S3S_G2_PREFETCH
+          asm volatile("" ::"v"(g2));
+#endif
+          const bool em = live && (w == v);
+          // per-lane event record: [15:0] table candidate, [19:16] forward length 0..8 (8 = at least),
+          // [22:20] backward equal bytes 0..4 (4 = at least), [30] candidate matches, [31] suspect lane
+          uint32_t info = grp ? 0x80000000u : 0u;
+          if (em) {
+            uint32_t fl = 8u, be = 0u;  // near0: lengths by the cooperative extension
+            if (!near0) {
+              const uint32_t xz = G.z ^ pw0.z, xw = G.w ^ pw0.w, xb = G.x ^ pw0.x;
+              fl = xz ? (uint32_t)(__builtin_ctz(xz) >> 3) : (xw ? 4u + (uint32_t)(__builtin_ctz(xw) >> 3) : 8u);
+              be = xb ? (uint32_t)(__builtin_clz(xb) >> 3) : 4u;
+            }
+            info |= cp | (fl << 16) | (be << 20) | 0x40000000u;
+          }
+          const uint64_t Ecp = __ballot(em);
+          const uint64_t Dp = __ballot(grp);
+          uint64_t ED = Ecp | Dp;  // lanes the run loop has to look at
+          DBG_T(t4d);
+          DBG_ADD(0, t4b - t4a);
+          DBG_ADD(1, t4c0 - t4b);
+          DBG_ADD(2, t4c - t4c0);
+          DBG_ADD(6, t4d - t4c);
+          // ================= runs (scalar work) ========================================================
+          // One loop with a single hot path: next event -> (rare: suspect lane) -> (cooperative extension)
+          // -> short-form emit -> advance.  Conditions are folded into sign tests of small integer
+          // expressions so that hipcc does not materialise 64-bit lane masks for every boolean.
+          uint64_t K = 0;      // lanes the sequential code inserts: probes and ip-2 positions
+          int rs = rs0, rt = t0, pend_q = -1;
+          int exit_kind = 0;   // 0: next window / batch, 1: last literals, 2: the general batch takes over
+          const int e0 = rs0 + 66 - t0;  // the first run may continue an older one (t0 <= 48 => e0 >= rs0 + 18)
+          int elim = e0 < kWave ? e0 : kWave;
+          uint64_t valid = e0 < kWave ? ((1ull << e0) - 1ull) : ~0ull;  // consecutive probes of the current run
+          const int lit_floor = vp_ok ? wbase - 64 : wbase;  // literals in registers start here
+          // Cost model measured on gfx950 (tools/probe/issue_probe.hip): a plain SALU / VALU instruction costs a
+          // wave ~5 cycles, a taken branch ~25, a not-taken one ~11, a VALU -> SGPR -> SALU crossing ~+20.  So the
+          // hot path below is one fall-through chain: every rare case leaves the loop (exit codes) and is handled
+          // behind it, then the loop is re-entered.
+          enum { kNoEvent = 0, kLeft = 2 };
+          int why;
+          {
+            DBG_T(tl0);
+            for (;;) {
+              const uint64_t live_m = valid & (~0ull << rs);
+              const uint64_t cm = ED & live_m;
+              if (cm == 0ull) { why = kNoEvent; break; }
+              const int m = __builtin_ctzll(cm);
+              const uint32_t inf = __builtin_amdgcn_readlane(info, m);
+              const uint64_t bit = 1ull << m;
+              // an earlier kept (or in-run) lane with the same table candidate may share the hash: rare path
+              const uint64_t dk = __ballot(cp == (inf & 0xffffu)) & (bit - 1ull) & (K | live_m) & Dp;
+              const int ip0 = wbase + m;
+              int mpos = (int)(inf & 0xffffu);
+              int fwd = (int)((inf >> 16) & 0xfu);
+              const int be = (int)((inf >> 20) & 0x7u);
+              const int nbmax = ip0 - anchor;
+              int nb = be < nbmax ? be : nbmax;
+              // need_ext <=> fwd >= 8 || (be >= 4 && nbmax > 4)   (a length hit its cap)
+              int ext = (7 - fwd) | ((3 - be) & (4 - nbmax));
+              if (__builtin_expect(dk != 0ull || (inf & 0x40000000u) == 0u, 0)) {
+                // exact duplicate-hash resolution: the highest earlier kept / in-run lane with the same HASH
+                DBG_ADD(15, 1);
+                const uint32_t hv = __builtin_amdgcn_readlane(h, m);
+                const uint64_t dh = __ballot(h == hv) & (bit - 1ull) & (K | live_m);
+                bool is_match = (inf & 0x40000000u) != 0u;
+                if (dh) {  // the sequential code's candidate is an earlier position of this window
+                  const int d = 63 - __builtin_clzll(dh);
+                  is_match = __builtin_amdgcn_readlane(v, d) == __builtin_amdgcn_readlane(v, m);
+                  mpos = wbase + d;
+                  ext = -1;
+                }
+                if (!is_match) {
+                  DBG_ADD(16, 1);
+                  ED &= ~bit;  // a plain no-match probe: the run goes on behind it
+                  continue;
+                }
+              }
+              if (ext < 0) {
+                DBG_T(ts0);
+                // cooperative extension, one round: 256 bytes forward, 64 backward (all loads issued together)
+                int fp = ip0 + kMinMatch + 4 * lane;
+                fp = fp < last4 ? fp : last4;
+                const uint32_t x = in.rd32(fp) ^ in.rd32(fp - (ip0 - mpos));
+                const int maxback = nbmax < mpos ? nbmax : mpos;
+                uint32_t ba = 0, bb = 1;
+                if (lane < maxback) {
+                  ba = in.rd8(ip0 - 1 - lane);
+                  bb = in.rd8(mpos - 1 - lane);
+                }
+                const uint64_t E = __ballot(ba == bb);
+                const uint64_t D = __ballot(x != 0u);
+                const int nbk = (int)__builtin_ctzll(~E | (1ull << 63));  // (lane 63 always stops the count)
+                const int f = D ? (int)__builtin_ctzll(D) : 0;
+                const uint32_t xf = __builtin_amdgcn_readlane(x, f);
+                int got = D ? 4 * f + (int)(__builtin_ctz(xf) >> 3) : 4 * kWave;
+                const int avail = matchlimit - (ip0 + kMinMatch);
+                if (__builtin_expect((got >= 4 * kWave && avail > 4 * kWave) || nbk >= 63, 0)) {
+                  fwd = extend_match(in, ip0, mpos, anchor, matchlimit, last4, lane, nb);  // longer than one round
+                } else {
+                  fwd = got < avail ? got : avail;
+                  nb = nbk;
+                }
+                DBG_T(ts1);
+                DBG_ADD(4, ts1 - ts0);
+                DBG_ADD(10, 1);
+              }
+              DBG_ADD(9, 1);
+              const int lit = nbmax - nb, offset = ip0 - mpos, mcode = nb + fwd;
+              const int total = 3 + lit + (mcode >= 15 ? 1 : 0);
+              const int ipe = ip0 + kMinMatch + fwd;
+              // short form <=> anchor >= lit_floor && lit < 15 && mcode < 270 && op + total <= len
+              if (__builtin_expect(((anchor - lit_floor) | (14 - lit) | (269 - mcode) | (len - op - total)) < 0, 0)) {
+                op = emit_sequence(out, len, op, in, anchor, lit, true, offset, mcode, false, 0u, lane);
+                if (op < 0) return -1;
+              } else {
+                // every literal is the low byte of a lane's v (this window) or vp (the previous one): lane L
+                // stores its own byte, four otherwise idle lanes store token / offset / match-length byte
+#ifdef S3S_ABL_NOEMIT
+                if (false) {
+#else
+                {
+#endif
+                const uint32_t rel = (uint32_t)(lane - anchor) & 63u;
+                const uint32_t tok = (uint32_t)(lit << 4) | (uint32_t)(mcode < 15 ? mcode : 15);
+                const uint32_t d = rel - (uint32_t)lit;  // 0: token, 1/2: offset, 3: match-length byte
+                uint32_t bv = (((int)(anchor + rel) < wbase) ? vp : v) & 0xffu;
+                bv = d == 0u ? tok : bv;
+                bv = d == 1u ? (uint32_t)offset : bv;
+                bv = d == 2u ? (uint32_t)offset >> 8 : bv;
+                bv = d == 3u ? (uint32_t)(mcode - 15) : bv;
+                const uint32_t idx = d == 0u ? 0u : rel + (rel < (uint32_t)lit ? 1u : 0u);
+#if defined(S3S_ABL_NOSTORE)
+                asm volatile("" ::"v"(bv), "v"(idx));
+#else
+                if (rel < (uint32_t)total) out[(uint32_t)op + idx] = (uint8_t)bv;
+#endif
+                }
+                op += total;
+              }
+              K |= live_m & ((bit << 1) - 1ull);
+              anchor = ipe;
+              const int q = ipe - 2 - wbase;  // LZ4_putPosition(ip - 2)
+              K |= q < kWave ? (1ull << (q & 63)) : 0ull;
+              pend_q = q < kWave ? pend_q : q + wbase;
+              rs = ipe - wbase;
+              rt = 0;
+              elim = kWave;
+              valid = ~0ull;
+              if (rs >= kWave) { why = kLeft; break; }
+            }
+            DBG_T(tl1);
+            DBG_ADD(12, tl1 - tl0);
+            if (why == kNoEvent) {  // the run leaves the window (or its consecutive part) without a match
+              K |= valid & (~0ull << rs);
+              base = wbase + elim;
+              t0 = rt + (elim - rs);
+              exit_kind = elim < kWave ? 2 : 0;
+            } else {  // the match left the window
+              base = anchor;
+              t0 = 0;
+              exit_kind = anchor >= mfl1 ? 1 : 0;
+            }
+          }
+          DBG_T(t4e);
+          DBG_ADD(3, t4e - t4d);
+          if (exit_kind == 1) break;
+          // ================= commit: the highest kept lane of every hash group writes ==================
+          const bool kept = ((K >> lane) & 1ull) != 0ull;
+          if (kept) T[h] = (uint16_t)p;
+          if (K & Dp) {
+            for (;;) {
+              const bool redo = kept && (uint32_t)T[h] < (uint32_t)p;
+              if (!__ballot(redo)) break;
+              if (redo) T[h] = (uint16_t)p;
+            }
+          }
+          if (pend_q >= 0) {  // the put happens at the top of the next iteration (base - 2 == pend_q)
+            const int dq = pend_q - wbase;
+            vput = dq < 2 * kWave ? __builtin_amdgcn_readlane(pw1.y, dq - kWave)
+                                  : (dq < 3 * kWave ? __builtin_amdgcn_readlane(pw2.y, dq - 2 * kWave)
+                                                    : in.rd32(pend_q));
+            put_pending = true;
+          }
+          force_general = exit_kind == 2;
+          DBG_T(t4f);
+          DBG_ADD(5, t4f - t4e);
           continue;
         }
         force_general = false;
@@ -1375,6 +1645,9 @@ void launch_lz4_compress(const uint8_t* d_src, const Item* d_items, int32_t n_it
                        d_items, n_items, d_item_check, d_slots, d_item_size);
   else if (variant == 4)
     hipLaunchKernelGGL(lz4_compress_l2_kernel<3>, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
+                       d_items, n_items, d_item_check, d_slots, d_item_size);
+  else if (variant == 10)
+    hipLaunchKernelGGL(lz4_compress_l2_kernel<4>, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
                        d_items, n_items, d_item_check, d_slots, d_item_size);
   else if (variant == 5)
     hipLaunchKernelGGL((lz4_compress_l2_kernel<0, true>), dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,

@@ -11,7 +11,12 @@ LZ4, SNAPPY, NONE = 1, 2, 0
 ADLER, CRC = 1, 2
 
 
-@pytest.fixture(params=[0, 1, 2, 9], ids=["chunk-in-lds", "chunk-in-l2", "window", "auto"], autouse=True)
+import os
+
+_VARIANTS = [int(x) for x in os.environ.get("S3S_TEST_LZ4_VARIANTS", "0,1,2,9").split(",")]
+
+
+@pytest.fixture(params=_VARIANTS, ids=[f"variant{v}" for v in _VARIANTS], autouse=True)
 def lz4_variant(request, gpu_codec):
     """Every test runs against both placements of the chunk bytes and both parses
     (S3S_OPT_LZ4_VARIANT; 2 = default, 9 = self-tuning choice between 1 and 2)."""

@@ -20,8 +20,9 @@ d_src = torch.from_numpy(data).cuda()
 cap = c.max_compressed_size(1, offs)
 d_dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
 torch.cuda.synchronize()
-names = ["validate", "w_wait", "advance", "runs", "slow_ext", "commit", "", "", "windows", "seqs", "slow", "general"]
-for variant in (3,):
+names = ["top2Tread", "dup_passes", "G_wait", "runs", "slow_ext", "commit", "prep_valu", "", "windows", "seqs", "slow", "general", "ev_find", "ev_emit", "ev_update", "suspects", "nonmatch"]
+variants = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [10]
+for variant in variants:
     c.set_option(4, variant)
     for it in range(2):
         buf = (ctypes.c_ulonglong * 32)()
@@ -33,5 +34,5 @@ for variant in (3,):
     for i, n in enumerate(names):
         if n:
             print(f"  {n:10s} {buf[i] / nchunks:12.1f} per chunk")
-    cyc = sum(buf[i] for i in range(6)) / nchunks
-    print(f"  accounted cycles/chunk {cyc:.0f}; per window: " + ", ".join(f"{names[i]}={buf[i]/max(buf[8],1):.0f}" for i in (0, 1, 2, 3, 5)) + f"; per slow ext {buf[4]/max(buf[10],1):.0f}")
+    cyc = sum(buf[i] for i in (0, 1, 2, 3, 5, 6)) / nchunks
+    print(f"  accounted cycles/chunk {cyc:.0f}; per window: " + ", ".join(f"{names[i]}={buf[i]/max(buf[8],1):.0f}" for i in (0, 1, 2, 6, 3, 5)) + f"; per slow ext {buf[4]/max(buf[10],1):.0f}")
