@@ -66,7 +66,8 @@
 extern "C" {
 #endif
 
-#define S3S_ABI_VERSION 2 /* 2: + segments entry points, page-locked staging, tuning options 6, 7 */
+#define S3S_ABI_VERSION 3 /* 2: + segments entry points, page-locked staging, tuning options 6, 7;
+                             3: + s3s_compress_map_outputs_batch_device / s3s_decompress_ranges_batch_device */
 
 /* spark.io.compression.codec (only when spark.shuffle.compress=true) */
 enum { S3S_CODEC_NONE = 0, S3S_CODEC_LZ4 = 1, S3S_CODEC_SNAPPY = 2 };
@@ -162,6 +163,32 @@ int s3s_compress_map_output_device(s3s_ctx* ctx, int codec, int checksum_algo,
                                    int32_t num_partitions, uint8_t* d_dst, int64_t dst_capacity,
                                    int64_t* out_index, int64_t* out_checksums,
                                    int64_t* out_total);
+
+/* Batched form of s3s_compress_map_output_device: several map tasks of one executor in ONE call.
+ * No reference counterpart as an interface — on the JVM every task thread drives its own
+ * LZ4BlockOutputStream (shuffle/S3ShuffleMapOutputWriter.scala:168-202); the shim collects the
+ * spill buffers of the tasks that commit together (shuffle/S3ShuffleMapOutputWriter.scala:91-118)
+ * and hands them over at once, so that the chip sees enough 32 KiB chunks to fill its 2 560
+ * resident wavefronts (an 8 MiB map output — the reference's default write buffer,
+ * shuffle/helper/S3ShuffleDispatcher.scala:55 — is 256 chunks).  All chunks of all tasks go
+ * through one codec launch; offsets, gather and checksums run per task behind it; one stream
+ * synchronisation for the batch.  Every task gets exactly the bytes, index and checksums
+ * s3s_compress_map_output_device would have produced for it alone.  One codec stream per
+ * non-empty partition (no multi-spill pieces in the batched form).
+ * Returns S3S_OK, or the first failing task's error; each task's own result is in .status.   */
+typedef struct s3s_map_task {
+  const uint8_t* d_src;         /* in: device memory holding this task's partitions */
+  const int64_t* src_offsets;   /* in: host array [num_partitions + 1], offsets into d_src */
+  int32_t num_partitions;       /* in */
+  uint8_t* d_dst;               /* in: device buffer for the .data image */
+  int64_t dst_capacity;         /* in */
+  int64_t* out_index;           /* out: host array [num_partitions + 1] */
+  int64_t* out_checksums;       /* out: host array [num_partitions] (may be NULL iff checksum NONE) */
+  int64_t out_total;            /* out: bytes of the .data image */
+  int32_t status;               /* out: S3S_OK / S3S_E_CAPACITY for this task */
+} s3s_map_task;
+int s3s_compress_map_outputs_batch_device(s3s_ctx* ctx, int codec, int checksum_algo,
+                                          s3s_map_task* tasks, int32_t n_tasks);
 
 /* ---- checksum only ---------------------------------------------------------------------- */
 /* out[i] = checksum(data[offsets[i], offsets[i+1])) for i in [0, n). */

@@ -77,7 +77,7 @@ template <int ALGO>
 __global__ __launch_bounds__(kThreads) void checksum_segments_kernel(
     const uint8_t* __restrict__ data, const int64_t* __restrict__ offsets, int32_t n,
     const int32_t* __restrict__ seg_start, const Tables* __restrict__ tabs,
-    uint32_t* __restrict__ partial) {
+    uint32_t* __restrict__ partial, int64_t data_len) {
   __shared__ uint32_t lds_slice[4 * 256];
   __shared__ uint32_t scratch[kThreads / kWave];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -93,6 +93,9 @@ __global__ __launch_bounds__(kThreads) void checksum_segments_kernel(
   const int64_t soff = (int64_t)s * kChecksumSegBytes;
   if (soff >= plen) return;  // slot beyond the actual (compressed) length
   const int seg_len = (int)((plen - soff) < kChecksumSegBytes ? (plen - soff) : kChecksumSegBytes);
+  // never read past the caller's buffer: after a capacity overflow the device-computed offsets exceed it
+  // (the call reports S3S_E_CAPACITY; the sums of such ranges are not used)
+  if (pstart + soff + seg_len > data_len) return;
   const uint8_t* g = data + pstart + soff;
 
   if (ALGO == S3S_CHECKSUM_CRC32) {
@@ -263,21 +266,21 @@ void checksum_tables_build(void* host_buf) {
 void launch_checksum_with_tables(int algo, const uint8_t* d_data, const int64_t* d_offsets,
                                  int32_t n, const int32_t* d_seg_start, int32_t total_segs,
                                  const void* d_tables, uint32_t* d_partial, int64_t* d_out,
-                                 hipStream_t st) {
+                                 int64_t data_len, hipStream_t st) {
   if (n <= 0) return;
   const Tables* tabs = static_cast<const Tables*>(d_tables);
   if (algo == S3S_CHECKSUM_ADLER32) {
     if (total_segs > 0) {
       (void)hipMemsetAsync(d_partial, 0, 16 * (size_t)total_segs, st);  // wavefront sums are added atomically
       hipLaunchKernelGGL(checksum_segments_kernel<S3S_CHECKSUM_ADLER32>, dim3((unsigned)total_segs),
-                         dim3(kThreads), 0, st, d_data, d_offsets, n, d_seg_start, tabs, d_partial);
+                         dim3(kThreads), 0, st, d_data, d_offsets, n, d_seg_start, tabs, d_partial, data_len);
     }
     hipLaunchKernelGGL(checksum_combine_kernel<S3S_CHECKSUM_ADLER32>, dim3((unsigned)n),
                        dim3(kWave), 0, st, d_offsets, n, d_seg_start, tabs, d_partial, d_out);
   } else {
     if (total_segs > 0)
       hipLaunchKernelGGL(checksum_segments_kernel<S3S_CHECKSUM_CRC32>, dim3((unsigned)total_segs),
-                         dim3(kThreads), 0, st, d_data, d_offsets, n, d_seg_start, tabs, d_partial);
+                         dim3(kThreads), 0, st, d_data, d_offsets, n, d_seg_start, tabs, d_partial, data_len);
     hipLaunchKernelGGL(checksum_combine_kernel<S3S_CHECKSUM_CRC32>, dim3((unsigned)n),
                        dim3(kThreads), 0, st, d_offsets, n, d_seg_start, tabs, d_partial, d_out);
   }

@@ -325,7 +325,7 @@ static int compress_core(s3s_ctx* ctx, int codec, int checksum_algo, const uint8
   }
   if (checksum_algo != S3S_CHECKSUM_NONE && n > 0) {
     if ((rc = run_checksum(ctx, checksum_algo, d_dst, dev<int64_t>(ctx, B_INDEX), n, h_seg,
-                           dev<int64_t>(ctx, B_SUMS))))
+                           dev<int64_t>(ctx, B_SUMS), dst_capacity)))
       return rc;
   }
   record(ctx, 3);
@@ -382,6 +382,210 @@ int s3s_compress_map_output_device(s3s_ctx* ctx, int codec, int checksum_algo,
   for (int32_t p = 0; p <= n; p++) pfs[(size_t)p] = p;
   return compress_core(ctx, codec, checksum_algo, d_src, src_offsets, n, pfs.data(), n, d_dst, dst_capacity,
                        out_index, out_checksums, out_total);
+}
+
+// Batched map side: ONE codec launch over the chunks of every map task (a 128 MiB task alone is 1.6
+// rounds of the chip's 2 560 resident wavefronts; an 8 MiB one a tenth of a round), then scan / gather /
+// checksum per task on the same stream, ONE stream synchronisation for the whole batch.
+int s3s_compress_map_outputs_batch_device(s3s_ctx* ctx, int codec, int checksum_algo, s3s_map_task* tasks,
+                                          int32_t n_tasks) {
+  if (!ctx) return S3S_E_INVALID;
+  ctx->err[0] = 0;
+  if (n_tasks < 0 || (n_tasks > 0 && !tasks)) return fail(ctx, S3S_E_INVALID, "null task array or negative count");
+  if (codec != S3S_CODEC_NONE && codec != S3S_CODEC_LZ4 && codec != S3S_CODEC_SNAPPY)
+    return fail(ctx, S3S_E_INVALID, "unknown codec %d", codec);
+  if (checksum_algo != S3S_CHECKSUM_NONE && checksum_algo != S3S_CHECKSUM_ADLER32 &&
+      checksum_algo != S3S_CHECKSUM_CRC32)
+    return fail(ctx, S3S_E_INVALID, "unknown checksum algorithm %d", checksum_algo);
+  if (codec == S3S_CODEC_SNAPPY && !snappy_compress_available())
+    return fail(ctx, S3S_E_UNSUPPORTED, "snappy compression is not available in this build");
+  if (n_tasks == 0) return S3S_OK;
+  if (codec == S3S_CODEC_NONE) {  // nothing to batch: plain copies
+    int worst = S3S_OK;
+    for (int32_t t = 0; t < n_tasks; t++) {
+      s3s_map_task& k = tasks[t];
+      k.status = s3s_compress_map_output_device(ctx, codec, checksum_algo, k.d_src, k.src_offsets, k.num_partitions,
+                                                k.d_dst, k.dst_capacity, k.out_index, k.out_checksums, &k.out_total);
+      if (k.status != S3S_OK && worst == S3S_OK) worst = k.status;
+    }
+    return worst;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int64_t bs = effective_block(ctx, codec);
+  const int level = codec == S3S_CODEC_LZ4 ? lz4_level(bs) : 0;
+  // ---- validate, count ------------------------------------------------------------------------------
+  int64_t n_items64 = 0, n_chunks64 = 0, n_parts64 = 0;
+  for (int32_t t = 0; t < n_tasks; t++) {
+    const s3s_map_task& k = tasks[t];
+    if (k.num_partitions < 0 || !k.src_offsets || !k.out_index || k.dst_capacity < 0)
+      return fail(ctx, S3S_E_INVALID, "task %d: null offsets/index, negative partition count or capacity", t);
+    if (checksum_algo != S3S_CHECKSUM_NONE && !k.out_checksums)
+      return fail(ctx, S3S_E_INVALID, "task %d: out_checksums is null but a checksum algorithm is selected", t);
+    for (int32_t p = 0; p < k.num_partitions; p++) {
+      const int64_t u = k.src_offsets[p + 1] - k.src_offsets[p];
+      if (u < 0) return fail(ctx, S3S_E_INVALID, "task %d: offsets not monotonic at %d", t, p);
+      if (u > 0) {
+        const int64_t ch = (u + bs - 1) / bs;
+        n_chunks64 += ch;
+        n_items64 += ch + 1;
+      }
+    }
+    const int64_t tu = k.num_partitions > 0 ? k.src_offsets[k.num_partitions] - k.src_offsets[0] : 0;
+    if ((tu > 0 && !k.d_src) || (!k.d_dst && k.dst_capacity > 0)) return fail(ctx, S3S_E_INVALID, "task %d: null data pointer", t);
+    n_parts64 += k.num_partitions;
+  }
+  if (n_items64 > 0x7fffff00ll) return fail(ctx, S3S_E_UNSUPPORTED, "too many codec blocks in one call");
+  const int32_t n_items = (int32_t)n_items64, n_chunks = (int32_t)n_chunks64;
+  const size_t np1 = (size_t)n_parts64 + (size_t)n_tasks;  // sum of (n_t + 1)
+  // pinned staging: [items][part_first (per task, relative)][seg_start (per task)][index out][sums out][status out]
+  const size_t items_bytes = sizeof(Item) * (size_t)n_items;
+  auto al = [](size_t x) { return (x + 15) & ~size_t(15); };
+  const size_t o_items = 0, o_pf = al(o_items + items_bytes), o_seg = al(o_pf + 4 * np1), o_idx = al(o_seg + 4 * np1),
+               o_sums = al(o_idx + 8 * np1), o_status = al(o_sums + 8 * ((size_t)n_parts64 + 1)),
+               stage_total = o_status + 4 * (size_t)n_tasks + 16;
+  int rc;
+  if ((rc = ensure_stage(ctx, stage_total))) return rc;
+  uint8_t* hs = static_cast<uint8_t*>(ctx->h_stage);
+  Item* h_items = reinterpret_cast<Item*>(hs + o_items);
+  int32_t* h_pf = reinterpret_cast<int32_t*>(hs + o_pf);
+  int32_t* h_seg = reinterpret_cast<int32_t*>(hs + o_seg);
+  int64_t* h_idx = reinterpret_cast<int64_t*>(hs + o_idx);
+  int64_t* h_sums = reinterpret_cast<int64_t*>(hs + o_sums);
+  int32_t* h_status = reinterpret_cast<int32_t*>(hs + o_status);
+  std::vector<int32_t> first_item((size_t)n_tasks + 1), first_part((size_t)n_tasks + 1), first_seg((size_t)n_tasks + 1);
+  const uint8_t* base = tasks[0].d_src;  // item sources are offsets from one base pointer (signed 64-bit)
+  {
+    int32_t it = 0, ch = 0, pp = 0, seg = 0;
+    for (int32_t t = 0; t < n_tasks; t++) {
+      const s3s_map_task& k = tasks[t];
+      first_item[(size_t)t] = it;
+      first_part[(size_t)t] = pp;
+      first_seg[(size_t)t] = seg;
+      const int64_t delta = k.d_src ? (int64_t)(k.d_src - base) : 0;
+      int32_t* pf = h_pf + pp + t;
+      int32_t* sg = h_seg + pp + t;
+      int32_t seg_t = 0;
+      for (int32_t p = 0; p < k.num_partitions; p++) {
+        pf[p] = it - first_item[(size_t)t];
+        sg[p] = seg_t;
+        const int64_t u = k.src_offsets[p + 1] - k.src_offsets[p];
+        seg_t += worst_segs(max_partition_size(codec, bs, u));
+        if (u <= 0) continue;
+        if (codec == S3S_CODEC_SNAPPY) h_items[it++] = Item{0, 0, kItemSnappyHeader, -1, p};
+        for (int64_t pos = 0; pos < u; pos += bs) {
+          const int32_t len = (int32_t)((u - pos) < bs ? (u - pos) : bs);
+          const int32_t kind = codec == S3S_CODEC_LZ4 ? (kItemLz4Chunk | (level << 8)) : kItemSnappyChunk;
+          h_items[it++] = Item{delta + k.src_offsets[p] + pos, len, kind, ch++, p};
+        }
+        if (codec == S3S_CODEC_LZ4) h_items[it++] = Item{0, 0, kItemLz4End | (level << 8), -1, p};
+      }
+      pf[k.num_partitions] = it - first_item[(size_t)t];
+      sg[k.num_partitions] = seg_t;
+      seg += seg_t;
+      pp += k.num_partitions;
+    }
+    first_item[(size_t)n_tasks] = it;
+    first_part[(size_t)n_tasks] = pp;
+    first_seg[(size_t)n_tasks] = seg;
+  }
+  const int32_t total_segs = first_seg[(size_t)n_tasks];
+  const int64_t slot_stride = codec == S3S_CODEC_SNAPPY
+                                  ? (int64_t)kSlotHeader + ((snappy_max_len(bs) + 15) & ~int64_t(15))
+                                  : (int64_t)kSlotBytes;
+  if ((rc = ensure(ctx, B_ITEMS, items_bytes + 16))) return rc;
+  if ((rc = ensure(ctx, B_PART_FIRST, 4 * np1))) return rc;
+  if ((rc = ensure(ctx, B_SEG_START, 4 * np1))) return rc;
+  if ((rc = ensure(ctx, B_INDEX, 8 * np1))) return rc;
+  if ((rc = ensure(ctx, B_SUMS, 8 * ((size_t)n_parts64 + 1)))) return rc;
+  if ((rc = ensure(ctx, B_STATUS, 4 * (size_t)n_tasks + 16))) return rc;
+  if ((rc = ensure(ctx, B_PARTIAL, 16 * (size_t)(total_segs > 0 ? total_segs : 1)))) return rc;
+  if ((rc = ensure(ctx, B_SLOTS, (size_t)slot_stride * (size_t)(n_chunks > 0 ? n_chunks : 1)))) return rc;
+  if ((rc = ensure(ctx, B_ITEM_SIZE, sizeof(uint32_t) * (size_t)(n_items + 1)))) return rc;
+  if ((rc = ensure(ctx, B_ITEM_OFF, sizeof(int64_t) * ((size_t)n_items + (size_t)n_tasks + 1)))) return rc;
+  if ((rc = ensure(ctx, B_ITEM_CHECK, sizeof(uint32_t) * (size_t)(n_items + 1)))) return rc;
+  HIP_TRY(ctx, hipMemsetAsync(ctx->buf[B_STATUS].p, 0, 4 * (size_t)n_tasks + 16, ctx->stream));
+  // one upload: items | part_first | seg_start are consecutive in the staging buffer but live in separate
+  // device buffers
+  if (n_items > 0)
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_ITEMS].p, h_items, items_bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_PART_FIRST].p, h_pf, 4 * np1, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_SEG_START].p, h_seg, 4 * np1, hipMemcpyHostToDevice, ctx->stream));
+  record(ctx, 0);
+  // ---- ONE codec launch over every task's chunks ---------------------------------------------------------
+  if (codec == S3S_CODEC_LZ4) {
+    const int variant = ctx->lz4_variant == 9 ? 2 : ctx->lz4_variant;
+    ctx->lz4_variant_used = variant;
+    launch_lz4_compress(base, dev<Item>(ctx, B_ITEMS), n_items, dev<uint32_t>(ctx, B_ITEM_CHECK),
+                        dev<uint8_t>(ctx, B_SLOTS), dev<uint32_t>(ctx, B_ITEM_SIZE), variant, ctx->stream,
+                        ctx->profile ? ctx->ev_hash : nullptr);
+  } else {
+    launch_snappy_compress(base, dev<Item>(ctx, B_ITEMS), n_items, dev<uint8_t>(ctx, B_SLOTS), slot_stride,
+                           dev<uint32_t>(ctx, B_ITEM_SIZE), ctx->snappy_variant, ctx->stream);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  record(ctx, 1);
+  // ---- per task: offsets, .data image, checksums ------------------------------------------------------------
+  for (int32_t t = 0; t < n_tasks; t++) {
+    const s3s_map_task& k = tasks[t];
+    const int32_t fi = first_item[(size_t)t], ni = first_item[(size_t)t + 1] - fi, pp = first_part[(size_t)t] + t;
+    launch_scan_items(dev<Item>(ctx, B_ITEMS) + fi, dev<uint32_t>(ctx, B_ITEM_SIZE) + fi, ni,
+                      dev<int64_t>(ctx, B_ITEM_OFF) + fi + t, dev<int32_t>(ctx, B_PART_FIRST) + pp, k.num_partitions,
+                      dev<int64_t>(ctx, B_INDEX) + pp, ctx->stream);
+    launch_gather_items(base, dev<Item>(ctx, B_ITEMS) + fi, ni, dev<uint8_t>(ctx, B_SLOTS), slot_stride,
+                        dev<uint32_t>(ctx, B_ITEM_SIZE) + fi, dev<int64_t>(ctx, B_ITEM_OFF) + fi + t, k.d_dst,
+                        k.dst_capacity, dev<int32_t>(ctx, B_STATUS) + t, ctx->stream);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  record(ctx, 2);
+  if (checksum_algo != S3S_CHECKSUM_NONE) {
+    for (int32_t t = 0; t < n_tasks; t++) {
+      const s3s_map_task& k = tasks[t];
+      if (k.num_partitions <= 0) continue;
+      const int32_t pp = first_part[(size_t)t] + t;
+      launch_checksum_with_tables(checksum_algo, k.d_dst, dev<int64_t>(ctx, B_INDEX) + pp, k.num_partitions,
+                                  dev<int32_t>(ctx, B_SEG_START) + pp, first_seg[(size_t)t + 1] - first_seg[(size_t)t],
+                                  ctx->buf[B_TABLES].p, dev<uint32_t>(ctx, B_PARTIAL) + 4 * (size_t)first_seg[(size_t)t],
+                                  dev<int64_t>(ctx, B_SUMS) + first_part[(size_t)t], k.dst_capacity, ctx->stream);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  record(ctx, 3);
+  HIP_TRY(ctx, hipMemcpyAsync(h_idx, ctx->buf[B_INDEX].p, 8 * np1, hipMemcpyDeviceToHost, ctx->stream));
+  if (checksum_algo != S3S_CHECKSUM_NONE && n_parts64 > 0)
+    HIP_TRY(ctx, hipMemcpyAsync(h_sums, ctx->buf[B_SUMS].p, 8 * (size_t)n_parts64, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(h_status, ctx->buf[B_STATUS].p, 4 * (size_t)n_tasks, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->profile) {
+    float ms = 0;
+    hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]); ctx->stage_ms[S3S_STAGE_TOTAL] = ms;
+    hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); ctx->stage_ms[S3S_STAGE_CODEC] = ms;
+    ctx->stage_ms[S3S_STAGE_HASH] = 0;
+    if (codec == S3S_CODEC_LZ4) {
+      hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev_hash); ctx->stage_ms[S3S_STAGE_HASH] = ms;
+      hipEventElapsedTime(&ms, ctx->ev_hash, ctx->ev[1]); ctx->stage_ms[S3S_STAGE_CODEC] = ms;
+    }
+    hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]); ctx->stage_ms[S3S_STAGE_ASSEMBLE] = ms;
+    hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); ctx->stage_ms[S3S_STAGE_CHECKSUM] = ms;
+    ctx->stage_ms[S3S_STAGE_DISCOVER] = 0;
+  }
+  int worst = S3S_OK;
+  for (int32_t t = 0; t < n_tasks; t++) {
+    s3s_map_task& k = tasks[t];
+    const int32_t pp = first_part[(size_t)t] + t;
+    memcpy(k.out_index, h_idx + pp, sizeof(int64_t) * ((size_t)k.num_partitions + 1));
+    k.out_total = h_idx[pp + k.num_partitions];
+    k.status = S3S_OK;
+    if (h_status[t] != 0 || k.out_total > k.dst_capacity) {
+      k.status = S3S_E_CAPACITY;
+      if (worst == S3S_OK)
+        worst = fail(ctx, S3S_E_CAPACITY, "task %d: dst_capacity %lld too small for %lld output bytes", t,
+                     (long long)k.dst_capacity, (long long)k.out_total);
+      continue;
+    }
+    if (checksum_algo != S3S_CHECKSUM_NONE && k.num_partitions > 0)
+      memcpy(k.out_checksums, h_sums + first_part[(size_t)t], sizeof(int64_t) * (size_t)k.num_partitions);
+  }
+  return worst;
 }
 
 int64_t s3s_max_compressed_size_segments(const s3s_ctx* ctx, int codec, const int64_t* seg_offsets, int32_t n_segs) {
@@ -495,7 +699,7 @@ int s3s_checksum_ranges_device(s3s_ctx* ctx, int algo, const uint8_t* d_data,
   if ((rc = ensure(ctx, B_SUMS, sizeof(int64_t) * (size_t)n))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_OFFSETS].p, h_off, off_bytes, hipMemcpyHostToDevice, ctx->stream));
   record(ctx, 0);
-  if ((rc = run_checksum(ctx, algo, d_data, dev<int64_t>(ctx, B_OFFSETS), n, h_seg, dev<int64_t>(ctx, B_SUMS)))) return rc;
+  if ((rc = run_checksum(ctx, algo, d_data, dev<int64_t>(ctx, B_OFFSETS), n, h_seg, dev<int64_t>(ctx, B_SUMS), offsets[n]))) return rc;
   record(ctx, 3);
   HIP_TRY(ctx, hipMemcpyAsync(h_out, ctx->buf[B_SUMS].p, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

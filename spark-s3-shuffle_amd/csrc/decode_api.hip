@@ -151,7 +151,7 @@ int s3s_decompress_range_device(s3s_ctx* ctx, int codec, int checksum_algo, cons
     if ((rc = ensure(ctx, B_SUMS, sizeof(int64_t) * (size_t)n))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_OFFSETS].p, h_off, off_bytes, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = run_checksum(ctx, checksum_algo, d_comp, dev<int64_t>(ctx, B_OFFSETS), n, h_seg,
-                           dev<int64_t>(ctx, B_SUMS))))
+                           dev<int64_t>(ctx, B_SUMS), comp_len)))
       return rc;
     HIP_TRY(ctx, hipMemcpyAsync(h_sums, ctx->buf[B_SUMS].p, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   }

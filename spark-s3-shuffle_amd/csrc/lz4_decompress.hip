@@ -1117,7 +1117,13 @@ __global__ __launch_bounds__(kWave) void lz4_decompress_valu_kernel(
     int wb = -1 << 20;   // dword index (relative to c_al) of window lane 0; VGPR-uniform
     asm volatile("" : "+v"(wb));
     uint32_t win = 0;
+#ifdef S3S_LZ4_TIMING
+    unsigned long long ddbg[8] = {0};
+    const unsigned long long tk0 = __builtin_amdgcn_s_memtime();
+#endif
     for (;;) {
+      DDBG_T(tv0);
+      DDBG_ADD(4, 1);
       // ---- loop control: everything scalar the loop needs, from one readfirstlane -----------------
       const int ipu = __builtin_amdgcn_readfirstlane(ip);
       if (ipu >= clen) { bad = 1; break; }
@@ -1132,6 +1138,7 @@ __global__ __launch_bounds__(kWave) void lz4_decompress_valu_kernel(
           di = di < last_dw ? di : last_dw;
           win = reinterpret_cast<const uint32_t*>(c_al)[di];
           k = 0;
+          DDBG_ADD(7, 1);
         }
         const uint32_t d0 = (uint32_t)__shfl((int)win, k), d1 = (uint32_t)__shfl((int)win, k + 1);
         const uint32_t d2 = (uint32_t)__shfl((int)win, k + 2), d3 = (uint32_t)__shfl((int)win, k + 3);
@@ -1166,6 +1173,7 @@ __global__ __launch_bounds__(kWave) void lz4_decompress_valu_kernel(
         }
       }
       if (!fast) {
+        DDBG_ADD(5, 1);
         // byte-wise parse (long literal runs, long matches, the tail of the frame): rare
         int ips = ipu, ops = __builtin_amdgcn_readfirstlane(op);
         const uint32_t token = __builtin_amdgcn_readfirstlane((uint32_t)c[ips]);
@@ -1209,6 +1217,8 @@ __global__ __launch_bounds__(kWave) void lz4_decompress_valu_kernel(
         ip = ips;
       }
       ml += 4;
+      DDBG_T(tv1);
+      DDBG_ADD(0, tv1 - tv0);
       // one scalar decision word: bit0 malformed, bit1 near (source in the ring), bit2 single round
       const int near = (offset + kWave <= kRing);
       const int dec = ((offset == 0) | (offset > op) | (ml > olen - op)) | (near << 1) | ((ml <= kWave) << 2) |
@@ -1274,7 +1284,15 @@ __global__ __launch_bounds__(kWave) void lz4_decompress_valu_kernel(
         }
       }
       op += ml;
+      DDBG_T(tv2);
+      DDBG_ADD(1, tv2 - tv1);
     }
+#ifdef S3S_LZ4_TIMING
+    ddbg[2] = __builtin_amdgcn_s_memtime() - tk0;
+    ddbg[6] = 1;
+    if (lane == 0)
+      for (int i = 0; i < 8; i++) atomicAdd(&g_dec_dbg[i], ddbg[i]);
+#endif
     if (!bad && __builtin_amdgcn_readfirstlane(op) != olen) bad = 1;
   }
   if (bad) {

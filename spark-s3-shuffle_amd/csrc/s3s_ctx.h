@@ -152,7 +152,7 @@ inline int32_t worst_segs(int64_t bytes) { return (int32_t)((bytes + kChecksumSe
 
 inline int run_checksum(s3s_ctx* ctx, int algo, const uint8_t* d_data, const int64_t* d_offsets,
                  int32_t n, const int32_t* h_seg_start /* n+1, in pinned stage */,
-                 int64_t* d_out) {
+                 int64_t* d_out, int64_t data_len) {
   const int32_t total = h_seg_start[n];
   int rc;
   if ((rc = ensure(ctx, B_SEG_START, sizeof(int32_t) * (size_t)(n + 1)))) return rc;
@@ -160,7 +160,7 @@ inline int run_checksum(s3s_ctx* ctx, int algo, const uint8_t* d_data, const int
   HIP_TRY(ctx, hipMemcpyAsync(dev<int32_t>(ctx, B_SEG_START), h_seg_start,
                               sizeof(int32_t) * (size_t)(n + 1), hipMemcpyHostToDevice, ctx->stream));
   launch_checksum_with_tables(algo, d_data, d_offsets, n, dev<int32_t>(ctx, B_SEG_START), total,
-                              ctx->buf[B_TABLES].p, dev<uint32_t>(ctx, B_PARTIAL), d_out,
+                              ctx->buf[B_TABLES].p, dev<uint32_t>(ctx, B_PARTIAL), d_out, data_len,
                               ctx->stream);
   HIP_TRY(ctx, hipGetLastError());
   return S3S_OK;

@@ -74,7 +74,7 @@ void checksum_tables_build(void* host_buf);
 void launch_checksum_with_tables(int algo, const uint8_t* d_data, const int64_t* d_offsets,
                                  int32_t n, const int32_t* d_seg_start, int32_t total_segs,
                                  const void* d_tables, uint32_t* d_partial, int64_t* d_out,
-                                 hipStream_t st);
+                                 int64_t data_len /* bytes readable at d_data */, hipStream_t st);
 constexpr int kChecksumSegBytes = 16384;
 
 // reduce side ------------------------------------------------------------------------------

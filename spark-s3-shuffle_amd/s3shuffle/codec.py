@@ -50,6 +50,14 @@ def library_path() -> str:
     return os.path.join(_PKG_ROOT, "lib", "libs3shuffle_codec.so")
 
 
+class MapTask(ctypes.Structure):
+    """struct s3s_map_task (include/s3shuffle_codec.h): one map task of a batched compress call."""
+    _fields_ = [("d_src", ctypes.c_void_p), ("src_offsets", ctypes.POINTER(ctypes.c_int64)),
+                ("num_partitions", ctypes.c_int32), ("d_dst", ctypes.c_void_p), ("dst_capacity", ctypes.c_int64),
+                ("out_index", ctypes.POINTER(ctypes.c_int64)), ("out_checksums", ctypes.POINTER(ctypes.c_int64)),
+                ("out_total", ctypes.c_int64), ("status", ctypes.c_int32)]
+
+
 _LIB = None
 
 
@@ -108,6 +116,8 @@ def load_library() -> ctypes.CDLL:
                 ctypes.c_int64, c_i64p, c_i64p, c_i64p]
     lib.s3s_compress_map_output_segments.argtypes = seg_args
     lib.s3s_compress_map_output_segments_device.argtypes = seg_args
+    lib.s3s_compress_map_outputs_batch_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(MapTask),
+                                                          ctypes.c_int32]
     lib.s3s_host_alloc.restype = vp
     lib.s3s_host_alloc.argtypes = [ctypes.c_int64]
     lib.s3s_host_free.argtypes = [vp]
@@ -246,6 +256,29 @@ class Codec:
             ctypes.byref(total))
         self._check(rc)
         return int(total.value), index, (sums[:n] if checksum != CHECKSUM_NONE else None)
+
+    def compress_map_outputs_batch_device(self, codec: int, checksum: int, tasks):
+        """Batched device form: `tasks` = [(d_src, src_offsets, d_dst, dst_capacity), ...] -> per task
+        (total bytes, index[N+1], checksums[N] or None).  One codec launch and one stream sync for all."""
+        arr = (MapTask * len(tasks))()
+        keep = []
+        for i, (d_src, src_offsets, d_dst, cap) in enumerate(tasks):
+            offs = _i64(src_offsets)
+            n = len(offs) - 1
+            index = np.zeros(n + 1, dtype=np.int64)
+            sums = np.zeros(max(n, 1), dtype=np.int64)
+            keep.append((offs, index, sums, n))
+            arr[i].d_src = d_src
+            arr[i].src_offsets = _p64(offs)
+            arr[i].num_partitions = n
+            arr[i].d_dst = d_dst
+            arr[i].dst_capacity = int(cap)
+            arr[i].out_index = _p64(index)
+            arr[i].out_checksums = _p64(sums) if checksum != CHECKSUM_NONE else None
+        rc = self._lib.s3s_compress_map_outputs_batch_device(self._h, codec, checksum, arr, len(tasks))
+        self._check(rc)
+        return [(int(arr[i].out_total), k[1], (k[2][:k[3]] if checksum != CHECKSUM_NONE else None))
+                for i, k in enumerate(keep)]
 
     # ---- checksum only -----------------------------------------------------------------------
     def checksum_ranges(self, algo: int, data: np.ndarray, offsets) -> np.ndarray:

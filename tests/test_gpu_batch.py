@@ -1,0 +1,100 @@
+"""GPU parity of the batched map-side entry point (s3s_compress_map_outputs_batch_device): every task of a
+batch must get exactly the bytes, index and checksums of the oracle (and of a single-task call)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import corpus
+
+pytestmark = pytest.mark.gpu
+
+LZ4, SNAPPY = 1, 2
+ADLER, CRC = 1, 2
+
+
+class _Dev:
+    """Device buffers through the HIP runtime directly (no torch in the test process)."""
+
+    def __init__(self):
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+        self.hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        self.hip.hipFree.argtypes = [ctypes.c_void_p]
+        self.ptrs = []
+
+    def alloc(self, n):
+        p = ctypes.c_void_p()
+        assert self.hip.hipMalloc(ctypes.byref(p), max(int(n), 16)) == 0
+        self.ptrs.append(p)
+        return p.value
+
+    def upload(self, arr):
+        p = self.alloc(arr.size)
+        if arr.size:
+            assert self.hip.hipMemcpy(p, arr.ctypes.data, arr.size, 1) == 0
+        return p
+
+    def download(self, p, n):
+        out = np.empty(max(n, 1), np.uint8)
+        if n:
+            assert self.hip.hipMemcpy(out.ctypes.data, p, n, 2) == 0
+        return out[:n]
+
+    def free(self):
+        for p in self.ptrs:
+            self.hip.hipFree(p)
+        self.ptrs = []
+
+
+@pytest.mark.parametrize("codec,algo", [(LZ4, ADLER), (LZ4, CRC), (SNAPPY, ADLER), (LZ4, 0)])
+def test_batch_equals_oracle_per_task(gpu_codec, oracle, codec, algo):
+    rng = np.random.default_rng(77 + codec * 10 + algo)
+    dev = _Dev()
+    try:
+        host, tasks = [], []
+        for t in range(7):
+            if t == 3:
+                data, offs = np.zeros(0, np.uint8), np.zeros(1, np.int64)  # a map task without partitions
+            elif t == 5:
+                data, offs = np.zeros(0, np.uint8), np.zeros(4, np.int64)  # only empty partitions
+            else:
+                data, offs = corpus.ragged_map_output(rng, n_parts=int(rng.integers(1, 30)), max_len=120_000)
+            cap = gpu_codec.max_compressed_size(codec, offs)
+            host.append((data, offs))
+            tasks.append((dev.upload(data), offs, dev.alloc(cap), cap))
+        res = gpu_codec.compress_map_outputs_batch_device(codec, algo, tasks)
+        assert len(res) == len(tasks)
+        for (data, offs), (d_src, _, d_dst, cap), (total, index, sums) in zip(host, tasks, res):
+            r_img, r_index, r_sums = oracle.compress_map_output(codec, algo, data, offs)
+            assert np.array_equal(index, r_index)
+            assert total == r_img.size
+            if algo:
+                assert np.array_equal(sums, r_sums)
+            assert np.array_equal(dev.download(d_dst, total), r_img)
+    finally:
+        dev.free()
+
+
+def test_batch_capacity_error_is_per_task(gpu_codec, oracle):
+    import s3shuffle
+
+    rng = np.random.default_rng(5)
+    dev = _Dev()
+    try:
+        a, ao = corpus.ragged_map_output(rng, n_parts=5, max_len=60_000)
+        b, bo = corpus.ragged_map_output(rng, n_parts=5, max_len=60_000)
+        cap_a, cap_b = gpu_codec.max_compressed_size(LZ4, ao), 1000  # task b's buffer is far too small
+        tasks = [(dev.upload(a), ao, dev.alloc(cap_a), cap_a), (dev.upload(b), bo, dev.alloc(cap_b), cap_b)]
+        with pytest.raises(s3shuffle.CodecError) as e:
+            gpu_codec.compress_map_outputs_batch_device(LZ4, CRC, tasks)
+        assert e.value.code == s3shuffle.codec.E_CAPACITY
+        # the same batch with a fitting buffer works afterwards (the context stays usable)
+        cap_b = gpu_codec.max_compressed_size(LZ4, bo)
+        tasks[1] = (tasks[1][0], bo, dev.alloc(cap_b), cap_b)
+        res = gpu_codec.compress_map_outputs_batch_device(LZ4, CRC, tasks)
+        for (data, offs), (total, index, sums) in zip(((a, ao), (b, bo)), res):
+            r = oracle.compress_map_output(LZ4, CRC, data, offs)
+            assert total == r[0].size and np.array_equal(index, r[1]) and np.array_equal(sums, r[2])
+    finally:
+        dev.free()
