@@ -13,7 +13,7 @@ ADLER, CRC = 1, 2
 
 import os
 
-_VARIANTS = [int(x) for x in os.environ.get("S3S_TEST_LZ4_VARIANTS", "0,1,2,9").split(",")]
+_VARIANTS = [int(x) for x in os.environ.get("S3S_TEST_LZ4_VARIANTS", "1,2,9,10").split(",")]
 
 
 @pytest.fixture(params=_VARIANTS, ids=[f"variant{v}" for v in _VARIANTS], autouse=True)
@@ -22,7 +22,7 @@ def lz4_variant(request, gpu_codec):
     (S3S_OPT_LZ4_VARIANT; 2 = default, 9 = self-tuning choice between 1 and 2)."""
     gpu_codec.set_option(4, request.param)
     yield request.param
-    gpu_codec.set_option(4, 2)
+    gpu_codec.set_option(4, 10)
 
 
 def test_auto_variant_settles_and_stays_bit_exact(gpu_codec, oracle, lz4_variant):
