@@ -112,7 +112,7 @@ int s3s_set_option(s3s_ctx* ctx, int key, int64_t value) {
       ctx->profile = value != 0;
       return S3S_OK;
     case S3S_OPT_LZ4_DECODE_VARIANT:
-      if (value < 0 || value > 3) return fail(ctx, S3S_E_INVALID, "lz4 decode variant must be 0..3");
+      if (value < 0 || value > 4) return fail(ctx, S3S_E_INVALID, "lz4 decode variant must be 0..4");
       ctx->lz4_decode_variant = (int)value;
       return S3S_OK;
     case S3S_OPT_SNAPPY_VARIANT:

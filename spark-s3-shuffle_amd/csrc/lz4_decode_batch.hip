@@ -1,0 +1,487 @@
+// lz4_decode_batch.hip — LZ4 block decoder that works on BATCHES of sequences (decode variant 4).
+//
+// Replaces the per-block LZ4_decompress call inside [EXT] LZ4BlockInputStream.refill()
+// (S3ShuffleReader.scala:108 wraps the range stream with it).  One wavefront per LZ4Block frame.
+//
+// The ring decoder (lz4_decompress.hip, variant 3) spends ~100+ vector instructions per LZ4 sequence
+// and a CU issues one vector instruction per cycle, so it is instruction-issue bound at ~1 sequence
+// per 2000 CU cycles.  A decoder is free to reorganise the work (no bit-exact parse to follow), so
+// this one makes the lanes work on DIFFERENT sequences:
+//
+//   parse    lane i assumes a token starts at stream byte ip+i and decodes it speculatively (literal
+//            length, offset, match length, position of the next token) from two dword loads; a short
+//            scalar walk over `next` marks the real tokens of the 64-byte window (~7 instructions per
+//            sequence); they are appended to the batch (one record per lane, via LDS)
+//   batch    (up to 64 sequences) a prefix sum gives every sequence its output position; ALL literal
+//            runs of the batch are copied at once, one lane per sequence; matches are copied in
+//            dependency rounds: lanes whose source ends before the round's first output byte copy
+//            their (short) matches side by side, a long / overlapping / far match is copied by the
+//            whole wave, 64 bytes per step
+//   output   is staged in a sliding LDS window (7.5 KiB, 4 KiB of history survive a slide): match
+//            sources are LDS reads, the block leaves in 16-byte coalesced stores; a source older than
+//            the window is read back from L2 (after the flush that wrote it has drained)
+//   tokens the fast parse does not take (lengths with a 255 chain, the block's last sequence) go
+//            through a byte-wise scalar path that performs every LZ4_decompress_safe bounds check
+//
+// tests/model/lz4_batch_decode_model.cpp is the lock-step CPU model of this kernel (fuzzed against
+// liblz4 incl. malformed blocks); malformed input ends in S3S_E_BAD_FRAME, never out of bounds.
+#include "s3s_internal.h"
+
+namespace s3s {
+namespace {
+
+constexpr int kBWin = 7616;   // staged output bytes (multiple of 16); with pad + records = 8 KiB -> 20 wavefronts / CU
+constexpr int kBHist = 4096;  // history a slide keeps
+constexpr int kBPad = 64;
+constexpr int kSmallMl = 16;  // matches up to this length are copied one lane per sequence
+constexpr int kSmallLit = 16; // literal runs up to this length are copied one lane per sequence
+
+constexpr uint32_t XP1 = 2654435761u, XP2 = 2246822519u, XP3 = 3266489917u, XP4 = 668265263u, XP5 = 374761393u;
+
+__device__ __forceinline__ uint32_t g_ld32(const uint8_t* p) {
+  uint32_t v;
+  __builtin_memcpy(&v, p, 4);
+  return v;
+}
+__device__ __forceinline__ uint32_t l2_ld8(const uint8_t* p) {
+  return (uint32_t)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t lds_ld32(const uint8_t* p) {
+  uint32_t v;
+  __builtin_memcpy(&v, p, 4);  // gfx950: unaligned ds_read_b32
+  return v;
+}
+__device__ __forceinline__ void lds_st32(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+__device__ __forceinline__ void lds_st16(uint8_t* p, uint32_t v) {
+  const uint16_t h = (uint16_t)v;
+  __builtin_memcpy(p, &h, 2);
+}
+
+__global__ __launch_bounds__(kWave) void lz4_decompress_batch_kernel(
+    const uint8_t* __restrict__ comp, const Frame* __restrict__ frames, int32_t n_frames,
+    const int64_t* __restrict__ frame_out, uint8_t* dst, int32_t* __restrict__ status) {
+  __shared__ __attribute__((aligned(16))) uint8_t win[kBWin + kBPad];
+  __shared__ uint2 rec[kWave];
+  const int f = blockIdx.x;
+  if (f >= n_frames) return;
+  const Frame fr = frames[f];
+  const int olen = fr.orig_len, clen = fr.comp_len;
+  if (olen == 0) return;
+  const int lane = threadIdx.x;
+  const uint8_t* c = comp + fr.comp_off;
+  uint8_t* out = dst + frame_out[f];
+  bool bad = false;
+  if (fr.method != 0x10 && clen > kMaxBlock + kMaxBlock / 255 + 64) {
+    bad = true;  // no LZ4 block of <= 32 KiB is that long (the records below keep stream offsets in 16 bits)
+  } else if (fr.method == 0x10) {  // stored frame
+    for (int j = lane * 4; j < olen; j += kWave * 4) {
+      if (j + 4 <= olen) {
+        const uint32_t x = g_ld32(c + j);
+        __builtin_memcpy(out + j, &x, 4);
+      } else {
+        for (int k = j; k < olen; k++) out[k] = c[k];
+      }
+    }
+  } else {
+    const int sh = (int)(reinterpret_cast<uintptr_t>(out) & 15u);  // window index of output byte o: o + sh - wb
+    int wb = 0, flushed = 0, op = 0, ip = 0, nseq = 0;             // wave-uniform
+    bool need_drain = false;  // stores of a flush may still be in flight (matters to far matches only)
+
+    // ---- window management ---------------------------------------------------------------------------
+    auto flush_to = [&](int upto) __attribute__((always_inline)) {  // window -> out for output bytes [flushed, upto)
+      int o = flushed;
+      int head = (-(o + sh)) & 15;
+      head = head < upto - o ? head : upto - o;
+      if (lane < head) out[o + lane] = win[o + sh - wb + lane];
+      o += head;
+      const int body = (upto - o) & ~15;
+      for (int j = lane * 16; j < body; j += kWave * 16) {
+        const uint4 x = *reinterpret_cast<const uint4*>(win + (o + sh - wb) + j);
+        *reinterpret_cast<uint4*>(out + o + j) = x;
+      }
+      o += body;
+      if (lane < upto - o) out[o + lane] = win[o + sh - wb + lane];
+      flushed = upto;
+      need_drain = true;
+    };
+    auto slide = [&]() __attribute__((always_inline)) {
+      flush_to(op);
+      const int nwb = (op + sh - kBHist) & ~15;
+      if (nwb > wb) {
+        const int shift = nwb - wb, keep = op + sh - nwb;
+        for (int j = lane * 16; j < keep; j += kWave * 16) {
+          const uint4 x = *reinterpret_cast<const uint4*>(win + shift + j);
+          *reinterpret_cast<uint4*>(win + j) = x;
+        }
+        wb = nwb;
+      }
+    };
+    auto room = [&]() __attribute__((always_inline)) -> int { return wb + kBWin - (op + sh); };
+
+    // ---- generic emitters: any length, chunked by the room of the window (all arguments uniform) ------
+    auto emit_literals = [&](int src, int n) __attribute__((always_inline)) -> bool {
+      if (n < 0 || n > clen - src || n > olen - op) return false;
+      while (n > 0) {
+        if (room() == 0) slide();
+        int k = room();
+        k = k < n ? k : n;
+        uint8_t* d = win + (op + sh - wb);
+        const int body = k >> 2;
+        for (int j = lane; j < body; j += kWave) lds_st32(d + 4 * j, g_ld32(c + src + 4 * j));
+        if (lane < (k & 3)) d[4 * body + lane] = c[src + 4 * body + lane];
+        op += k;
+        src += k;
+        n -= k;
+      }
+      return true;
+    };
+    auto emit_match = [&](int off, int ml) __attribute__((always_inline)) -> bool {
+      if (off <= 0 || off > op || ml > olen - op) return false;
+      while (ml > 0) {
+        if (room() == 0) slide();
+        int k = room();
+        k = k < ml ? k : ml;
+        const int srco = op - off;
+        uint8_t* d = win + (op + sh - wb);
+        if (srco + sh < wb) {
+          // far: the source left the window; it was flushed, read it back from L2
+          const int avail = wb - sh - srco;
+          k = k < avail ? k : avail;
+          if (need_drain) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            need_drain = false;
+          }
+          for (int j = lane; j < k; j += kWave) d[j] = (uint8_t)l2_ld8(out + srco + j);
+        } else {
+          const uint8_t* s = win + (srco + sh - wb);
+          if (off >= kWave) {
+            for (int j0 = 0; j0 < k; j0 += kWave) {  // each step reads what earlier steps (or older data) wrote
+              const int j = j0 + lane;
+              if (j < k) d[j] = s[j];
+            }
+          } else {
+            // overlapping: a periodic pattern of the `off` bytes in front of the destination
+            int idx = lane % off;
+            const int r = kWave % off;
+            for (int j0 = 0; j0 < k; j0 += kWave) {
+              const int j = j0 + lane;
+              if (j < k) d[j] = s[idx];
+              idx += r;
+              idx = idx >= off ? idx - off : idx;
+            }
+          }
+        }
+        op += k;
+        ml -= k;
+      }
+      return true;
+    };
+
+    // ---- the batch: one sequence per lane -------------------------------------------------------------
+    auto flush_batch = [&]() __attribute__((always_inline)) -> bool {
+      if (nseq == 0) return true;
+      const uint2 rc = rec[lane];
+      const bool act = lane < nseq;
+      const int lit = act ? (int)(rc.x & 0xffffu) : 0;
+      const int ml = act ? (int)(rc.x >> 16) : 0;
+      const int off = (int)(rc.y & 0xffffu);
+      const int src = (int)(rc.y >> 16);
+      // inclusive prefix sum of the sequence lengths
+      int end = lit + ml;
+#pragma unroll
+      for (int d = 1; d < kWave; d <<= 1) {
+        const int up = __shfl_up(end, d);
+        end += lane >= d ? up : 0;
+      }
+      end += op;
+      const int start = end - lit - ml, mstart = end - ml;
+      const bool wrong = act && (off == 0 || off > mstart || end > olen || src + lit > clen);
+      if (__ballot(wrong)) return false;
+      // dep: the first sequence of the batch whose match may start a round that contains this lane's match,
+      // i.e. the number of sequences t with mstart[t] < source end (binary search over the sorted mstart)
+      const int srcend = mstart - off + ml;
+      int dep = 0;
+#pragma unroll
+      for (int step = 32; step >= 1; step >>= 1) {
+        const int probe = dep + step - 1;  // candidate index
+        const int mv = __shfl(mstart, probe & 63);
+        const bool take = probe < nseq && mv < srcend;
+        dep = take ? dep + step : dep;
+      }
+      int s0 = 0;
+      while (s0 < nseq) {
+        // sequences [s0, s1) fit into the window
+        const uint64_t fits = __ballot(act && lane >= s0 && end + sh <= wb + kBWin);
+        const uint64_t fr0 = fits >> s0;
+        const int nfit = (~fr0 == 0ull) ? kWave - s0 : __builtin_ctzll(~fr0);
+        const int s1 = s0 + nfit;
+        if (nfit == 0) {
+          if (op + sh - wb > kBHist + 16) {
+            slide();
+            continue;
+          }
+          // one sequence larger than the free part of a freshly slid window
+          const int l0 = __builtin_amdgcn_readlane(lit, s0), m0 = __builtin_amdgcn_readlane(ml, s0);
+          const int o0 = __builtin_amdgcn_readlane(off, s0), r0 = __builtin_amdgcn_readlane(src, s0);
+          if (!emit_literals(r0, l0)) return false;
+          if (!emit_match(o0, m0)) return false;
+          s0++;
+          continue;
+        }
+        const bool in = lane >= s0 && lane < s1;
+        // ---- literals of [s0, s1) ----
+        {
+          uint8_t* d = win + (start + sh - wb);
+          const bool smalll = in && lit <= kSmallLit;
+          if (__ballot(smalll && lit > 0)) {
+            if (smalll && lit > 0) {
+              if (src + 16 <= clen) {
+                uint4 x;
+                __builtin_memcpy(&x, c + src, 16);
+                if (lit >= 4) lds_st32(d, x.x);
+                if (lit >= 8) lds_st32(d + 4, x.y);
+                if (lit >= 12) lds_st32(d + 8, x.z);
+                if (lit >= 16) lds_st32(d + 12, x.w);
+                const int q = lit >> 2;
+                const uint32_t tw = q == 0 ? x.x : (q == 1 ? x.y : (q == 2 ? x.z : x.w));
+                if (lit & 2) lds_st16(d + 4 * q, tw);
+                if (lit & 1) d[(lit & ~1)] = (uint8_t)(tw >> ((lit & 2) * 8));
+              } else {
+                for (int j = 0; j < lit; j++) d[j] = c[src + j];  // a literal run in the last bytes of the block
+              }
+            }
+          }
+          uint64_t big = __ballot(in && lit > kSmallLit);
+          while (big) {
+            const int s = __builtin_ctzll(big);
+            big &= big - 1;
+            const int l0 = __builtin_amdgcn_readlane(lit, s), r0 = __builtin_amdgcn_readlane(src, s);
+            const int st0 = __builtin_amdgcn_readlane(start, s);
+            uint8_t* dd = win + (st0 + sh - wb);
+            const int body = l0 >> 2;
+            for (int j = lane; j < body; j += kWave) lds_st32(dd + 4 * j, g_ld32(c + r0 + 4 * j));
+            if (lane < (l0 & 3)) dd[4 * body + lane] = c[r0 + 4 * body + lane];
+          }
+        }
+        // ---- matches of [s0, s1) in dependency rounds ----
+        const bool near = mstart - off + sh >= wb;
+        const uint64_t smallm = __ballot(in && ml <= kSmallMl && off >= ml && near);
+        int cur = s0;
+        while (cur < s1) {
+          const uint64_t okm = __ballot(dep <= cur) & smallm;
+          const uint64_t ok0 = okm >> cur;
+          const int run = (~ok0 == 0ull) ? kWave - cur : __builtin_ctzll(~ok0);
+          if (run >= 2) {
+            // lanes [cur, cur + run): one short match each, sources complete before this round's first byte
+            const bool mine = lane >= cur && lane < cur + run;
+            const uint8_t* s = win + (mstart - off + sh - wb);
+            uint8_t* d = win + (mstart + sh - wb);
+            uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+            if (mine) {
+              w0 = lds_ld32(s);
+              if (ml > 4) w1 = lds_ld32(s + 4);
+              if (ml > 8) w2 = lds_ld32(s + 8);
+              if (ml > 12) w3 = lds_ld32(s + 12);
+            }
+            if (mine) {
+              if (ml >= 4) lds_st32(d, w0);
+              if (ml >= 8) lds_st32(d + 4, w1);
+              if (ml >= 12) lds_st32(d + 8, w2);
+              if (ml >= 16) lds_st32(d + 12, w3);
+              const int q = ml >> 2;
+              const uint32_t tw = q == 0 ? w0 : (q == 1 ? w1 : (q == 2 ? w2 : w3));
+              if (ml & 2) lds_st16(d + 4 * q, tw);
+              if (ml & 1) d[(ml & ~1)] = (uint8_t)(tw >> ((ml & 2) * 8));
+            }
+            cur += run;
+          } else {
+            // one match by the whole wave
+            const int m0 = __builtin_amdgcn_readlane(ml, cur), o0 = __builtin_amdgcn_readlane(off, cur);
+            const int ms0 = __builtin_amdgcn_readlane(mstart, cur);
+            const int srco = ms0 - o0;
+            if (m0 <= kWave && o0 >= m0 && srco + sh >= wb) {
+              if (lane < m0) win[ms0 + sh - wb + lane] = win[srco + sh - wb + lane];
+            } else {
+              op = ms0;
+              if (!emit_match(o0, m0)) return false;  // (fits: never slides here)
+            }
+            cur++;
+          }
+        }
+        op = __builtin_amdgcn_readlane(end, s1 - 1);
+        s0 = s1;
+      }
+      nseq = 0;
+      return true;
+    };
+
+    // ---- one sequence, byte by byte (255-chains, the last sequence of the block) -------------------------
+    // returns 1: block finished, 0: go on, -1: malformed
+    auto slow_sequence = [&]() __attribute__((always_inline)) -> int {
+      int ips = ip;
+      if (ips >= clen) return -1;
+      const uint32_t token = __builtin_amdgcn_readfirstlane((uint32_t)c[ips]);
+      ips++;
+      int lit = (int)(token >> 4);
+      if (lit == 15) {
+        uint32_t b;
+        do {
+          if (ips >= clen) return -1;
+          b = __builtin_amdgcn_readfirstlane((uint32_t)c[ips]);
+          ips++;
+          lit += (int)b;
+        } while (b == 255u);
+      }
+      if (lit > clen - ips || lit > olen - op) return -1;
+      if (!emit_literals(ips, lit)) return -1;
+      ips += lit;
+      ip = ips;
+      if (ips == clen) return 1;
+      if (clen - ips < 2) return -1;
+      const int off = (int)__builtin_amdgcn_readfirstlane((uint32_t)c[ips] | ((uint32_t)c[ips + 1] << 8));
+      ips += 2;
+      int ml = (int)(token & 15u);
+      if (ml == 15) {
+        uint32_t b;
+        do {
+          if (ips >= clen) return -1;
+          b = __builtin_amdgcn_readfirstlane((uint32_t)c[ips]);
+          ips++;
+          ml += (int)b;
+        } while (b == 255u);
+      }
+      ml += 4;
+      ip = ips;
+      if (!emit_match(off, ml)) return -1;
+      return 0;
+    };
+
+    // ---- main loop: parse windows of 64 stream bytes ---------------------------------------------------
+    for (;;) {
+      if (ip >= clen) { bad = true; break; }
+      const int cpos = ip + lane;
+      bool cx = true;
+      int nxt = 0;
+      uint32_t r0 = 0, r1 = 0;
+      if (cpos + 4 <= clen) {
+        const uint32_t d0 = g_ld32(c + cpos);
+        const uint32_t tok = d0 & 0xffu, b1 = (d0 >> 8) & 0xffu;
+        int lit = (int)(tok >> 4), hdr = 1;
+        bool complex_ = false;
+        if (lit == 15) {
+          lit += (int)b1;
+          hdr = 2;
+          complex_ = b1 == 255u;
+        }
+        const int p2 = cpos + hdr + lit;
+        if (p2 + 4 <= clen) {
+          const uint32_t d1 = g_ld32(c + p2);
+          int ml = (int)(tok & 15u), adv = 2;
+          if (ml == 15) {
+            const uint32_t e = (d1 >> 16) & 0xffu;
+            ml += (int)e;
+            adv = 3;
+            complex_ = complex_ || e == 255u;
+          }
+          cx = complex_;
+          nxt = p2 + adv;
+          r0 = (uint32_t)lit | ((uint32_t)(ml + 4) << 16);
+          r1 = (d1 & 0xffffu) | ((uint32_t)(cpos + hdr) << 16);
+        }
+      }
+      const uint64_t CX = __ballot(cx);
+      uint64_t mask = 0;
+      int cur = ip;
+      for (;;) {
+        const int rel = cur - ip;
+        if (rel >= kWave) break;
+        if ((CX >> rel) & 1ull) break;
+        mask |= 1ull << rel;
+        cur = __builtin_amdgcn_readlane(nxt, rel);
+      }
+      const int cnt = __builtin_popcountll(mask);
+      // the batch is flushed when this window's sequences do not fit any more, and in front of every
+      // sequence of the byte-wise path (so in particular in front of the block's last sequence)
+      if (mask == 0ull || nseq + cnt > kWave) {
+        if (!flush_batch()) { bad = true; break; }
+      }
+      if (mask == 0ull) {
+        const int r = slow_sequence();
+        if (r < 0) { bad = true; break; }
+        if (r == 1) break;
+        continue;
+      }
+      if ((mask >> lane) & 1ull) {
+        const int t = nseq + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        rec[t] = make_uint2(r0, r1);
+      }
+      nseq += cnt;
+      ip = cur;
+    }
+    if (!bad && nseq != 0) bad = true;  // (a block always ends in the byte-wise path, behind a flush)
+    if (!bad && op != olen) bad = true;
+    if (!bad) flush_to(op);
+  }
+  if (bad) {
+    if (lane == 0) atomicExch(status, S3S_E_BAD_FRAME);
+    return;
+  }
+  // ---- frame check: xxHash32 of the decoded block, re-read from L2 -----------------------------------
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  {
+    const uint32_t seed = kLz4BlockSeed;
+    uint32_t acc = lane == 0 ? seed + XP1 + XP2 : lane == 1 ? seed + XP2 : lane == 2 ? seed : seed - XP1;
+    const int stripes = olen >> 4;
+    const int nblk = olen >> 8;
+    auto ld32o = [&](int byte_pos) -> uint32_t {
+      uint32_t x;
+      __builtin_memcpy(&x, out + byte_pos, 4);
+      return x;
+    };
+    uint32_t curw = nblk > 0 ? ld32o(4 * lane) : 0u;
+    for (int bk = 0; bk < nblk; bk++) {
+      const uint32_t nx = bk + 1 < nblk ? ld32o(256 * (bk + 1) + 4 * lane) : 0u;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const uint32_t wv = (uint32_t)__shfl((int)curw, 4 * j + (lane & 3));
+        acc = rotl32(acc + wv * XP2, 13) * XP1;
+      }
+      curw = nx;
+    }
+    for (int j = nblk * 16; j < stripes; j++) {
+      const uint32_t wv = ld32o(16 * j + 4 * (lane & 3));
+      acc = rotl32(acc + wv * XP2, 13) * XP1;
+    }
+    uint32_t h;
+    if (olen >= 16) {
+      const uint32_t v1 = __builtin_amdgcn_readlane(acc, 0), v2 = __builtin_amdgcn_readlane(acc, 1),
+                     v3 = __builtin_amdgcn_readlane(acc, 2), v4 = __builtin_amdgcn_readlane(acc, 3);
+      h = rotl32(v1, 1) + rotl32(v2, 7) + rotl32(v3, 12) + rotl32(v4, 18);
+    } else {
+      h = seed + XP5;
+    }
+    h += (uint32_t)olen;
+    int p = stripes << 4;
+    for (; p + 4 <= olen; p += 4) h = rotl32(h + ld32o(p) * XP3, 17) * XP4;
+    for (; p < olen; p++) h = rotl32(h + (uint32_t)out[p] * XP5, 11) * XP1;
+    h ^= h >> 15;
+    h *= XP2;
+    h ^= h >> 13;
+    h *= XP3;
+    h ^= h >> 16;
+    if (lane == 0 && (h & 0x0FFFFFFFu) != fr.check) atomicExch(status, S3S_E_BAD_FRAME);
+  }
+}
+
+}  // namespace
+
+void launch_lz4_decompress_batch(const uint8_t* d_comp, const Frame* d_frames, int32_t n_frames,
+                                 const int64_t* d_frame_out, uint8_t* d_dst, int32_t* d_status,
+                                 hipStream_t st) {
+  if (n_frames <= 0) return;
+  hipLaunchKernelGGL(lz4_decompress_batch_kernel, dim3((unsigned)n_frames), dim3(kWave), 0, st, d_comp, d_frames,
+                     n_frames, d_frame_out, d_dst, d_status);
+}
+
+}  // namespace s3s

@@ -12,7 +12,13 @@ LZ4, NONE = 1, 0
 ADLER, CRC = 1, 2
 
 
-@pytest.fixture(params=[0, 1, 2, 3], ids=["frame-in-lds", "frame-in-global", "ring", "ring-valu"], autouse=True)
+import os
+
+_DEC_IDS = {0: "frame-in-lds", 1: "frame-in-global", 2: "ring", 3: "ring-valu", 4: "batch"}
+_DEC_VARIANTS = [int(x) for x in os.environ.get("S3S_TEST_LZ4_DECODE_VARIANTS", "3,4").split(",")]
+
+
+@pytest.fixture(params=_DEC_VARIANTS, ids=[_DEC_IDS[v] for v in _DEC_VARIANTS], autouse=True)
 def lz4_decode_variant(request, gpu_codec):
     """Every test runs against both decoders (S3S_OPT_LZ4_DECODE_VARIANT)."""
     default = gpu_codec.get_option(5)
