@@ -46,6 +46,10 @@ __device__ __forceinline__ uint32_t g_ld32(const uint8_t* p) {
 __device__ __forceinline__ uint32_t l2_ld8(const uint8_t* p) {
   return (uint32_t)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// four bytes at an arbitrarily aligned address, served by L2 (the bytes were written by this wave's own flush)
+__device__ __forceinline__ uint32_t l2_ld32u(const uint8_t* p) {
+  return l2_ld8(p) | (l2_ld8(p + 1) << 8) | (l2_ld8(p + 2) << 16) | (l2_ld8(p + 3) << 24);
+}
 __device__ __forceinline__ uint32_t lds_ld32(const uint8_t* p) {
   uint32_t v;
   __builtin_memcpy(&v, p, 4);  // gfx950: unaligned ds_read_b32
@@ -177,6 +181,44 @@ __global__ __launch_bounds__(kWave) void lz4_decompress_batch_kernel(
       return true;
     };
 
+    // A match whose output range is known to fit into the window (no slide, `op` untouched): far part from L2,
+    // then the part inside the window, plain or as a periodic pattern.  Arguments uniform.
+    auto copy_match_fit = [&](int ms, int off, int ml) __attribute__((always_inline)) {
+      while (ml > 0) {
+        int k = ml;
+        const int srco = ms - off;
+        uint8_t* d = win + (ms + sh - wb);
+        if (srco + sh < wb) {
+          const int avail = wb - sh - srco;
+          k = k < avail ? k : avail;
+          if (need_drain) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            need_drain = false;
+          }
+          for (int j = lane; j < k; j += kWave) d[j] = (uint8_t)l2_ld8(out + srco + j);
+        } else {
+          const uint8_t* s = win + (srco + sh - wb);
+          if (off >= kWave) {
+            for (int j0 = 0; j0 < k; j0 += kWave) {
+              const int j = j0 + lane;
+              if (j < k) d[j] = s[j];
+            }
+          } else {
+            int idx = lane % off;
+            const int r = kWave % off;
+            for (int j0 = 0; j0 < k; j0 += kWave) {
+              const int j = j0 + lane;
+              if (j < k) d[j] = s[idx];
+              idx += r;
+              idx = idx >= off ? idx - off : idx;
+            }
+          }
+        }
+        ms += k;
+        ml -= k;
+      }
+    };
+
     // ---- the batch: one sequence per lane -------------------------------------------------------------
     auto flush_batch = [&]() __attribute__((always_inline)) -> bool {
       if (nseq == 0) return true;
@@ -264,24 +306,48 @@ __global__ __launch_bounds__(kWave) void lz4_decompress_batch_kernel(
           }
         }
         // ---- matches of [s0, s1) in dependency rounds ----
-        const bool near = mstart - off + sh >= wb;
-        const uint64_t smallm = __ballot(in && ml <= kSmallMl && off >= ml && near);
+        // A "plain" match (source inside the window, not overlapping its destination, <= 64 bytes) whose
+        // source ends at or before the first byte the round writes (dep <= cur) can be copied side by side
+        // with its neighbours: short ones (<= 16 bytes) one LANE per match, up to 64 per round; longer ones
+        // one QUARTER WAVE per match (16 lanes x 4 bytes), four per round.  Anything else goes alone.
+        // (a source entirely in front of the window was flushed long ago: those lanes read it back from L2)
+        const bool near = mstart - off + sh >= wb, far = mstart - off + ml + sh <= wb;
+        const bool plain = in && off >= ml && (near || far) && ml <= kWave;
+        if (need_drain && __ballot(plain && far)) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          need_drain = false;
+        }
+        const uint64_t P64 = __ballot(plain), P16 = __ballot(plain && ml <= kSmallMl);
         int cur = s0;
         while (cur < s1) {
-          const uint64_t okm = __ballot(dep <= cur) & smallm;
-          const uint64_t ok0 = okm >> cur;
-          const int run = (~ok0 == 0ull) ? kWave - cur : __builtin_ctzll(~ok0);
-          if (run >= 2) {
-            // lanes [cur, cur + run): one short match each, sources complete before this round's first byte
-            const bool mine = lane >= cur && lane < cur + run;
+          const uint64_t dok = __ballot(dep <= cur);
+          const uint64_t a64 = (dok & P64) >> cur, a16 = (dok & P16) >> cur;
+          const int run = (~a64 == 0ull) ? kWave - cur : __builtin_ctzll(~a64);
+          const int run16 = (~a16 == 0ull) ? kWave - cur : __builtin_ctzll(~a16);
+          if (run == 0) {
+            // long, overlapping or far: by the whole wave, 64 bytes per step (no slide: the range fits)
+            const int m0 = __builtin_amdgcn_readlane(ml, cur), o0 = __builtin_amdgcn_readlane(off, cur);
+            const int ms0 = __builtin_amdgcn_readlane(mstart, cur);
+            copy_match_fit(ms0, o0, m0);
+            cur++;
+          } else if (run16 >= 4 || run16 == run) {
+            // lanes [cur, cur + run16): one short match each
+            const bool mine = lane >= cur && lane < cur + run16;
             const uint8_t* s = win + (mstart - off + sh - wb);
             uint8_t* d = win + (mstart + sh - wb);
             uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-            if (mine) {
+            if (mine && near) {
               w0 = lds_ld32(s);
               if (ml > 4) w1 = lds_ld32(s + 4);
               if (ml > 8) w2 = lds_ld32(s + 8);
               if (ml > 12) w3 = lds_ld32(s + 12);
+            }
+            if (mine && !near) {
+              const uint8_t* gsrc = out + (mstart - off);
+              w0 = l2_ld32u(gsrc);
+              if (ml > 4) w1 = l2_ld32u(gsrc + 4);
+              if (ml > 8) w2 = l2_ld32u(gsrc + 8);
+              if (ml > 12) w3 = l2_ld32u(gsrc + 12);
             }
             if (mine) {
               if (ml >= 4) lds_st32(d, w0);
@@ -293,19 +359,26 @@ __global__ __launch_bounds__(kWave) void lz4_decompress_batch_kernel(
               if (ml & 2) lds_st16(d + 4 * q, tw);
               if (ml & 1) d[(ml & ~1)] = (uint8_t)(tw >> ((ml & 2) * 8));
             }
-            cur += run;
+            cur += run16;
           } else {
-            // one match by the whole wave
-            const int m0 = __builtin_amdgcn_readlane(ml, cur), o0 = __builtin_amdgcn_readlane(off, cur);
-            const int ms0 = __builtin_amdgcn_readlane(mstart, cur);
-            const int srco = ms0 - o0;
-            if (m0 <= kWave && o0 >= m0 && srco + sh >= wb) {
-              if (lane < m0) win[ms0 + sh - wb + lane] = win[srco + sh - wb + lane];
-            } else {
-              op = ms0;
-              if (!emit_match(o0, m0)) return false;  // (fits: never slides here)
+            // quarter waves: lanes 16g..16g+15 copy match cur+g, four bytes per lane
+            const int g = lane >> 4, b0 = (lane & 15) * 4;
+            const int sq = cur + g;
+            const int msq = __shfl(mstart, sq & 63), ofq = __shfl(off, sq & 63), mlq = __shfl(ml, sq & 63);
+            const int take = run < 4 ? run : 4;
+            if (g < take && b0 < mlq) {
+              const uint32_t w = (msq - ofq + sh >= wb) ? lds_ld32(win + (msq - ofq + sh - wb) + b0)
+                                                        : l2_ld32u(out + (msq - ofq) + b0);
+              uint8_t* d = win + (msq + sh - wb) + b0;
+              const int r = mlq - b0;
+              if (r >= 4) {
+                lds_st32(d, w);
+              } else {
+                if (r & 2) lds_st16(d, w);
+                if (r & 1) d[r & 2] = (uint8_t)(w >> ((r & 2) * 8));
+              }
             }
-            cur++;
+            cur += take;
           }
         }
         op = __builtin_amdgcn_readlane(end, s1 - 1);

@@ -150,40 +150,53 @@ struct Model {
       // literals of [s0, s1): small ones per lane, big ones cooperatively
       for (int s = s0; s < s1; s++)
         for (int j = 0; j < r_lit[s]; j++) L(start[s] + j) = rdc(r_src[s] + j);
-      // matches in dependency rounds
+      // matches in dependency rounds: plain matches (source in the window, no overlap, <= 64 bytes) whose
+      // source ends at or before the round's first output byte go side by side — short ones one lane each,
+      // longer ones one quarter wave each (four per round); anything else alone
       int cur = s0;
       while (cur < s1) {
         const int round_op = mstart[cur];
-        int n = 0;
-        while (cur + n < s1) {
-          const int s = cur + n;
-          const bool ok = r_ml[s] <= kSmallMl && mstart[s] - r_off[s] + r_ml[s] <= round_op &&
-                          mstart[s] - r_off[s] + sh >= wb;
-          if (!ok) {
-            if (r_ml[s] > kSmallMl) st_brk_len++;
-            else if (mstart[s] - r_off[s] + sh < wb) st_brk_far++;
-            else st_brk_dep++;
-            break;
-          }
-          n++;
-        }
-        if (n == 0) {
+        auto ok = [&](int s, int cap) {
+          const bool near = mstart[s] - r_off[s] + sh >= wb, far = mstart[s] - r_off[s] + r_ml[s] + sh <= wb;
+          return s < s1 && r_ml[s] <= cap && r_off[s] >= r_ml[s] && (near || far) &&
+                 mstart[s] - r_off[s] + r_ml[s] <= round_op;
+        };
+        int run = 0, run16 = 0;
+        while (ok(cur + run, W)) run++;
+        while (ok(cur + run16, kSmallMl)) run16++;
+        int take;
+        if (run == 0) {
           st_single++;
           op = mstart[cur];
+          if (r_ml[cur] > W) st_brk_len++;
+          else if (mstart[cur] - r_off[cur] + sh < wb) st_brk_far++;
+          else st_brk_dep++;
           if (!emit_match(r_off[cur], r_ml[cur])) return false;
           cur++;
+          continue;
+        } else if (run16 >= 4 || run16 == run) {
+          take = run16;
         } else {
-          st_rounds++;
-          st_roundseqs += n;
-          // all reads of the round happen before its writes in the kernel; the condition above makes the
-          // order irrelevant (sources end at or before the first byte the round writes)
-          uint8_t tmp[W][kSmallMl];
-          for (int s = cur; s < cur + n; s++)
-            for (int j = 0; j < r_ml[s]; j++) tmp[s][j] = L(mstart[s] - r_off[s] + j);
-          for (int s = cur; s < cur + n; s++)
-            for (int j = 0; j < r_ml[s]; j++) L(mstart[s] + j) = tmp[s][j];
-          cur += n;
+          take = run < 4 ? run : 4;
         }
+        st_rounds++;
+        st_roundseqs += take;
+        // all reads of a round happen before its writes in the kernel; the condition above makes the
+        // order irrelevant (sources end at or before the first byte the round writes)
+        static thread_local uint8_t tmp[W][W];
+        for (int s = cur; s < cur + take; s++)
+          for (int j = 0; j < r_ml[s]; j++) {
+            const int so = mstart[s] - r_off[s] + j;
+            if (mstart[s] - r_off[s] + sh >= wb) {
+              tmp[s][j] = L(so);
+            } else {  // a source in front of the window: read back from `out` (must have been flushed)
+              if (so < 0 || so >= flushed) oob = true;
+              else tmp[s][j] = out[so];
+            }
+          }
+        for (int s = cur; s < cur + take; s++)
+          for (int j = 0; j < r_ml[s]; j++) L(mstart[s] + j) = tmp[s][j];
+        cur += take;
       }
       op = end[s1 - 1];
       s0 = s1;
