@@ -61,7 +61,12 @@ __device__ __forceinline__ void lds_st16(uint8_t* p, uint32_t v) {
   __builtin_memcpy(p, &h, 2);
 }
 
-__global__ __launch_bounds__(kWave) void lz4_decompress_batch_kernel(
+enum { kFmtLz4 = 0, kFmtSnappy = 1 };
+
+// kFmt selects the front end (token parse + byte-wise path); batches, rounds and the output window are the same:
+// a Snappy element is a sequence with either literals only (ml = 0) or a copy only (lit = 0).
+template <int kFmt>
+__global__ __launch_bounds__(kWave) void batch_decode_kernel(
     const uint8_t* __restrict__ comp, const Frame* __restrict__ frames, int32_t n_frames,
     const int64_t* __restrict__ frame_out, uint8_t* dst, int32_t* __restrict__ status) {
   __shared__ __attribute__((aligned(16))) uint8_t win[kBWin + kBPad];
@@ -70,14 +75,34 @@ __global__ __launch_bounds__(kWave) void lz4_decompress_batch_kernel(
   if (f >= n_frames) return;
   const Frame fr = frames[f];
   const int olen = fr.orig_len, clen = fr.comp_len;
-  if (olen == 0) return;
   const int lane = threadIdx.x;
+  if (kFmt == kFmtSnappy && olen > kMaxBlock) {
+    if (lane == 0) atomicExch(status, S3S_E_UNSUPPORTED);
+    return;
+  }
+  if (kFmt == kFmtLz4 && olen == 0) return;
   const uint8_t* c = comp + fr.comp_off;
   uint8_t* out = dst + frame_out[f];
   bool bad = false;
-  if (fr.method != 0x10 && clen > kMaxBlock + kMaxBlock / 255 + 64) {
-    bad = true;  // no LZ4 block of <= 32 KiB is that long (the records below keep stream offsets in 16 bits)
-  } else if (fr.method == 0x10) {  // stored frame
+  int ip_start = 0;
+  if (kFmt == kFmtSnappy) {
+    // preamble: varint32 uncompressed length (scalar, once per block)
+    uint32_t ulen = 0;
+    int vs = 0;
+    for (;;) {
+      if (ip_start >= clen || vs > 28) { bad = true; break; }
+      const uint32_t b = __builtin_amdgcn_readfirstlane((uint32_t)c[ip_start]);
+      ip_start++;
+      ulen |= (b & 0x7fu) << vs;
+      if (!(b & 0x80u)) break;
+      vs += 7;
+    }
+    if (!bad && (int)ulen != olen) bad = true;
+  }
+  if (bad) {
+  } else if (clen > kMaxBlock + kMaxBlock / 6 + 64 && !(kFmt == kFmtLz4 && fr.method == 0x10)) {
+    bad = true;  // no block of <= 32 KiB is that long (the records below keep stream offsets in 16 bits)
+  } else if (kFmt == kFmtLz4 && fr.method == 0x10) {  // stored frame
     for (int j = lane * 4; j < olen; j += kWave * 4) {
       if (j + 4 <= olen) {
         const uint32_t x = g_ld32(c + j);
@@ -88,7 +113,7 @@ __global__ __launch_bounds__(kWave) void lz4_decompress_batch_kernel(
     }
   } else {
     const int sh = (int)(reinterpret_cast<uintptr_t>(out) & 15u);  // window index of output byte o: o + sh - wb
-    int wb = 0, flushed = 0, op = 0, ip = 0, nseq = 0;             // wave-uniform
+    int wb = 0, flushed = 0, op = 0, ip = ip_start, nseq = 0;      // wave-uniform
     bool need_drain = false;  // stores of a flush may still be in flight (matters to far matches only)
 
     // ---- window management ---------------------------------------------------------------------------
@@ -237,11 +262,11 @@ __global__ __launch_bounds__(kWave) void lz4_decompress_batch_kernel(
       }
       end += op;
       const int start = end - lit - ml, mstart = end - ml;
-      const bool wrong = act && (off == 0 || off > mstart || end > olen || src + lit > clen);
+      const bool wrong = act && ((ml > 0 && (off == 0 || off > mstart)) || end > olen || src + lit > clen);
       if (__ballot(wrong)) return false;
       // dep: the first sequence of the batch whose match may start a round that contains this lane's match,
       // i.e. the number of sequences t with mstart[t] < source end (binary search over the sorted mstart)
-      const int srcend = mstart - off + ml;
+      const int srcend = ml > 0 ? mstart - off + ml : 0;  // (a literal-only element depends on nothing)
       int dep = 0;
 #pragma unroll
       for (int step = 32; step >= 1; step >>= 1) {
@@ -266,7 +291,7 @@ __global__ __launch_bounds__(kWave) void lz4_decompress_batch_kernel(
           const int l0 = __builtin_amdgcn_readlane(lit, s0), m0 = __builtin_amdgcn_readlane(ml, s0);
           const int o0 = __builtin_amdgcn_readlane(off, s0), r0 = __builtin_amdgcn_readlane(src, s0);
           if (!emit_literals(r0, l0)) return false;
-          if (!emit_match(o0, m0)) return false;
+          if (m0 > 0 && !emit_match(o0, m0)) return false;
           s0++;
           continue;
         }
@@ -393,6 +418,52 @@ __global__ __launch_bounds__(kWave) void lz4_decompress_batch_kernel(
     auto slow_sequence = [&]() __attribute__((always_inline)) -> int {
       int ips = ip;
       if (ips >= clen) return -1;
+      if constexpr (kFmt == kFmtSnappy) {
+        // one element: literal (length in the tag or in 1-4 bytes behind it) or copy with 1 / 2 / 4 offset bytes
+        const uint32_t tag = __builtin_amdgcn_readfirstlane((uint32_t)c[ips]);
+        ips++;
+        const uint32_t ty = tag & 3u;
+        if (ty == 0u) {
+          uint32_t len = tag >> 2;
+          if (len >= 60u) {
+            const int nb = (int)len - 59;
+            if (clen - ips < nb) return -1;
+            uint32_t v = 0;
+            for (int k = 0; k < nb; k++) v |= __builtin_amdgcn_readfirstlane((uint32_t)c[ips + k]) << (8 * k);
+            ips += nb;
+            len = v;
+            if (len >= 0x7fffffffu) return -1;
+          }
+          const int n = (int)len + 1;
+          if (n > clen - ips || n > olen - op) return -1;
+          if (!emit_literals(ips, n)) return -1;
+          ip = ips + n;
+          return 0;
+        }
+        int len, off;
+        if (ty == 1u) {
+          if (clen - ips < 1) return -1;
+          len = 4 + (int)((tag >> 2) & 7u);
+          off = (int)(((tag >> 5) << 8) | __builtin_amdgcn_readfirstlane((uint32_t)c[ips]));
+          ips += 1;
+        } else if (ty == 2u) {
+          if (clen - ips < 2) return -1;
+          len = (int)(tag >> 2) + 1;
+          off = (int)__builtin_amdgcn_readfirstlane((uint32_t)c[ips] | ((uint32_t)c[ips + 1] << 8));
+          ips += 2;
+        } else {
+          if (clen - ips < 4) return -1;
+          len = (int)(tag >> 2) + 1;
+          const uint32_t o4 = __builtin_amdgcn_readfirstlane((uint32_t)c[ips] | ((uint32_t)c[ips + 1] << 8) |
+                                                              ((uint32_t)c[ips + 2] << 16) | ((uint32_t)c[ips + 3] << 24));
+          if (o4 > 0x7fffffffu) return -1;
+          off = (int)o4;
+          ips += 4;
+        }
+        ip = ips;
+        if (!emit_match(off, len)) return -1;
+        return 0;
+      }
       const uint32_t token = __builtin_amdgcn_readfirstlane((uint32_t)c[ips]);
       ips++;
       int lit = (int)(token >> 4);
@@ -431,53 +502,91 @@ __global__ __launch_bounds__(kWave) void lz4_decompress_batch_kernel(
 
     // ---- main loop: parse windows of 64 stream bytes ---------------------------------------------------
     for (;;) {
-      if (ip >= clen) { bad = true; break; }
-      const int cpos = ip + lane;
+      bool eob = false;
       bool cx = true;
       int nxt = 0;
       uint32_t r0 = 0, r1 = 0;
-      if (cpos + 4 <= clen) {
-        const uint32_t d0 = g_ld32(c + cpos);
-        const uint32_t tok = d0 & 0xffu, b1 = (d0 >> 8) & 0xffu;
-        int lit = (int)(tok >> 4), hdr = 1;
-        bool complex_ = false;
-        if (lit == 15) {
-          lit += (int)b1;
-          hdr = 2;
-          complex_ = b1 == 255u;
-        }
-        const int p2 = cpos + hdr + lit;
-        if (p2 + 4 <= clen) {
-          const uint32_t d1 = g_ld32(c + p2);
-          int ml = (int)(tok & 15u), adv = 2;
-          if (ml == 15) {
-            const uint32_t e = (d1 >> 16) & 0xffu;
-            ml += (int)e;
-            adv = 3;
-            complex_ = complex_ || e == 255u;
+      if (ip >= clen) {
+        // LZ4 blocks end inside the byte-wise path (last sequence: literals only); Snappy blocks end here
+        if (kFmt == kFmtLz4 || ip > clen) { bad = true; break; }
+        eob = true;
+      } else {
+        const int cpos = ip + lane;
+        if (cpos + 4 <= clen) {
+          const uint32_t d0 = g_ld32(c + cpos);
+          if constexpr (kFmt == kFmtSnappy) {
+            const uint32_t tag = d0 & 0xffu, ty = tag & 3u, n6 = tag >> 2;
+            if (ty == 0u) {
+              int len = (int)n6 + 1, hdr = 1;
+              if (n6 == 60u) {
+                len = (int)((d0 >> 8) & 0xffu) + 1;
+                hdr = 2;
+              } else if (n6 == 61u) {
+                len = (int)((d0 >> 8) & 0xffffu) + 1;
+                hdr = 3;
+              }
+              nxt = cpos + hdr + len;
+              cx = n6 > 61u || nxt > clen || len > kMaxBlock;
+              r0 = (uint32_t)len;
+              r1 = (uint32_t)(cpos + hdr) << 16;
+            } else if (ty == 1u) {
+              nxt = cpos + 2;
+              cx = false;
+              r0 = (4u + (n6 & 7u)) << 16;
+              r1 = ((tag >> 5) << 8) | ((d0 >> 8) & 0xffu);
+            } else if (ty == 2u) {
+              nxt = cpos + 3;
+              cx = false;
+              r0 = (n6 + 1u) << 16;
+              r1 = (d0 >> 8) & 0xffffu;
+            }
+          } else {
+            const uint32_t tok = d0 & 0xffu, b1 = (d0 >> 8) & 0xffu;
+            int lit = (int)(tok >> 4), hdr = 1;
+            bool complex_ = false;
+            if (lit == 15) {
+              lit += (int)b1;
+              hdr = 2;
+              complex_ = b1 == 255u;
+            }
+            const int p2 = cpos + hdr + lit;
+            if (p2 + 4 <= clen) {
+              const uint32_t d1 = g_ld32(c + p2);
+              int ml = (int)(tok & 15u), adv = 2;
+              if (ml == 15) {
+                const uint32_t e = (d1 >> 16) & 0xffu;
+                ml += (int)e;
+                adv = 3;
+                complex_ = complex_ || e == 255u;
+              }
+              cx = complex_;
+              nxt = p2 + adv;
+              r0 = (uint32_t)lit | ((uint32_t)(ml + 4) << 16);
+              r1 = (d1 & 0xffffu) | ((uint32_t)(cpos + hdr) << 16);
+            }
           }
-          cx = complex_;
-          nxt = p2 + adv;
-          r0 = (uint32_t)lit | ((uint32_t)(ml + 4) << 16);
-          r1 = (d1 & 0xffffu) | ((uint32_t)(cpos + hdr) << 16);
         }
       }
-      const uint64_t CX = __ballot(cx);
+      // scalar walk over the chain of real tokens: lane `rel` holds the window-relative position of the
+      // token behind it, or -1 if the byte-wise path has to take it
+      const int nrel = cx ? -1 : nxt - ip;
       uint64_t mask = 0;
-      int cur = ip;
+      int rel = 0;
       for (;;) {
-        const int rel = cur - ip;
-        if (rel >= kWave) break;
-        if ((CX >> rel) & 1ull) break;
+        const int n = __builtin_amdgcn_readlane(nrel, rel);
+        if (n < 0) break;
         mask |= 1ull << rel;
-        cur = __builtin_amdgcn_readlane(nxt, rel);
+        rel = n;
+        if (rel >= kWave) break;
       }
+      const int cur = ip + rel;
       const int cnt = __builtin_popcountll(mask);
       // the batch is flushed when this window's sequences do not fit any more, and in front of every
       // sequence of the byte-wise path (so in particular in front of the block's last sequence)
       if (mask == 0ull || nseq + cnt > kWave) {
         if (!flush_batch()) { bad = true; break; }
       }
+      if (eob) break;
       if (mask == 0ull) {
         const int r = slow_sequence();
         if (r < 0) { bad = true; break; }
@@ -499,52 +608,75 @@ __global__ __launch_bounds__(kWave) void lz4_decompress_batch_kernel(
     if (lane == 0) atomicExch(status, S3S_E_BAD_FRAME);
     return;
   }
-  // ---- frame check: xxHash32 of the decoded block, re-read from L2 -----------------------------------
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  {
-    const uint32_t seed = kLz4BlockSeed;
-    uint32_t acc = lane == 0 ? seed + XP1 + XP2 : lane == 1 ? seed + XP2 : lane == 2 ? seed : seed - XP1;
-    const int stripes = olen >> 4;
-    const int nblk = olen >> 8;
-    auto ld32o = [&](int byte_pos) -> uint32_t {
-      uint32_t x;
-      __builtin_memcpy(&x, out + byte_pos, 4);
-      return x;
-    };
-    uint32_t curw = nblk > 0 ? ld32o(4 * lane) : 0u;
-    for (int bk = 0; bk < nblk; bk++) {
-      const uint32_t nx = bk + 1 < nblk ? ld32o(256 * (bk + 1) + 4 * lane) : 0u;
-#pragma unroll
-      for (int j = 0; j < 16; j++) {
-        const uint32_t wv = (uint32_t)__shfl((int)curw, 4 * j + (lane & 3));
-        acc = rotl32(acc + wv * XP2, 13) * XP1;
-      }
-      curw = nx;
-    }
-    for (int j = nblk * 16; j < stripes; j++) {
-      const uint32_t wv = ld32o(16 * j + 4 * (lane & 3));
-      acc = rotl32(acc + wv * XP2, 13) * XP1;
-    }
-    uint32_t h;
-    if (olen >= 16) {
-      const uint32_t v1 = __builtin_amdgcn_readlane(acc, 0), v2 = __builtin_amdgcn_readlane(acc, 1),
-                     v3 = __builtin_amdgcn_readlane(acc, 2), v4 = __builtin_amdgcn_readlane(acc, 3);
-      h = rotl32(v1, 1) + rotl32(v2, 7) + rotl32(v3, 12) + rotl32(v4, 18);
-    } else {
-      h = seed + XP5;
-    }
-    h += (uint32_t)olen;
-    int p = stripes << 4;
-    for (; p + 4 <= olen; p += 4) h = rotl32(h + ld32o(p) * XP3, 17) * XP4;
-    for (; p < olen; p++) h = rotl32(h + (uint32_t)out[p] * XP5, 11) * XP1;
-    h ^= h >> 15;
-    h *= XP2;
-    h ^= h >> 13;
-    h *= XP3;
-    h ^= h >> 16;
-    if (lane == 0 && (h & 0x0FFFFFFFu) != fr.check) atomicExch(status, S3S_E_BAD_FRAME);
+}
+
+// ---- frame checks: xxHash32 of every decoded block, four lanes per frame ------------------------------
+// xxHash32 has four accumulators, each a serial multiply chain over every fourth dword — a wavefront per
+// frame keeps four lanes busy and pays two quarter-rate 32-bit multiplies per 16 bytes on all 64.  Here a
+// wavefront checks 16 frames at once (lane = 4 * frame-in-wave + accumulator); the blocks were written
+// moments ago by the decode kernel on the same stream, so they come out of L2 / MALL.
+__global__ __launch_bounds__(kWave) void lz4_verify_frames_kernel(
+    const Frame* __restrict__ frames, int32_t n_frames, const int64_t* __restrict__ frame_out,
+    const uint8_t* __restrict__ dst, int32_t* __restrict__ status) {
+  const int f = blockIdx.x * (kWave / 4) + (threadIdx.x >> 2);
+  const int l = threadIdx.x & 3;
+  int len = 0;
+  uint32_t want = 0;
+  const uint8_t* g = dst;
+  if (f < n_frames) {
+    const Frame fr = frames[f];
+    len = fr.orig_len;
+    want = fr.check;
+    g = dst + frame_out[f];
   }
+  const uint32_t seed = kLz4BlockSeed;
+  uint32_t acc = l == 0 ? seed + XP1 + XP2 : l == 1 ? seed + XP2 : l == 2 ? seed : seed - XP1;
+  const int stripes = len >> 4;
+  const uint8_t* q = g + 4 * l;
+  // 24 stripes per iteration in three register sets, each requested two multiply chains (16 stripes) before
+  // it is consumed; loads past the frame's last stripe are clamped and their values skipped
+  if (stripes > 0) {
+    const int last = stripes - 1;
+    uint32_t s0[8], s1[8], s2[8];
+    auto fetch = [&](uint32_t (&w)[8], int j0) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int jj = j0 + u;
+        w[u] = g_ld32(q + 16 * (jj < last ? jj : last));
+      }
+    };
+    auto fold = [&](const uint32_t (&w)[8], int j0) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const uint32_t nacc = rotl32(acc + w[u] * XP2, 13) * XP1;
+        acc = j0 + u < stripes ? nacc : acc;
+      }
+    };
+    fetch(s0, 0);
+    fetch(s1, 8);
+    for (int j = 0; j < stripes; j += 24) {
+      fetch(s2, j + 16);
+      fold(s0, j);
+      fetch(s0, j + 24);
+      fold(s1, j + 8);
+      fetch(s1, j + 32);
+      fold(s2, j + 16);
+    }
+  }
+  const int g0 = (threadIdx.x & 63) & ~3;
+  const uint32_t v1 = __shfl(acc, g0), v2 = __shfl(acc, g0 + 1), v3 = __shfl(acc, g0 + 2), v4 = __shfl(acc, g0 + 3);
+  if (len == 0 || l != 0) return;
+  uint32_t h = len >= 16 ? rotl32(v1, 1) + rotl32(v2, 7) + rotl32(v3, 12) + rotl32(v4, 18) : seed + XP5;
+  h += (uint32_t)len;
+  int p = stripes << 4;
+  for (; p + 4 <= len; p += 4) h = rotl32(h + g_ld32(g + p) * XP3, 17) * XP4;
+  for (; p < len; p++) h = rotl32(h + (uint32_t)g[p] * XP5, 11) * XP1;
+  h ^= h >> 15;
+  h *= XP2;
+  h ^= h >> 13;
+  h *= XP3;
+  h ^= h >> 16;
+  if ((h & 0x0FFFFFFFu) != want) atomicExch(status, S3S_E_BAD_FRAME);
 }
 
 }  // namespace
@@ -553,7 +685,17 @@ void launch_lz4_decompress_batch(const uint8_t* d_comp, const Frame* d_frames, i
                                  const int64_t* d_frame_out, uint8_t* d_dst, int32_t* d_status,
                                  hipStream_t st) {
   if (n_frames <= 0) return;
-  hipLaunchKernelGGL(lz4_decompress_batch_kernel, dim3((unsigned)n_frames), dim3(kWave), 0, st, d_comp, d_frames,
+  hipLaunchKernelGGL(batch_decode_kernel<kFmtLz4>, dim3((unsigned)n_frames), dim3(kWave), 0, st, d_comp, d_frames,
+                     n_frames, d_frame_out, d_dst, d_status);
+  hipLaunchKernelGGL(lz4_verify_frames_kernel, dim3((unsigned)((n_frames + kWave / 4 - 1) / (kWave / 4))), dim3(kWave),
+                     0, st, d_frames, n_frames, d_frame_out, d_dst, d_status);
+}
+
+void launch_snappy_decompress_batch(const uint8_t* d_comp, const Frame* d_frames, int32_t n_frames,
+                                    const int64_t* d_frame_out, uint8_t* d_dst, int32_t* d_status,
+                                    hipStream_t st) {
+  if (n_frames <= 0) return;
+  hipLaunchKernelGGL(batch_decode_kernel<kFmtSnappy>, dim3((unsigned)n_frames), dim3(kWave), 0, st, d_comp, d_frames,
                      n_frames, d_frame_out, d_dst, d_status);
 }
 

@@ -44,7 +44,7 @@ struct s3s_ctx {
   double auto_ms_per_mib[2] = {0, 0};
   int lz4_variant_used = 0;  // the parse the last LZ4 compress call ran (S3S_OPT_LZ4_VARIANT_USED)
   hipEvent_t ev_auto[2] = {nullptr, nullptr};
-  int lz4_decode_variant = 3;
+  int lz4_decode_variant = 4;  // 4 = batch decoder (lz4_decode_batch.hip), 3 = ring decoder on the vector ALU
   int snappy_variant = 1;
   s3s::DevBuf buf[s3s::B_COUNT];
   void* h_stage = nullptr;  // pinned

@@ -107,6 +107,9 @@ void launch_lz4_decompress(const uint8_t* d_comp, const Frame* d_frames, int32_t
 void launch_lz4_decompress_batch(const uint8_t* d_comp, const Frame* d_frames, int32_t n_frames,
                                  const int64_t* d_frame_out, uint8_t* d_dst, int32_t* d_status,
                                  hipStream_t st);
+void launch_snappy_decompress_batch(const uint8_t* d_comp, const Frame* d_frames, int32_t n_frames,
+                                    const int64_t* d_frame_out, uint8_t* d_dst, int32_t* d_status,
+                                    hipStream_t st);
 // Snappy (SnappyInputStream framing): chunks are chained by their i32 BE length only, so the walk
 // is one lane per partition (each non-empty partition is one or more complete streams, each
 // starting with the 16-byte header).  Pass 1 counts, pass 2 (after a scan of the counts) writes

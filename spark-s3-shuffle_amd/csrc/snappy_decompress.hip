@@ -410,6 +410,10 @@ void launch_snappy_decompress(const uint8_t* d_comp, const Frame* d_frames, int3
                               const int64_t* d_frame_out, uint8_t* d_dst, int32_t* d_status,
                               int variant, hipStream_t st) {
   if (n_frames <= 0) return;
+  if (variant == 4) {  // batch decoder (lz4_decode_batch.hip, Snappy front end)
+    launch_snappy_decompress_batch(d_comp, d_frames, n_frames, d_frame_out, d_dst, d_status, st);
+    return;
+  }
   if (variant != 0) {
     hipLaunchKernelGGL(snappy_decompress_valu_kernel, dim3((unsigned)n_frames), dim3(kWave), 0, st, d_comp,
                        d_frames, n_frames, d_frame_out, d_dst, d_status);

@@ -36,6 +36,7 @@ struct Model {
   int flushed = 0;  // output offset of the first byte not yet written to `out`
   int op = 0;       // output offset of the next byte to produce
   int ip = 0;       // stream offset of the next token
+  int fmt = 0;      // 0 = LZ4 block, 1 = raw Snappy block (varint length + elements)
   // batch records (one per lane)
   int r_lit[W], r_ml[W], r_off[W], r_src[W];
   int nseq = 0;
@@ -127,7 +128,7 @@ struct Model {
       acc += r_lit[s] + r_ml[s];
       end[s] = acc;
       // validation: offset, source not before the block, output not past olen
-      if (r_off[s] == 0 || r_off[s] > mstart[s] || end[s] > olen) bad = true;
+      if ((r_ml[s] > 0 && (r_off[s] == 0 || r_off[s] > mstart[s])) || end[s] > olen) bad = true;
       if (r_src[s] + r_lit[s] > clen) bad = true;
     }
     if (bad) return false;
@@ -143,7 +144,7 @@ struct Model {
         }
         // one sequence larger than the free part of a freshly slid window: generic emitters
         if (!emit_literals(r_src[s0], r_lit[s0])) return false;
-        if (!emit_match(r_off[s0], r_ml[s0])) return false;
+        if (r_ml[s0] > 0 && !emit_match(r_off[s0], r_ml[s0])) return false;
         s0++;
         continue;
       }
@@ -158,6 +159,7 @@ struct Model {
         const int round_op = mstart[cur];
         auto ok = [&](int s, int cap) {
           const bool near = mstart[s] - r_off[s] + sh >= wb, far = mstart[s] - r_off[s] + r_ml[s] + sh <= wb;
+          if (s < s1 && r_ml[s] == 0) return true;  // a literal-only element depends on nothing
           return s < s1 && r_ml[s] <= cap && r_off[s] >= r_ml[s] && (near || far) &&
                  mstart[s] - r_off[s] + r_ml[s] <= round_op;
         };
@@ -211,6 +213,49 @@ struct Model {
     st_slow++;
     int ips = ip;
     if (ips >= clen) return -1;
+    if (fmt == 1) {
+      const uint32_t tag = rdc(ips++);
+      const uint32_t ty = tag & 3u;
+      if (ty == 0u) {
+        uint32_t len = tag >> 2;
+        if (len >= 60u) {
+          const int nb = (int)len - 59;
+          if (clen - ips < nb) return -1;
+          uint32_t v = 0;
+          for (int k = 0; k < nb; k++) v |= (uint32_t)rdc(ips + k) << (8 * k);
+          ips += nb;
+          len = v;
+          if (len >= 0x7fffffffu) return -1;
+        }
+        const int n = (int)len + 1;
+        if (n > clen - ips || n > olen - op) return -1;
+        if (!emit_literals(ips, n)) return -1;
+        ip = ips + n;
+        return 0;
+      }
+      int len, off;
+      if (ty == 1u) {
+        if (clen - ips < 1) return -1;
+        len = 4 + (int)((tag >> 2) & 7u);
+        off = (int)(((tag >> 5) << 8) | rdc(ips));
+        ips += 1;
+      } else if (ty == 2u) {
+        if (clen - ips < 2) return -1;
+        len = (int)(tag >> 2) + 1;
+        off = (int)rdc(ips) | ((int)rdc(ips + 1) << 8);
+        ips += 2;
+      } else {
+        if (clen - ips < 4) return -1;
+        len = (int)(tag >> 2) + 1;
+        const uint32_t o4 = (uint32_t)rdc(ips) | ((uint32_t)rdc(ips + 1) << 8) | ((uint32_t)rdc(ips + 2) << 16) | ((uint32_t)rdc(ips + 3) << 24);
+        if (o4 > 0x7fffffffu) return -1;
+        off = (int)o4;
+        ips += 4;
+      }
+      ip = ips;
+      if (!emit_match(off, len)) return -1;
+      return 0;
+    }
     const uint32_t token = rdc(ips++);
     int lit = (int)(token >> 4);
     if (lit == 15) {
@@ -245,10 +290,25 @@ struct Model {
   }
 
   int run() {
-    if (olen == 0) return clen == 1 && c[0] == 0 ? 0 : -1;  // (the frame layer never sends empty blocks)
+    if (fmt == 0 && olen == 0) return clen == 1 && c[0] == 0 ? 0 : -1;  // (the frame layer never sends empty blocks)
+    if (fmt == 1) {  // preamble: varint32 uncompressed length
+      uint32_t ulen = 0;
+      int vs = 0;
+      for (;;) {
+        if (ip >= clen || vs > 28) return -1;
+        const uint32_t b = rdc(ip++);
+        ulen |= (b & 0x7fu) << vs;
+        if (!(b & 0x80u)) break;
+        vs += 7;
+      }
+      if ((int)ulen != olen) return -1;
+    }
     for (;;) {
-      if (ip >= clen) return -1;
-      if (nseq > W - 22 && !flush_batch()) return -1;
+      if (ip >= clen) {
+        if (fmt == 0 || ip > clen) return -1;
+        if (!flush_batch()) return -1;  // Snappy blocks end here
+        break;
+      }
       st_windows++;
       // ---- speculative parse: lane i assumes a token at stream byte ip + i ----------------------------
       int nxt[W], p_lit[W], p_ml[W], p_off[W], p_src[W];
@@ -260,6 +320,30 @@ struct Model {
         p_lit[i] = p_ml[i] = p_off[i] = p_src[i] = 0;
         if (cpos + 4 > clen) continue;  // the kernel clamps the load address and marks the lane complex
         const uint32_t d0 = rdc32(cpos);
+        if (fmt == 1) {
+          const uint32_t tag = d0 & 0xffu, ty = tag & 3u, n6 = tag >> 2;
+          if (ty == 0u) {
+            int len = (int)n6 + 1, hdr = 1;
+            if (n6 == 60u) { len = (int)((d0 >> 8) & 0xffu) + 1; hdr = 2; }
+            else if (n6 == 61u) { len = (int)((d0 >> 8) & 0xffffu) + 1; hdr = 3; }
+            if (n6 > 61u || cpos + hdr + len > clen || len > 32768) continue;
+            cx[i] = false;
+            p_lit[i] = len;
+            p_src[i] = cpos + hdr;
+            nxt[i] = cpos + hdr + len;
+          } else if (ty == 1u) {
+            cx[i] = false;
+            p_ml[i] = 4 + (int)(n6 & 7u);
+            p_off[i] = (int)(((tag >> 5) << 8) | ((d0 >> 8) & 0xffu));
+            nxt[i] = cpos + 2;
+          } else if (ty == 2u) {
+            cx[i] = false;
+            p_ml[i] = (int)n6 + 1;
+            p_off[i] = (int)((d0 >> 8) & 0xffffu);
+            nxt[i] = cpos + 3;
+          }
+          continue;
+        }
         const uint32_t tok = d0 & 0xffu, b1 = (d0 >> 8) & 0xffu;
         int lit = (int)(tok >> 4), hdr = 1;
         bool complex_ = false;
@@ -296,6 +380,7 @@ struct Model {
         mask |= 1ull << rel;
         cur = nxt[rel];
       }
+      if (mask != 0 && nseq + __builtin_popcountll(mask) > W && !flush_batch()) return -1;
       if (mask == 0) {  // the token at ip itself is complex
         if (!flush_batch()) return -1;
         const int r = slow_sequence();
@@ -324,10 +409,19 @@ struct Model {
 
 }  // namespace
 
+extern "C" int batch_decode_model(int fmt, const uint8_t* comp, int clen, uint8_t* out, int olen, int out_misalign,
+                                  long* stats);
+
 extern "C" int lz4_batch_decode_model(const uint8_t* comp, int clen, uint8_t* out, int olen, int out_misalign,
                                       long* stats) {
+  return batch_decode_model(0, comp, clen, out, olen, out_misalign, stats);
+}
+
+extern "C" int batch_decode_model(int fmt, const uint8_t* comp, int clen, uint8_t* out, int olen, int out_misalign,
+                                  long* stats) {
   static thread_local Model m;
   m = Model();
+  m.fmt = fmt;
   m.c = comp;
   m.clen = clen;
   m.out = out;

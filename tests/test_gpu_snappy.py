@@ -12,7 +12,7 @@ SNAPPY = 2
 ADLER, CRC = 1, 2
 
 
-@pytest.fixture(params=[(0, 0), (3, 1)], ids=["batch+block-in-lds", "window+ring-valu"], autouse=True)
+@pytest.fixture(params=[(3, 0), (4, 1)], ids=["general+ring-valu", "window+batch-decoder"], autouse=True)
 def variants(request, gpu_codec):
     """Every test runs against both Snappy decoders (S3S_OPT_LZ4_DECODE_VARIANT: 0 / non-zero) and
     both compressor paths (S3S_OPT_SNAPPY_VARIANT: 0 general batch only / 1 exact windows first)."""
