@@ -93,24 +93,18 @@ enum {
                                     supported 1024..32768 (snappy-java raises smaller values
                                     to 1024) */
   S3S_OPT_PROFILE = 3,           /* 1: record per-stage HIP-event timings (s3s_stage_ms) */
-  S3S_OPT_LZ4_VARIANT = 4,       /* tuning, identical output: 0 = chunk staged in LDS (3 wavefronts per CU),
-                                    1 = chunk read through L1/L2, table-only LDS (10 per CU), general batch
-                                    only, 2 (default) = 1 + exact-window parse in front of the batch
-                                    (several sequences per memory round trip, plain sequences in straight-line
-                                    steps: 1.6x on match-dense rows, 0.97x on TeraSort records single-stream,
-                                    1.02x with two task threads),
-                                    3 = 2 software-pipelined, 4 = 3 with the run loop on the vector ALU,
-                                    5 = 1 with the frame check fused in, 6 / 7 = 1 at 5 / 7 wavefronts per
-                                    CU (occupancy experiments), 9 = auto: the context times 1 and 2 on its
-                                    first large map outputs (1, 2, 1, 2), keeps the faster and re-measures
-                                    the other every 32nd call */
-  S3S_OPT_LZ4_VARIANT_USED = 7,  /* read-only: the parse (1 or 2 under auto) the last LZ4 compress call ran */
+  S3S_OPT_LZ4_VARIANT = 4,       /* tuning, identical output: 1 = general batch only (64 probes of the greedy
+                                    parse per step), 10 (default) = lean exact 64-byte windows in front of
+                                    it (one candidate gather per window, several sequences per round trip),
+                                    9 = auto: the context times 1 and 10 on its first large map outputs
+                                    (1, 10, 1, 10), keeps the faster and re-measures the other every 32nd
+                                    call.  Other values are refused. */
+  S3S_OPT_LZ4_VARIANT_USED = 7,  /* read-only: the parse (1 or 10) the last LZ4 compress call ran */
   S3S_OPT_SNAPPY_VARIANT = 6,    /* tuning, identical output: 0 = general batch only, 1 (default) = exact
                                     64-byte windows in front of it (several copies per round trip) */
-  S3S_OPT_LZ4_DECODE_VARIANT = 5 /* tuning, identical output (Snappy: 0 = staged in LDS, else the
-                                    VALU ring decoder): 0 = frame staged in LDS, 1 = decoded
-                                    straight to global memory, 2 = 1 + 8 KiB LDS ring of recent
-                                    output, 3 (default) = 2 with the parse on the vector ALU */
+  S3S_OPT_LZ4_DECODE_VARIANT = 5 /* tuning, identical output, LZ4 and Snappy: 4 (default) = batch decoder
+                                    (one sequence per lane, dependency rounds, sliding LDS output window),
+                                    3 = ring decoder (one sequence per step, parse on the vector ALU) */
 };
 
 /* stages reported by s3s_stage_ms (valid after a call made with S3S_OPT_PROFILE=1) */

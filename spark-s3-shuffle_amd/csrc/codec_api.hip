@@ -112,7 +112,7 @@ int s3s_set_option(s3s_ctx* ctx, int key, int64_t value) {
       ctx->profile = value != 0;
       return S3S_OK;
     case S3S_OPT_LZ4_DECODE_VARIANT:
-      if (value < 0 || value > 4) return fail(ctx, S3S_E_INVALID, "lz4 decode variant must be 0..4");
+      if (value != 3 && value != 4) return fail(ctx, S3S_E_INVALID, "decode variant must be 3 (ring decoder) or 4 (batch decoder)");
       ctx->lz4_decode_variant = (int)value;
       return S3S_OK;
     case S3S_OPT_SNAPPY_VARIANT:
@@ -120,7 +120,7 @@ int s3s_set_option(s3s_ctx* ctx, int key, int64_t value) {
       ctx->snappy_variant = (int)value;
       return S3S_OK;
     case S3S_OPT_LZ4_VARIANT:
-      if (value < 0 || value > 10 || value == 8) return fail(ctx, S3S_E_INVALID, "lz4 variant must be 0..7, 9 (auto) or 10");
+      if (value != 1 && value != 9 && value != 10) return fail(ctx, S3S_E_INVALID, "lz4 variant must be 1 (general batch), 10 (exact windows) or 9 (auto)");
       ctx->lz4_variant = (int)value;
       ctx->auto_samples[0] = ctx->auto_samples[1] = 0;
       ctx->auto_tick = 0;
@@ -297,11 +297,11 @@ static int compress_core(s3s_ctx* ctx, int codec, int checksum_algo, const uint8
         if (total_u >= kAutoMinBytes) {  // large enough for the kernel time to mean something
           auto_timed = true;
           if (ctx->auto_samples[0] < 2 || ctx->auto_samples[1] < 2)
-            auto_which = ctx->auto_samples[0] <= ctx->auto_samples[1] ? 0 : 1;  // 1, 2, 1, 2
+            auto_which = ctx->auto_samples[0] <= ctx->auto_samples[1] ? 0 : 1;  // 1, 10, 1, 10
           else if (++ctx->auto_tick % 32 == 0)
             auto_which = 1 - ctx->auto_choice;  // keep the other one's figure fresh
         }
-        variant = auto_which ? 2 : 1;
+        variant = auto_which ? 10 : 1;
         if (auto_timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_auto[0], ctx->stream));
       }
       ctx->lz4_variant_used = variant;
@@ -513,7 +513,7 @@ int s3s_compress_map_outputs_batch_device(s3s_ctx* ctx, int codec, int checksum_
   record(ctx, 0);
   // ---- ONE codec launch over every task's chunks ---------------------------------------------------------
   if (codec == S3S_CODEC_LZ4) {
-    const int variant = ctx->lz4_variant == 9 ? 2 : ctx->lz4_variant;
+    const int variant = ctx->lz4_variant == 9 ? 10 : ctx->lz4_variant;
     ctx->lz4_variant_used = variant;
     launch_lz4_compress(base, dev<Item>(ctx, B_ITEMS), n_items, dev<uint32_t>(ctx, B_ITEM_CHECK),
                         dev<uint8_t>(ctx, B_SLOTS), dev<uint32_t>(ctx, B_ITEM_SIZE), variant, ctx->stream,

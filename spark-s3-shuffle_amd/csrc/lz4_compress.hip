@@ -7,26 +7,23 @@
 // single-pass parse of LZ4_compress_generic(byU16, acceleration 1) exactly, including its
 // hash-table update order, skip schedule, backward catch-up and end-of-block rules.
 //
-// One wavefront per chunk.  The sequential probe loop of the CPU code is evaluated 64
-// positions at a time: lane i takes the i-th position of the deterministic "no match yet"
-// schedule, hashes it, reads the 8192 x u16 table (LDS), and ALL lanes insert speculatively
-// with one ds_write.  A readback tells every lane whether it lost a same-slot race (=> some
-// lane in the batch shares its hash); the first such lane bounds the prefix in which the
-// pre-batch table entries are the true candidates ("cut").  The first lane below the cut
-// whose candidate matches wins (ballot + ctz); lanes after it undo their inserts, so the
-// table state is exactly the sequential one.  Match extension is cooperative: 256 B forward /
-// 64 B backward per memory round trip.  Which lane wins a same-address LDS store is
-// irrelevant to the result (tests/model/lz4_wave_model.cpp proves it under adversarial
-// orders).
-//
-// Two placements of the chunk bytes, same parse (template parameter):
-//   kInLds   chunk staged in LDS (32 KiB + 16 KiB table -> 3 wavefronts per CU)
-//   kInL2    chunk read in place through L1/L2 (16 KiB table only -> 10 wavefronts per CU);
-//            the parse is issue/latency bound, so resident wavefronts are what buy throughput
-// The frame's xxHash32 is computed by a separate streaming kernel (16 chunks per wavefront).
-// Output: token/literal/offset bytes go straight to the chunk's slot in HBM; compressed output
-// never exceeds the chunk length (anything longer is stored RAW by the frame rule
-// compressedLength >= originalLength), so a slot is 32 B + 32 KiB.
+// One wavefront per 32 KiB chunk; the chunk is read in place through L1/L2 and only the 8192 x u16 hash table
+// lives in LDS (16 KiB -> 10 wavefronts per CU: the parse is issue / latency bound, so resident wavefronts are
+// what buy throughput).  Two parses, same bytes:
+//   general batch (kWindows = false, S3S_OPT_LZ4_VARIANT 1)  the sequential probe loop 64 probes at a time:
+//       lane i takes the i-th position of the deterministic "no match yet" schedule, hashes it, reads the table
+//       and ALL lanes insert speculatively with one ds_write.  A readback tells every lane whether it lost a
+//       same-slot race; the first such lane bounds the clean prefix, the first matching lane below it wins
+//       (ballot + ctz), lanes behind it undo their inserts.  Match extension is cooperative (256 B forward /
+//       64 B backward per memory round trip).  tests/model/lz4_wave_model.cpp proves that which lane wins a
+//       same-address LDS store is irrelevant.
+//   lean exact windows (kWindows = true, variant 10, default)  in front of the general batch: aligned 64-byte
+//       windows resolved with scalar mask arithmetic (see below; tests/model/lz4_window_model.cpp).
+// Earlier experiments (chunk staged in LDS, pipelined windows, run loop on the vector ALU, fused frame hash,
+// occupancy probes: variants 0, 2-7 of round 1) are in the git history and DESIGN.md §6, not in the product.
+// The frame's xxHash32 is computed by a separate streaming kernel.  Output: token / literal / offset bytes go
+// straight to the chunk's slot in HBM; compressed output never exceeds the chunk length (anything longer is
+// stored RAW by the frame rule compressedLength >= originalLength), so a slot is 32 B + 32 KiB.
 #include "s3s_internal.h"
 
 #ifdef S3S_LZ4_TIMING
@@ -41,7 +38,6 @@ __device__ unsigned long long g_lz4_dbg[32];
 namespace s3s {
 namespace {
 
-constexpr int kLdsSlack = 320;  // cooperative compares over-read at most 4*63+3+7 bytes
 constexpr int kMfLimit = 12, kLastLiterals = 5, kMinMatch = 4;
 
 __device__ __forceinline__ uint32_t hash13(uint32_t v) { return (v * 2654435761u) >> 19; }
@@ -56,16 +52,6 @@ __device__ __forceinline__ int sched_S(int t) {
 }
 
 // ---- chunk byte sources -------------------------------------------------------------------
-struct SrcLds {  // chunk staged in LDS
-  static constexpr bool kClamp = false;  // the LDS copy has kLdsSlack bytes of slack
-  const uint8_t* base;
-  __device__ __forceinline__ uint32_t rd32(int pos) const {
-    uint32_t v;
-    __builtin_memcpy(&v, base + pos, 4);  // gfx950: unaligned ds_read_b32
-    return v;
-  }
-  __device__ __forceinline__ uint32_t rd8(int pos) const { return base[pos]; }
-};
 struct SrcGlobal {  // chunk read in place (L1/L2)
   static constexpr bool kClamp = true;  // never read past the chunk: it may end the allocation
   const uint8_t* base;
@@ -239,7 +225,7 @@ typedef __attribute__((address_space(3))) uint16_t lds_u16;
 //   and then resolved run by run with SCALAR mask arithmetic only.  K collects what the
 //   sequential code inserts (probes and ip-2 positions); for a suspect probe the true candidate
 //   is the highest lane of (same hash) & K below it, else cp.  One store commits K at the end.
-template <typename Src, int kMode>
+template <typename Src, bool kWindows>
 __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t* out, int lane) {
   volatile lds_u16* T = table;  // every access is a real ds_read_u16 / ds_write_b16, in order
   const int mfl1 = len - kMfLimit + 1;  // mflimitPlusOne
@@ -268,525 +254,15 @@ __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t*
     // fast windows: far enough from the end of the chunk that neither mflimit nor matchlimit nor
     // the end of the buffer can be met by a window's probes and speculative loads
     const int fast_limit = len - 224;
-    const int pipe_limit = len - 448;  // pipelined windows prefetch up to 323 bytes ahead
-    int kn = -1;         // first position of the window whose v is held in vn
-    uint32_t vn = 0;
-    int kp = -2;         // first position of the window whose v is held in vp (kMode 1)
+    int kp = -2;         // first position of the window whose v is held in vp
     uint32_t vp = 0;
-    int pk = -1000;      // first position of the window whose stream bytes are held in pw0 (kMode 4)
+    int pk = -1000;      // first position of the window whose stream bytes are held in pw0
     uint4 pw0 = make_uint4(0, 0, 0, 0), pw1 = pw0, pw2 = pw0;
     bool force_general = false;
     for (;;) {
-      if constexpr (kMode == 2) {
-        // ===== pipelined exact windows: window k is resolved while the loads of k+1, k+2, k+3 fly =====
-        //   stage A  v   = rd32(position)                 issued 3 windows ahead
-        //   stage B  cp  = T[hash(v)], w = rd32(cp)       table snapshot + candidate bytes, 2 ahead
-        //   stage C  em  = (w == v), 64+8 bytes at p and cp for the em lanes ("raw")   1 ahead
-        //   stage D  info = lengths from raw                        at the start of the window's turn
-        // A snapshot is validated when its window is resolved: cp' = T[h] again; a lane is stale iff
-        // cp' != cp.  Everything inserted since the snapshot lies in [wbase-128, p), i.e. in the v
-        // registers of this and the two previous windows, so a stale lane's match test is a
-        // cross-lane read; its lengths come from the cooperative extension.
-        if (!force_general && t0 <= 48 && (base & ~63) <= pipe_limit) {
-          if (put_pending) T[hash13(vput)] = (uint16_t)(base - 2);  // LZ4_putPosition(ip - 2)
-          put_pending = false;
-          have_pre = false;
-          int wbase = base & ~63;
-          // ---- (re)start: fill the pipeline synchronously ---------------------------------------------
-          uint32_t v0 = in.rd32(wbase + lane), v1 = in.rd32(wbase + 64 + lane);
-          uint32_t v2 = in.rd32(wbase + 128 + lane), vA = in.rd32(wbase + 192 + lane);
-          uint32_t vm1 = in.rd32((wbase >= 64 ? wbase - 64 : 0) + lane);
-          uint32_t vm2 = in.rd32((wbase >= 128 ? wbase - 128 : 0) + lane);
-          uint32_t cp0 = T[hash13(v0)], cp1 = T[hash13(v1)], cp2 = T[hash13(v2)];
-          uint32_t wN;
-          uint32_t info0;
-          uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;  // raw: 64 bytes behind p+4 and behind cp+4
-          uint2 rqa, rqb;                                // raw: 8 bytes in front of p and of cp
-          bool rem;                                      // raw belongs to an em lane
-#define S3S_STAGE_C(VV, CP, WW, WB)                                                   \
-  {                                                                                   \
-    rem = (WW) == (VV);                                                               \
-    if (rem) {                                                                        \
-      const int pa_ = (WB) + lane + kMinMatch, pb_ = (int)(CP) + kMinMatch;           \
-      ra0 = in.ld16(pa_), rb0 = in.ld16(pb_);                                         \
-      ra1 = in.ld16(pa_ + 16), rb1 = in.ld16(pb_ + 16);                               \
-      ra2 = in.ld16(pa_ + 32), rb2 = in.ld16(pb_ + 32);                               \
-      ra3 = in.ld16(pa_ + 48), rb3 = in.ld16(pb_ + 48);                               \
-      const int qa_ = (WB) + lane >= 8 ? (WB) + lane - 8 : 0;                         \
-      const int qb_ = (CP) >= 8u ? (int)(CP) - 8 : 0;                                 \
-      rqa = in.ld8(qa_), rqb = in.ld8(qb_);                                           \
-    }                                                                                 \
-  }
-#define S3S_STAGE_D(CP, WB, INFO)                                                     \
-  {                                                                                   \
-    INFO = 0u;                                                                        \
-    if (rem) {                                                                        \
-      uint32_t be_ = 9;                                                               \
-      if ((CP) >= 8u && (WB) + lane >= 8) {                                           \
-        const uint32_t xh_ = rqa.y ^ rqb.y, xl_ = rqa.x ^ rqb.x;                      \
-        be_ = xh_ ? (uint32_t)(__builtin_clz(xh_) >> 3)                               \
-                  : (xl_ ? 4u + (uint32_t)(__builtin_clz(xl_) >> 3) : 8u);            \
-      }                                                                               \
-      int fl_ = first_diff16(make_uint4(ra0.x ^ rb0.x, ra0.y ^ rb0.y, ra0.z ^ rb0.z, ra0.w ^ rb0.w)); \
-      if (fl_ == 16) {                                                                \
-        fl_ = 16 + first_diff16(make_uint4(ra1.x ^ rb1.x, ra1.y ^ rb1.y, ra1.z ^ rb1.z, ra1.w ^ rb1.w)); \
-        if (fl_ == 32) {                                                              \
-          fl_ = 32 + first_diff16(make_uint4(ra2.x ^ rb2.x, ra2.y ^ rb2.y, ra2.z ^ rb2.z, ra2.w ^ rb2.w)); \
-          if (fl_ == 48)                                                              \
-            fl_ = 48 + first_diff16(make_uint4(ra3.x ^ rb3.x, ra3.y ^ rb3.y, ra3.z ^ rb3.z, ra3.w ^ rb3.w)); \
-        }                                                                             \
-      }                                                                               \
-      INFO = (CP) | ((uint32_t)fl_ << 16) | (be_ << 24) | 0x20000000u;                \
-    }                                                                                 \
-  }
-          {
-            const uint32_t w0 = in.rd32((int)cp0), w1 = in.rd32((int)cp1);
-            wN = in.rd32((int)cp2);
-            S3S_STAGE_C(v0, cp0, w0, wbase);
-            S3S_STAGE_D(cp0, wbase, info0);
-            S3S_STAGE_C(v1, cp1, w1, wbase + 64);  // raw(k+1) stays in flight
-          }
-          // ---- steady state: one window per iteration -------------------------------------------------
-          int exit_kind = 0;  // 0: leave to the outer loop, 1: last literals, 2: the general batch takes over
-          int pend_far = -1;
-          for (;;) {
-            DBG_ADD(8, 1);
-            DBG_T(pa);
-            const int p = wbase + lane;
-            const uint32_t h = hash13(v0);
-            const int rs0 = base - wbase;
-            const bool live = lane >= rs0;
-            // fresh candidates + duplicate-hash groups among the live lanes (rolled back)
-            const uint32_t cpn = T[h];
-            bool grp = false;
-            if (live) {
-              T[h] = (uint16_t)p;
-              const uint32_t r1 = T[h];
-              const bool lost1 = r1 != (uint32_t)p;
-              if (lost1) T[h] = (uint16_t)p;
-              const uint32_t r2 = T[h];
-              grp = lost1 || (r2 != (uint32_t)p);
-              if (r2 == (uint32_t)p) T[h] = (uint16_t)cpn;
-            }
-            // info: [15:0] candidate [22:16] forward 0..64 [27:24] backward 0..8 / 9 unknown
-            //       [29] candidate matches [30] lengths unknown (stale snapshot) [31] suspect lane
-            uint32_t info = info0;
-            const bool stale = live && (cpn != cp0);
-            if (__ballot(stale)) {
-              const int idx = (int)(cpn & 63u);
-              const int dwin = (wbase - (int)(cpn & ~63u)) >> 6;  // 0, 1 or 2 windows back
-              uint32_t sv = __shfl(v0, idx);
-              const uint32_t s1 = __shfl(vm1, idx), s2 = __shfl(vm2, idx);
-              sv = dwin == 1 ? s1 : sv;
-              sv = dwin == 2 ? s2 : sv;
-              // (dwin <= 2 by construction: everything inserted since the snapshot is in these windows)
-              if (stale) info = (sv == v0) ? (cpn | 0x60000000u) : 0u;
-            }
-            const bool em = live && ((info & 0x20000000u) != 0u);
-            if (grp) info |= 0x80000000u;
-            const uint64_t Ecp = __ballot(em);
-            const uint64_t Dp = __ballot(grp);
-            uint64_t ED = Ecp | Dp;
-            DBG_T(pb);
-            DBG_ADD(0, pb - pa);
-            // ---- runs (scalar) ---------------------------------------------------------------------------
-            uint64_t K = 0;
-            int rs = rs0, rt = t0, pend_q = -1;
-            const int e0 = rs0 + 66 - t0;
-            int elim = e0 < kWave ? e0 : kWave;
-            uint64_t runmask = e0 < kWave ? ((1ull << e0) - 1ull) : ~0ull;
-            for (;;) {
-              const uint64_t cm = ED & runmask & (~0ull << rs);
-              if (cm == 0ull) {
-                K |= runmask & (~0ull << rs);
-                base = wbase + elim;
-                t0 = rt + (elim - rs);
-                exit_kind = elim < kWave ? 2 : 0;
-                break;
-              }
-              const int m = __builtin_ctzll(cm);
-              const uint32_t inf = __builtin_amdgcn_readlane(info, m);
-              const int ip0 = wbase + m;
-              int mpos = (int)(inf & 0xffffu);
-              int fwd = (int)((inf >> 16) & 0x7fu);
-              const int be = (int)((inf >> 24) & 0xfu);
-              const int nbmax = ip0 - anchor;
-              int nb = be < nbmax ? be : nbmax;
-              bool need_ext = fwd >= 64 || (be >= 8 && nbmax > (be == 8 ? 8 : 0)) || (inf & 0x40000000u) != 0u;
-              if (__builtin_expect((int)inf < 0, 0)) {
-                const uint64_t bit = 1ull << m;
-                bool is_match = (Ecp & bit) != 0ull;
-                const uint32_t hv = __builtin_amdgcn_readlane(h, m);
-                const uint64_t dk = __ballot(h == hv) & (bit - 1ull) & (K | (runmask & (~0ull << rs)));
-                if (dk) {
-                  const int d = 63 - __builtin_clzll(dk);
-                  is_match = __builtin_amdgcn_readlane(v0, d) == __builtin_amdgcn_readlane(v0, m);
-                  mpos = wbase + d;
-                  need_ext = true;
-                }
-                if (!is_match) {
-                  ED &= ~bit;
-                  continue;
-                }
-              }
-              if (__builtin_expect(need_ext, 0)) {
-                DBG_ADD(10, 1);
-                fwd = extend_match(in, ip0, mpos, anchor, matchlimit, last4, lane, nb);
-              }
-              DBG_ADD(9, 1);
-              K |= ((2ull << m) - 1ull) & (~0ull << rs);
-              const int lit = ip0 - nb - anchor, offset = ip0 - mpos, mcode = nb + fwd;
-              if (__builtin_expect(anchor >= wbase && lit < 15 && mcode < 15 + 255, 1)) {
-                const int total = 3 + lit + (mcode >= 15 ? 1 : 0);
-                if (op + total > len) return -1;
-                const int rel = (lane - (anchor - wbase)) & 63;
-                uint32_t bv = v0 & 0xffu;
-                int idx = rel < lit ? 1 + rel : rel;
-                if (rel == lit) {
-                  bv = (uint32_t)(lit << 4) | (uint32_t)(mcode < 15 ? mcode : 15);
-                  idx = 0;
-                }
-                if (rel == lit + 1) bv = (uint32_t)offset;
-                if (rel == lit + 2) bv = (uint32_t)offset >> 8;
-                if (rel == lit + 3) bv = (uint32_t)(mcode - 15);
-#ifndef S3S_ABL_NOSTORE
-                if (rel < total) out[op + idx] = (uint8_t)bv;
-#else
-                asm volatile("" ::"v"(bv), "v"(idx));
-#endif
-                op += total;
-              } else {
-                op = emit_sequence(out, len, op, in, anchor, lit, true, offset, mcode, false, 0u, lane);
-                if (op < 0) return -1;
-              }
-              const int ipe = ip0 + kMinMatch + fwd;
-              anchor = ipe;
-              if (__builtin_expect(ipe >= mfl1, 0)) {
-                exit_kind = 1;
-                break;
-              }
-              const int q = ipe - 2 - wbase;
-              if (q < kWave) K |= 1ull << q;
-              else pend_q = q + wbase;
-              if (ipe >= wbase + kWave) {
-                base = ipe;
-                t0 = 0;
-                exit_kind = 0;
-                break;
-              }
-              rs = ipe - wbase;
-              rt = 0;
-              elim = kWave;
-              runmask = ~0ull;
-            }
-            DBG_T(pc);
-            DBG_ADD(3, pc - pb);
-            if (exit_kind == 1) break;
-            // ---- commit ---------------------------------------------------------------------------------
-            uint64_t Wm = K, sus = K & Dp;
-            while (sus) {
-              const int i = __builtin_ctzll(sus);
-              sus &= sus - 1ull;
-              const uint32_t hv = __builtin_amdgcn_readlane(h, i);
-              if (__ballot(h == hv) & K & ~((2ull << i) - 1ull)) Wm &= ~(1ull << i);
-            }
-            if ((Wm >> lane) & 1ull) T[h] = (uint16_t)p;
-            if (pend_q >= 0) {
-              if (pend_q < wbase + 3 * kWave) {
-                const uint32_t vq = pend_q < wbase + 2 * kWave
-                                        ? __builtin_amdgcn_readlane(v1, pend_q - wbase - kWave)
-                                        : __builtin_amdgcn_readlane(v2, pend_q - wbase - 2 * kWave);
-                T[hash13(vq)] = (uint16_t)pend_q;
-                pend_q = -1;
-              } else {
-                pend_far = pend_q;  // beyond the pipeline: inserted after the loop (it ends here)
-              }
-            }
-            DBG_T(pd);
-            DBG_ADD(5, pd - pc);
-            // ---- advance: only a step into the very next window keeps the pipeline -----------------------
-            if (exit_kind != 0 || t0 > 48 || (base & ~63) != wbase + kWave || wbase + kWave > pipe_limit) break;
-            wbase += kWave;
-            S3S_STAGE_D(cp1, wbase, info0);              // raw(k+1) -> info of the new current window
-            vm2 = vm1;
-            vm1 = v0;
-            v0 = v1;
-            cp0 = cp1;
-            v1 = v2;
-            cp1 = cp2;
-            S3S_STAGE_C(v1, cp1, wN, wbase + 64);        // w of the new k+1 landed long ago
-            v2 = vA;
-            cp2 = T[hash13(v2)];
-            wN = in.rd32((int)cp2);
-            vA = in.rd32(wbase + 192 + lane);
-            DBG_T(pe);
-            DBG_ADD(2, pe - pd);
-          }
-#undef S3S_STAGE_C
-#undef S3S_STAGE_D
-          if (exit_kind == 1) break;
-          if (pend_far >= 0) T[hash13(in.rd32(pend_far))] = (uint16_t)pend_far;  // LZ4_putPosition(ip - 2)
-          force_general = exit_kind == 2;
-          continue;
-        }
-        force_general = false;
-      }
-      if constexpr (kMode == 3) {
-        // ===== pipelined exact windows, VALU style (variant 4): as kMode 2, but every wave-uniform
-        // quantity of the run loop lives in VGPRs and only branch conditions are made scalar — the CU's
-        // single scalar ALU is what bounds these kernels =====
-        //   stage A  v   = rd32(position)                 issued 3 windows ahead
-        //   stage B  cp  = T[hash(v)], w = rd32(cp)       table snapshot + candidate bytes, 2 ahead
-        //   stage C  em  = (w == v), 64+8 bytes at p and cp for the em lanes ("raw")   1 ahead
-        //   stage D  info = lengths from raw                        at the start of the window's turn
-        // A snapshot is validated when its window is resolved: cp' = T[h] again; a lane is stale iff
-        // cp' != cp.  Everything inserted since the snapshot lies in [wbase-128, p), i.e. in the v
-        // registers of this and the two previous windows, so a stale lane's match test is a
-        // cross-lane read; its lengths come from the cooperative extension.
-        if (!force_general && t0 <= 48 && (base & ~63) <= pipe_limit) {
-          if (put_pending) T[hash13(vput)] = (uint16_t)(base - 2);  // LZ4_putPosition(ip - 2)
-          put_pending = false;
-          have_pre = false;
-          int wbase = base & ~63;
-          // ---- (re)start: fill the pipeline synchronously ---------------------------------------------
-          uint32_t v0 = in.rd32(wbase + lane), v1 = in.rd32(wbase + 64 + lane);
-          uint32_t v2 = in.rd32(wbase + 128 + lane), vA = in.rd32(wbase + 192 + lane);
-          uint32_t vm1 = in.rd32((wbase >= 64 ? wbase - 64 : 0) + lane);
-          uint32_t vm2 = in.rd32((wbase >= 128 ? wbase - 128 : 0) + lane);
-          uint32_t cp0 = T[hash13(v0)], cp1 = T[hash13(v1)], cp2 = T[hash13(v2)];
-          uint32_t wN;
-          uint32_t info0;
-          uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;  // raw: 64 bytes behind p+4 and behind cp+4
-          uint2 rqa, rqb;                                // raw: 8 bytes in front of p and of cp
-          bool rem;                                      // raw belongs to an em lane
-#define S3S_STAGE_C(VV, CP, WW, WB)                                                   \
-  {                                                                                   \
-    rem = (WW) == (VV);                                                               \
-    if (rem) {                                                                        \
-      const int pa_ = (WB) + lane + kMinMatch, pb_ = (int)(CP) + kMinMatch;           \
-      ra0 = in.ld16(pa_), rb0 = in.ld16(pb_);                                         \
-      ra1 = in.ld16(pa_ + 16), rb1 = in.ld16(pb_ + 16);                               \
-      ra2 = in.ld16(pa_ + 32), rb2 = in.ld16(pb_ + 32);                               \
-      ra3 = in.ld16(pa_ + 48), rb3 = in.ld16(pb_ + 48);                               \
-      const int qa_ = (WB) + lane >= 8 ? (WB) + lane - 8 : 0;                         \
-      const int qb_ = (CP) >= 8u ? (int)(CP) - 8 : 0;                                 \
-      rqa = in.ld8(qa_), rqb = in.ld8(qb_);                                           \
-    }                                                                                 \
-  }
-#define S3S_STAGE_D(CP, WB, INFO)                                                     \
-  {                                                                                   \
-    INFO = 0u;                                                                        \
-    if (rem) {                                                                        \
-      uint32_t be_ = 9;                                                               \
-      if ((CP) >= 8u && (WB) + lane >= 8) {                                           \
-        const uint32_t xh_ = rqa.y ^ rqb.y, xl_ = rqa.x ^ rqb.x;                      \
-        be_ = xh_ ? (uint32_t)(__builtin_clz(xh_) >> 3)                               \
-                  : (xl_ ? 4u + (uint32_t)(__builtin_clz(xl_) >> 3) : 8u);            \
-      }                                                                               \
-      int fl_ = first_diff16(make_uint4(ra0.x ^ rb0.x, ra0.y ^ rb0.y, ra0.z ^ rb0.z, ra0.w ^ rb0.w)); \
-      if (fl_ == 16) {                                                                \
-        fl_ = 16 + first_diff16(make_uint4(ra1.x ^ rb1.x, ra1.y ^ rb1.y, ra1.z ^ rb1.z, ra1.w ^ rb1.w)); \
-        if (fl_ == 32) {                                                              \
-          fl_ = 32 + first_diff16(make_uint4(ra2.x ^ rb2.x, ra2.y ^ rb2.y, ra2.z ^ rb2.z, ra2.w ^ rb2.w)); \
-          if (fl_ == 48)                                                              \
-            fl_ = 48 + first_diff16(make_uint4(ra3.x ^ rb3.x, ra3.y ^ rb3.y, ra3.z ^ rb3.z, ra3.w ^ rb3.w)); \
-        }                                                                             \
-      }                                                                               \
-      INFO = (CP) | ((uint32_t)fl_ << 16) | (be_ << 24) | 0x20000000u;                \
-    }                                                                                 \
-  }
-          {
-            const uint32_t w0 = in.rd32((int)cp0), w1 = in.rd32((int)cp1);
-            wN = in.rd32((int)cp2);
-            S3S_STAGE_C(v0, cp0, w0, wbase);
-            S3S_STAGE_D(cp0, wbase, info0);
-            S3S_STAGE_C(v1, cp1, w1, wbase + 64);  // raw(k+1) stays in flight
-          }
-          // ---- steady state: one window per iteration; wave-uniform state in VGPRs -------------------------
-          int vbase = base, vt0 = t0, vanchor = anchor, vop = op;
-          asm volatile("" : "+v"(vbase), "+v"(vt0), "+v"(vanchor), "+v"(vop));
-          int exit_kind = 0;  // 0: leave to the outer loop, 1: last literals, 2: the general batch takes over
-          int pend_far = -1;
-          bool overflow = false;
-          for (;;) {
-            const int p = wbase + lane;
-            const uint32_t h = hash13(v0);
-            const int rs0 = vbase - wbase;
-            const bool live = lane >= rs0;
-            const uint32_t cpn = T[h];
-            bool grp = false;
-            if (live) {
-              T[h] = (uint16_t)p;
-              const uint32_t r1 = T[h];
-              const bool lost1 = r1 != (uint32_t)p;
-              if (lost1) T[h] = (uint16_t)p;
-              const uint32_t r2 = T[h];
-              grp = lost1 || (r2 != (uint32_t)p);
-              if (r2 == (uint32_t)p) T[h] = (uint16_t)cpn;
-            }
-            uint32_t info = info0;
-            const bool stale = live && (cpn != cp0);
-            if (__ballot(stale)) {
-              const int idx = (int)(cpn & 63u);
-              const int dwin = (wbase - (int)(cpn & ~63u)) >> 6;
-              uint32_t sv = __shfl(v0, idx);
-              const uint32_t s1 = __shfl(vm1, idx), s2 = __shfl(vm2, idx);
-              sv = dwin == 1 ? s1 : sv;
-              sv = dwin == 2 ? s2 : sv;
-              if (stale) info = (sv == v0) ? (cpn | 0x60000000u) : 0u;
-            }
-            if (grp) info |= 0x80000000u;
-            bool ed = live && ((info & 0xa0000000u) != 0u);  // event lanes: candidate matches, or suspect
-            // ---- runs ---------------------------------------------------------------------------------------
-            bool kept = false;
-            int rs = rs0, rt = vt0, pendq = -1;
-            int elim = rs0 + 66 - vt0;
-            elim = elim < kWave ? elim : kWave;
-            for (;;) {
-              const bool inrun = lane >= rs && lane < elim;
-              const uint64_t cm = __ballot(ed && inrun);
-              if (cm == 0ull) {  // the run leaves the window (or its consecutive part) without a match
-                kept = kept || inrun;
-                vbase = wbase + elim;
-                vt0 = rt + (elim - rs);
-                exit_kind = __builtin_amdgcn_readfirstlane((int)(elim < kWave)) ? 2 : 0;
-                break;
-              }
-              const int m = __builtin_ctzll(cm);
-              int mv = m;
-              asm volatile("" : "+v"(mv));
-              const uint32_t inf = (uint32_t)__shfl((int)info, mv);
-              const int ip0 = wbase + mv;
-              int mpos = (int)(inf & 0xffffu);
-              int fwd = (int)((inf >> 16) & 0x7fu);
-              const int be = (int)((inf >> 24) & 0xfu);
-              const int nbmax = ip0 - vanchor;
-              int nb = be < nbmax ? be : nbmax;
-              int is_match = (int)((inf >> 29) & 1u);
-              int need_ext = (fwd >= 64) | ((be >= 8) & (nbmax > (be == 8 ? 8 : 0))) | (int)((inf >> 30) & 1u);
-              if (__builtin_amdgcn_readfirstlane((int)(inf >> 31))) {
-                // suspect lane: does a kept (or earlier-in-run) lane of this window share its hash?
-                const uint32_t hv = (uint32_t)__shfl((int)h, mv);
-                const uint64_t dk = __ballot(h == hv && lane < m && (kept || lane >= rs));
-                if (dk) {
-                  const int d = 63 - __builtin_clzll(dk);
-                  is_match = __builtin_amdgcn_readlane(v0, d) == __builtin_amdgcn_readlane(v0, m);
-                  mpos = wbase + d;
-                  need_ext = 1;
-                }
-              }
-              if (!__builtin_amdgcn_readfirstlane(is_match)) {
-                ed = ed && (lane != m);  // a plain no-match probe: the run goes on behind it
-                continue;
-              }
-              bool ended = false;
-              if (__builtin_amdgcn_readfirstlane(need_ext)) {
-                const int anchors = __builtin_amdgcn_readfirstlane(vanchor);
-                const int mposs = __builtin_amdgcn_readfirstlane(mpos);
-                int nbs = 0;
-                fwd = extend_match(in, wbase + m, mposs, anchors, matchlimit, last4, lane, nbs);
-                nb = nbs;
-                ended = wbase + m + kMinMatch + fwd >= mfl1;
-              }
-              kept = kept || (lane >= rs && lane <= m);
-              const int lit = ip0 - nb - vanchor, offset = ip0 - mpos, mcode = nb + fwd;
-              const int fe = (vanchor >= wbase) & (lit < 15) & (mcode < 15 + 255) & (vop + 20 <= len);
-              if (__builtin_amdgcn_readfirstlane(fe)) {
-                const int total = 3 + lit + (mcode >= 15 ? 1 : 0);
-                const int rel = (lane - (vanchor - wbase)) & 63;
-                uint32_t bv = v0 & 0xffu;
-                int idx = rel < lit ? 1 + rel : rel;
-                bv = rel == lit ? ((uint32_t)(lit << 4) | (uint32_t)(mcode < 15 ? mcode : 15)) : bv;
-                idx = rel == lit ? 0 : idx;
-                bv = rel == lit + 1 ? (uint32_t)offset : bv;
-                bv = rel == lit + 2 ? ((uint32_t)offset >> 8) : bv;
-                bv = rel == lit + 3 ? (uint32_t)(mcode - 15) : bv;
-                if (rel < total) out[vop + idx] = (uint8_t)bv;
-                vop += total;
-              } else {
-                const int ops = emit_sequence(out, len, __builtin_amdgcn_readfirstlane(vop), in,
-                                              __builtin_amdgcn_readfirstlane(vanchor), __builtin_amdgcn_readfirstlane(lit),
-                                              true, __builtin_amdgcn_readfirstlane(offset),
-                                              __builtin_amdgcn_readfirstlane(mcode), false, 0u, lane);
-                if (ops < 0) {
-                  overflow = true;
-                  break;
-                }
-                vop = ops;
-              }
-              const int ipe = ip0 + kMinMatch + fwd;
-              vanchor = ipe;
-              if (ended) {
-                exit_kind = 1;
-                break;
-              }
-              const int q = ipe - 2 - wbase;  // LZ4_putPosition(ip - 2)
-              kept = kept || (lane == q);
-              pendq = q >= kWave ? ipe - 2 : pendq;
-              if (__builtin_amdgcn_readfirstlane((int)(ipe >= wbase + kWave))) {
-                vbase = ipe;
-                vt0 = 0;
-                exit_kind = 0;
-                break;
-              }
-              rs = ipe - wbase;
-              rt = 0;
-              elim = kWave;
-            }
-            if (overflow || exit_kind == 1) break;
-            // ---- commit: the highest kept lane of every hash bucket must own the slot --------------------------
-            if (kept) T[h] = (uint16_t)p;
-            for (;;) {
-              uint32_t r = (uint32_t)p;
-              if (kept) r = T[h];
-              const bool redo = kept && ((uint32_t)p > r);
-              if (!__ballot(redo)) break;
-              if (redo) T[h] = (uint16_t)p;
-            }
-            const int pq = __builtin_amdgcn_readfirstlane(pendq);
-            if (pq >= 0) {
-              if (pq < wbase + 3 * kWave) {
-                const uint32_t vq = pq < wbase + 2 * kWave ? __builtin_amdgcn_readlane(v1, pq - wbase - kWave)
-                                                           : __builtin_amdgcn_readlane(v2, pq - wbase - 2 * kWave);
-                T[hash13(vq)] = (uint16_t)pq;
-              } else {
-                pend_far = pq;
-              }
-            }
-            // ---- advance: only a step into the very next window keeps the pipeline ---------------------------
-            const int keep_going = (vt0 <= 48) & ((vbase & ~63) == wbase + kWave);
-            if (exit_kind != 0 || !__builtin_amdgcn_readfirstlane(keep_going) || wbase + kWave > pipe_limit) break;
-            wbase += kWave;
-            S3S_STAGE_D(cp1, wbase, info0);
-            vm2 = vm1;
-            vm1 = v0;
-            v0 = v1;
-            cp0 = cp1;
-            v1 = v2;
-            cp1 = cp2;
-            S3S_STAGE_C(v1, cp1, wN, wbase + 64);
-            v2 = vA;
-            cp2 = T[hash13(v2)];
-            wN = in.rd32((int)cp2);
-            vA = in.rd32(wbase + 192 + lane);
-          }
-          base = __builtin_amdgcn_readfirstlane(vbase);
-          t0 = __builtin_amdgcn_readfirstlane(vt0);
-          anchor = __builtin_amdgcn_readfirstlane(vanchor);
-          op = __builtin_amdgcn_readfirstlane(vop);
-          if (overflow) return -1;
-#undef S3S_STAGE_C
-#undef S3S_STAGE_D
-          if (exit_kind == 1) break;
-          if (pend_far >= 0) T[hash13(in.rd32(pend_far))] = (uint16_t)pend_far;  // LZ4_putPosition(ip - 2)
-          force_general = exit_kind == 2;
-          continue;
-        }
-        force_general = false;
-      }
-      if constexpr (kMode == 4) {
+      if constexpr (kWindows) {
         // ===== lean exact windows (variant 10) =====================================================================
-        // Same resolution rules as kMode 1 (runs resolved with scalar mask arithmetic over K / ED), but the
+        // Runs are resolved with scalar mask arithmetic over K / ED (round 1's exact windows), but the
         // window is prepared with ONE memory round trip instead of three:
         //   * every lane keeps the 16 bytes p-4 .. p+11 of its position for this window and the next two
         //     (linear, issued two windows ahead: never waited for in steady state);
@@ -1051,276 +527,6 @@ __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t*
         }
         force_general = false;
       }
-      if constexpr (kMode == 1) {
-        const int wbase = base & ~63;
-        if (!force_general && t0 <= 48 && wbase <= fast_limit) {
-          if (put_pending) T[hash13(vput)] = (uint16_t)(base - 2);  // LZ4_putPosition(ip - 2)
-          put_pending = false;
-          have_pre = false;
-          // ================= window preparation (vector work, every lane = one position) ============
-          DBG_T(tw0);
-          DBG_ADD(8, 1);
-          const int p = wbase + lane;
-          const uint32_t v = (kn == wbase) ? vn : in.rd32(p);
-          const bool vp_ok = kp == wbase - 64;  // vp holds the previous window's dwords (literals may start there)
-          vn = in.rd32(p + 64);
-          kn = wbase + 64;
-          const uint32_t h = hash13(v);
-          const int rs0 = base - wbase;
-          const bool live = lane >= rs0;
-          // table candidates, and duplicate-hash groups among the live lanes (two speculative store
-          // passes, rolled back: lanes of a group of >= 2 either lose pass 1 or see pass 2's winner)
-          const uint32_t cp = T[h];
-          bool grp = false;
-          if (live) {
-            T[h] = (uint16_t)p;
-            const uint32_t r1 = T[h];
-            const bool lost1 = r1 != (uint32_t)p;
-            if (lost1) T[h] = (uint16_t)p;
-            const uint32_t r2 = T[h];
-            grp = lost1 || (r2 != (uint32_t)p);
-            if (r2 == (uint32_t)p) T[h] = (uint16_t)cp;  // the slot's current owner restores it
-          }
-          DBG_T(tw1);
-          const uint32_t w = in.rd32((int)cp);
-          const bool em = live && (w == v);
-          DBG_T(tw2x);
-          DBG_ADD(1, tw2x - tw1 + (__ballot(em) & 0));
-          DBG_T(tw2);
-          // per-lane event record: [15:0] table candidate, [22:16] forward length 0..64,
-          // [27:24] backward equal bytes 0..8 (8 = at least, 9 = unknown), [31] suspect lane (member of
-          // a duplicate-hash group)
-          uint32_t info = grp ? 0x80000000u : 0u, info2 = 0u;
-          if (em) {
-            const int pa = p + kMinMatch, pb = (int)cp + kMinMatch;
-            const uint4 a0 = in.ld16(pa), b0 = in.ld16(pb);
-            const uint4 a1 = in.ld16(pa + 16), b1 = in.ld16(pb + 16);
-            const uint4 a2 = in.ld16(pa + 32), b2 = in.ld16(pb + 32);
-            const uint4 a3 = in.ld16(pa + 48), b3 = in.ld16(pb + 48);
-            uint32_t be = 9;  // 9 = unknown (too close to the start of the chunk), 8 = at least 8
-            if (cp >= 8u && p >= 8) {
-              const uint2 qa = in.ld8(p - 8), qb = in.ld8((int)cp - 8);
-              const uint32_t xh = qa.y ^ qb.y, xl = qa.x ^ qb.x;
-              be = xh ? (uint32_t)(__builtin_clz(xh) >> 3) : (xl ? 4u + (uint32_t)(__builtin_clz(xl) >> 3) : 8u);
-            }
-            int fl = first_diff16(make_uint4(a0.x ^ b0.x, a0.y ^ b0.y, a0.z ^ b0.z, a0.w ^ b0.w));
-            if (fl == 16) {
-              fl = 16 + first_diff16(make_uint4(a1.x ^ b1.x, a1.y ^ b1.y, a1.z ^ b1.z, a1.w ^ b1.w));
-              if (fl == 32) {
-                fl = 32 + first_diff16(make_uint4(a2.x ^ b2.x, a2.y ^ b2.y, a2.z ^ b2.z, a2.w ^ b2.w));
-                if (fl == 48) fl = 48 + first_diff16(make_uint4(a3.x ^ b3.x, a3.y ^ b3.y, a3.z ^ b3.z, a3.w ^ b3.w));
-              }
-            }
-            info = cp | ((uint32_t)fl << 16) | (be << 24) | (grp ? 0x80000000u : 0u);
-            // for the straight-line steps: backward bytes to take (0..8) and the longest literal run for which
-            // that count is exact (be < 8: any; be == 8: 8; unknown: 0)
-            info2 = (be <= 8u ? be : 0u) | ((be < 8u ? 0x7fffu : (be == 8u ? 8u : 0u)) << 4);
-          }
-          // vn (issued before every load above) has landed by now: pin it here, before the emit stores,
-          // so that no later use has to drain the in-order vmcnt queue behind those stores
-          asm volatile("" : "+v"(vn));
-          const uint64_t Ecp = __ballot(em);
-          const uint64_t Dp = __ballot(grp);
-          uint64_t ED = Ecp | Dp;  // lanes the run loop has to look at
-          DBG_T(tw3);
-          DBG_ADD(0, tw1 - tw0);
-          DBG_ADD(2, tw3 - tw2 + (__builtin_amdgcn_readfirstlane(info) & 0));
-          // ================= runs (scalar work) ========================================================
-          uint64_t K = 0;      // lanes the sequential code inserts: probes and ip-2 positions
-          int rs = rs0, rt = t0, pend_q = -1;
-          int exit_kind;       // 0: next window / batch, 1: last literals, 2: the general batch takes over
-          // the first run may continue an older one: its probes are consecutive only up to lane e0-1
-          const int e0 = rs0 + 66 - t0;  // t0 <= 48  =>  e0 >= rs0 + 18
-          int elim = e0 < kWave ? e0 : kWave;
-          uint64_t runmask = e0 < kWave ? ((1ull << e0) - 1ull) : ~0ull;
-          // ---- straight-line steps: up to three "plain" sequences (the first event of the run has its true candidate
-          // in the table, exact lengths, short-form encoding, literals in the registers of this or the previous
-          // window, not the end of the chunk) without the generic loop's control flow: ONE branch decides,
-          // everything else is arithmetic.  Anything else falls through to the generic loop below, which
-          // continues from whatever state the steps left.
-          constexpr int kFastSteps = S3S_FAST_STEPS;
-          bool left_window = false;
-          const int lit_floor = vp_ok ? wbase - 64 : wbase;  // literals must start at or after this position
-#pragma unroll
-          for (int step = 0; step < kFastSteps; step++) {
-            const uint64_t live_m = runmask & (~0ull << rs);
-            const uint64_t cm = ED & live_m;
-            if (cm == 0ull) break;  // no event left for this run: the generic loop's exit code handles it
-            const int m = __builtin_ctzll(cm);
-            const uint64_t bit = 1ull << m;
-            const uint32_t inf = __builtin_amdgcn_readlane(info, m);
-            const uint32_t inf2 = __builtin_amdgcn_readlane(info2, m);
-            // a duplicate-hash lane is plain iff no earlier kept lane of the window shares its hash
-            const uint32_t hv = __builtin_amdgcn_readlane(h, m);
-            const uint64_t dk = __ballot(h == hv) & (bit - 1ull) & (K | live_m);
-            const int ip0 = wbase + m;
-            const int mpos = (int)(inf & 0xffffu), fwd = (int)((inf >> 16) & 0x7fu);
-            const int nbmax = ip0 - anchor;
-            const int nbv = (int)(inf2 & 0xfu);
-            const int nb = nbv < nbmax ? nbv : nbmax;
-            const int lit = nbmax - nb, mcode = nb + fwd;
-            const int total = 3 + lit + (mcode >= 15 ? 1 : 0);
-            const int ipe = ip0 + kMinMatch + fwd;
-            // largest of the "how far beyond its limit" terms: <= 0 iff every condition holds
-            int over = fwd - 63;                                       // forward length capped
-            over = over > nbmax - (int)(inf2 >> 4) ? over : nbmax - (int)(inf2 >> 4);  // backward count not exact
-            over = over > lit_floor - anchor ? over : lit_floor - anchor;  // literals older than the registers
-            over = over > lit - 14 ? over : lit - 14;                  // literal length needs extra bytes
-            over = over > mcode - 269 ? over : mcode - 269;            // more than one match-length byte
-            over = over > ipe - mfl1 + 1 ? over : ipe - mfl1 + 1;      // end of the chunk
-            over = over > op + total - len ? over : op + total - len;  // would not fit: the frame is stored RAW
-            if ((Ecp & bit) == 0ull || dk != 0ull || over > 0) break;
-            DBG_ADD(9, 1);
-            K |= live_m & ((bit << 1) - 1ull);
-            {
-              const int offset = ip0 - mpos;
-              const int rel = (lane - anchor) & 63;
-              uint32_t bv = ((anchor + rel < wbase) ? vp : v) & 0xffu;
-              int idx = rel < lit ? 1 + rel : rel;
-              if (rel == lit) {
-                bv = (uint32_t)(lit << 4) | (uint32_t)(mcode < 15 ? mcode : 15);
-                idx = 0;
-              }
-              if (rel == lit + 1) bv = (uint32_t)offset;
-              if (rel == lit + 2) bv = (uint32_t)offset >> 8;
-              if (rel == lit + 3) bv = (uint32_t)(mcode - 15);
-              if (rel < total) out[op + idx] = (uint8_t)bv;
-            }
-            op += total;
-            anchor = ipe;
-            const int q = ipe - 2 - wbase;  // LZ4_putPosition(ip - 2)
-            K |= q < kWave ? (1ull << (q & 63)) : 0ull;
-            pend_q = q < kWave ? pend_q : q + wbase;
-            rs = ipe - wbase;  // (>= 64 when the match leaves the window: not used then)
-            rt = 0;
-            elim = kWave;
-            runmask = ~0ull;
-            if (ipe >= wbase + kWave) {
-              base = ipe;
-              t0 = 0;
-              left_window = true;
-              break;
-            }
-          }
-          exit_kind = 0;
-          if (!left_window) for (;;) {
-            const uint64_t cm = ED & runmask & (~0ull << rs);
-            if (cm == 0ull) {  // the run leaves the window (or its consecutive part) without a match
-              K |= runmask & (~0ull << rs);
-              base = wbase + elim;
-              t0 = rt + (elim - rs);
-              exit_kind = elim < kWave ? 2 : 0;
-              break;
-            }
-            const int m = __builtin_ctzll(cm);
-            const uint32_t inf = __builtin_amdgcn_readlane(info, m);
-            const int ip0 = wbase + m;
-            int mpos = (int)(inf & 0xffffu);
-            int fwd = (int)((inf >> 16) & 0x7fu);
-            const int be = (int)((inf >> 24) & 0xfu);
-            const int nbmax = ip0 - anchor;  // (the table candidate of a lane with known be is >= 8)
-            int nb = be < nbmax ? be : nbmax;
-            bool need_ext = fwd >= 64 || (be >= 8 && nbmax > (be == 8 ? 8 : 0));  // a length hit its cap
-            if (__builtin_expect((int)inf < 0, 0)) {
-              // ---- suspect lane: another live lane of the window has the same hash ----------------------
-              const uint64_t bit = 1ull << m;
-              bool is_match = (Ecp & bit) != 0ull;
-              const uint32_t hv = __builtin_amdgcn_readlane(h, m);
-              const uint64_t dk = __ballot(h == hv) & (bit - 1ull) & (K | (runmask & (~0ull << rs)));
-              if (dk) {  // the sequential code's candidate is an earlier position of this window
-                const int d = 63 - __builtin_clzll(dk);
-                is_match = __builtin_amdgcn_readlane(v, d) == __builtin_amdgcn_readlane(v, m);
-                mpos = wbase + d;
-                need_ext = true;
-              }
-              if (!is_match) {
-                ED &= ~bit;  // a plain no-match probe: the run goes on behind it
-                continue;
-              }
-            }
-            if (__builtin_expect(need_ext, 0)) {
-              DBG_T(ts0);
-              fwd = extend_match(in, ip0, mpos, anchor, matchlimit, last4, lane, nb);
-              DBG_T(ts1);
-              DBG_ADD(4, ts1 - ts0);
-              DBG_ADD(10, 1);
-            }
-            DBG_ADD(9, 1);
-            K |= ((2ull << m) - 1ull) & (~0ull << rs);
-            const int lit = ip0 - nb - anchor, offset = ip0 - mpos, mcode = nb + fwd;
-            if (__builtin_expect(anchor >= wbase && lit < 15 && mcode < 15 + 255, 1)) {
-              // every literal is the low byte of a lane's v: lane L stores its own byte, four
-              // otherwise idle lanes store token / offset / match-length byte — one store
-              const int total = 3 + lit + (mcode >= 15 ? 1 : 0);
-              if (op + total > len) return -1;
-              const int rel = (lane - (anchor - wbase)) & 63;
-              uint32_t bv = v & 0xffu;
-              int idx = rel < lit ? 1 + rel : rel;  // literals follow the token; the rest is in place
-              if (rel == lit) {
-                bv = (uint32_t)(lit << 4) | (uint32_t)(mcode < 15 ? mcode : 15);
-                idx = 0;
-              }
-              if (rel == lit + 1) bv = (uint32_t)offset;
-              if (rel == lit + 2) bv = (uint32_t)offset >> 8;
-              if (rel == lit + 3) bv = (uint32_t)(mcode - 15);
-              if (rel < total) out[op + idx] = (uint8_t)bv;
-              op += total;
-            } else {
-              op = emit_sequence(out, len, op, in, anchor, lit, true, offset, mcode, false, 0u, lane);
-              if (op < 0) return -1;
-            }
-            const int ipe = ip0 + kMinMatch + fwd;
-            anchor = ipe;
-            if (__builtin_expect(ipe >= mfl1, 0)) {
-              exit_kind = 1;
-              break;
-            }
-            const int q = ipe - 2 - wbase;  // LZ4_putPosition(ip - 2)
-            if (q < kWave) K |= 1ull << q;
-            else pend_q = q + wbase;
-            if (ipe >= wbase + kWave) {
-              base = ipe;
-              t0 = 0;
-              exit_kind = 0;
-              break;
-            }
-            rs = ipe - wbase;
-            rt = 0;
-            elim = kWave;
-            runmask = ~0ull;
-          }
-          DBG_T(tw4);
-          DBG_ADD(3, tw4 - tw3);
-          if (exit_kind == 1) break;
-          // ================= commit: the highest kept lane of every hash group writes ==================
-          // All kept lanes store at once; which lane wins a same-address store is the hardware's choice, so
-          // the lanes read back and every kept lane that finds a LOWER position in its slot stores again,
-          // until none does (the owner only moves up: at most group-size rounds, one or two in practice).
-          // This replaces a scalar loop over the kept group lanes (~10 SALU each, dozens per window).
-          const bool kept = ((K >> lane) & 1ull) != 0ull;
-          if (kept) T[h] = (uint16_t)p;
-          if (K & Dp) {
-            for (;;) {
-              const bool redo = kept && (uint32_t)T[h] < (uint32_t)p;
-              if (!__ballot(redo)) break;
-              if (redo) T[h] = (uint16_t)p;
-            }
-          }
-          if (pend_q >= 0) {
-            const uint32_t vq = pend_q < wbase + 2 * kWave
-                                    ? __builtin_amdgcn_readlane(vn, pend_q - wbase - kWave)
-                                    : in.rd32(pend_q);
-            T[hash13(vq)] = (uint16_t)pend_q;
-          }
-          vp = v;
-          kp = wbase;
-          force_general = exit_kind == 2;
-          DBG_T(tw5);
-          DBG_ADD(5, tw5 - tw4);
-          continue;
-        }
-        force_general = false;
-      }
       DBG_ADD(11, 1);
       // ---- one batch: lane i evaluates probe t0+i of the current no-match run ----------------
       int pos, nvalid;
@@ -1442,44 +648,6 @@ __device__ __forceinline__ void finish_frame(uint8_t* slot, int len, int clen, u
   if (lane == 0) *item_size_out = (kLz4FrameHeader + plen) | (raw ? kRawFlag : 0u);
 }
 
-// ---- variant A: chunk staged in LDS --------------------------------------------------------
-struct __attribute__((aligned(16))) Lz4LdsA {
-  uint8_t in[kMaxBlock + kLdsSlack];
-  uint16_t table[8192];
-};
-
-__global__ __launch_bounds__(kWave) void lz4_compress_lds_kernel(
-    const uint8_t* __restrict__ src, const Item* __restrict__ items, int32_t n_items,
-    const uint32_t* __restrict__ item_check, uint8_t* __restrict__ slots,
-    uint32_t* __restrict__ item_size) {
-  __shared__ Lz4LdsA s;
-  const int it = blockIdx.x;
-  if (it >= n_items) return;
-  const Item item = items[it];
-  const int kind = item.kind & 0xff;
-  const int lane = threadIdx.x;
-  if (kind != kItemLz4Chunk) {
-    if (lane == 0 && kind == kItemLz4End) item_size[it] = kLz4FrameHeader;
-    return;
-  }
-  const int len = item.len;
-  const uint8_t* g = src + item.src_off;
-  for (int i = lane * 16; i + 16 <= len; i += kWave * 16) {
-    uint4 x;
-    __builtin_memcpy(&x, g + i, 16);
-    *reinterpret_cast<uint4*>(s.in + i) = x;
-  }
-  for (int i = (len & ~15) + lane; i < len; i += kWave) s.in[i] = g[i];
-  {
-    uint4* tz = reinterpret_cast<uint4*>(s.table);
-    for (int i = lane; i < (int)(sizeof(s.table) / 16); i += kWave) tz[i] = make_uint4(0, 0, 0, 0);
-  }
-  __syncthreads();
-  uint8_t* slot = slots + (size_t)item.chunk * kSlotBytes;
-  const int clen = lz4_compress_wave<SrcLds, 0>(SrcLds{s.in}, (lds_u16*)s.table, len, slot + kSlotHeader, lane);
-  finish_frame(slot, len, clen, item_check[it], item.kind >> 8, item_size + it, lane);
-}
-
 constexpr uint32_t XXP1 = 2654435761u, XXP2 = 2246822519u, XXP3 = 3266489917u,
                    XXP4 = 668265263u, XXP5 = 374761393u;
 
@@ -1526,12 +694,12 @@ __device__ __forceinline__ uint32_t xxh32_wave(const uint8_t* g, int len, uint32
 }
 
 // ---- variant B: chunk read in place, only the table in LDS ----------------------------------
-template <int kMode, bool kFusedHash = false, int kLdsPad = 0>
+template <bool kWindows>
 __global__ __launch_bounds__(kWave) void lz4_compress_l2_kernel(
     const uint8_t* __restrict__ src, const Item* __restrict__ items, int32_t n_items,
     const uint32_t* __restrict__ item_check, uint8_t* __restrict__ slots,
     uint32_t* __restrict__ item_size) {
-  __shared__ __attribute__((aligned(16))) uint16_t table[8192 + kLdsPad / 2];  // kLdsPad: occupancy experiments
+  __shared__ __attribute__((aligned(16))) uint16_t table[8192];
   const int it = blockIdx.x;
   if (it >= n_items) return;
   const Item item = items[it];
@@ -1547,62 +715,10 @@ __global__ __launch_bounds__(kWave) void lz4_compress_l2_kernel(
   }
   __syncthreads();
   uint8_t* slot = slots + (size_t)item.chunk * kSlotBytes;
-  uint32_t check;
-  if constexpr (kFusedHash) check = xxh32_wave(src + item.src_off, item.len, kLz4BlockSeed, lane);
-  else check = item_check[it];
-  const int clen = lz4_compress_wave<SrcGlobal, kMode>(SrcGlobal{src + item.src_off}, (lds_u16*)table,
+  const uint32_t check = item_check[it];
+  const int clen = lz4_compress_wave<SrcGlobal, kWindows>(SrcGlobal{src + item.src_off}, (lds_u16*)table,
                                                       item.len, slot + kSlotHeader, lane);
   finish_frame(slot, item.len, clen, check, item.kind >> 8, item_size + it, lane);
-}
-
-// ---- xxHash32 of every chunk: 4 lanes per chunk (one per stripe accumulator) ----------------
-constexpr int kXxhThreads = 256;
-
-__device__ __forceinline__ uint32_t ld32u(const uint8_t* p) {
-  uint32_t v;
-  __builtin_memcpy(&v, p, 4);
-  return v;
-}
-
-__global__ __launch_bounds__(kXxhThreads) void xxh32_items_kernel(
-    const uint8_t* __restrict__ src, const Item* __restrict__ items, int32_t n_items,
-    uint32_t seed, uint32_t* __restrict__ item_check) {
-  const int it = blockIdx.x * (kXxhThreads / 4) + (threadIdx.x >> 2);
-  const int l = threadIdx.x & 3;
-  int len = 0;
-  const uint8_t* g = src;
-  bool chunk = false;
-  if (it < n_items) {
-    const Item item = items[it];
-    const int kind = item.kind & 0xff;
-    chunk = (kind == kItemLz4Chunk);
-    if (chunk) {
-      len = item.len;
-      g = src + item.src_off;
-    }
-  }
-  uint32_t acc = l == 0 ? seed + XXP1 + XXP2 : l == 1 ? seed + XXP2 : l == 2 ? seed : seed - XXP1;
-  const int stripes = len >> 4;
-  const uint8_t* q = g + 4 * l;
-#pragma unroll 8
-  for (int j = 0; j < stripes; j++) acc = rotl32(acc + ld32u(q + 16 * j) * XXP2, 13) * XXP1;
-  // gather the group's four accumulators (all lanes execute the shuffles)
-  const int g0 = (threadIdx.x & 63) & ~3;
-  const uint32_t v1 = __shfl(acc, g0), v2 = __shfl(acc, g0 + 1), v3 = __shfl(acc, g0 + 2),
-                 v4 = __shfl(acc, g0 + 3);
-  if (!chunk || l != 0) return;
-  uint32_t h = len >= 16 ? rotl32(v1, 1) + rotl32(v2, 7) + rotl32(v3, 12) + rotl32(v4, 18)
-                         : seed + XXP5;
-  h += (uint32_t)len;
-  int p = stripes << 4;
-  for (; p + 4 <= len; p += 4) h = rotl32(h + ld32u(g + p) * XXP3, 17) * XXP4;
-  for (; p < len; p++) h = rotl32(h + (uint32_t)g[p] * XXP5, 11) * XXP1;
-  h ^= h >> 15;
-  h *= XXP2;
-  h ^= h >> 13;
-  h *= XXP3;
-  h ^= h >> 16;
-  item_check[it] = h;
 }
 
 // one wavefront per chunk, coalesced streaming (xxh32_wave): ~3x the 4-lanes-per-chunk kernel above
@@ -1627,36 +743,14 @@ void launch_lz4_compress(const uint8_t* d_src, const Item* d_items, int32_t n_it
     if (after_hash) hipEventRecord(after_hash, st);
     return;
   }
-  if (variant != 5)  // variant 5 computes the frame check inside the compress kernel
-    hipLaunchKernelGGL(xxh32_items_wave_kernel, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src, d_items,
-                       n_items, kLz4BlockSeed, d_item_check);
+  hipLaunchKernelGGL(xxh32_items_wave_kernel, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src, d_items,
+                     n_items, kLz4BlockSeed, d_item_check);
   if (after_hash) hipEventRecord(after_hash, st);
-  if (variant == 0)
-    hipLaunchKernelGGL(lz4_compress_lds_kernel, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
+  if (variant == 1)
+    hipLaunchKernelGGL(lz4_compress_l2_kernel<false>, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
                        d_items, n_items, d_item_check, d_slots, d_item_size);
-  else if (variant == 1)
-    hipLaunchKernelGGL(lz4_compress_l2_kernel<0>, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
-                       d_items, n_items, d_item_check, d_slots, d_item_size);
-  else if (variant == 2)
-    hipLaunchKernelGGL(lz4_compress_l2_kernel<1>, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
-                       d_items, n_items, d_item_check, d_slots, d_item_size);
-  else if (variant == 3)
-    hipLaunchKernelGGL(lz4_compress_l2_kernel<2>, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
-                       d_items, n_items, d_item_check, d_slots, d_item_size);
-  else if (variant == 4)
-    hipLaunchKernelGGL(lz4_compress_l2_kernel<3>, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
-                       d_items, n_items, d_item_check, d_slots, d_item_size);
-  else if (variant == 10)
-    hipLaunchKernelGGL(lz4_compress_l2_kernel<4>, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
-                       d_items, n_items, d_item_check, d_slots, d_item_size);
-  else if (variant == 5)
-    hipLaunchKernelGGL((lz4_compress_l2_kernel<0, true>), dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
-                       d_items, n_items, d_item_check, d_slots, d_item_size);
-  else if (variant == 6)  // occupancy experiment: 5 wavefronts per CU
-    hipLaunchKernelGGL((lz4_compress_l2_kernel<0, false, 16384>), dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
-                       d_items, n_items, d_item_check, d_slots, d_item_size);
-  else  // occupancy experiment: 7 wavefronts per CU
-    hipLaunchKernelGGL((lz4_compress_l2_kernel<0, false, 6144>), dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
+  else
+    hipLaunchKernelGGL(lz4_compress_l2_kernel<true>, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
                        d_items, n_items, d_item_check, d_slots, d_item_size);
 }
 

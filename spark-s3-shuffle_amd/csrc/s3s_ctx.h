@@ -34,8 +34,8 @@ struct s3s_ctx {
   int64_t lz4_block = 32768;
   int64_t snappy_block = 32768;
   int profile = 0;
-  int lz4_variant = 10;  // 10 = lean exact windows (default); 9 = auto: the context times variants 1 and 2 on its own calls (below)
-  // auto-tuning state (S3S_OPT_LZ4_VARIANT = 9): index 0 = variant 1 (general batch), 1 = variant 2
+  int lz4_variant = 10;  // 10 = lean exact windows (default); 1 = general batch; 9 = auto: the context times both on its own calls
+  // auto-tuning state (S3S_OPT_LZ4_VARIANT = 9): index 0 = variant 1 (general batch), 1 = variant 10
   // (exact windows).  Shuffle data of one stage has one schema, so the faster parse for a
   // context's first map outputs stays the faster one; every 32nd large call re-measures the other.
   int auto_choice = 1;

@@ -14,7 +14,7 @@ ADLER, CRC = 1, 2
 
 @pytest.fixture(params=[(3, 0), (4, 1)], ids=["general+ring-valu", "window+batch-decoder"], autouse=True)
 def variants(request, gpu_codec):
-    """Every test runs against both Snappy decoders (S3S_OPT_LZ4_DECODE_VARIANT: 0 / non-zero) and
+    """Every test runs against both Snappy decoders (S3S_OPT_LZ4_DECODE_VARIANT: 3 ring / 4 batch) and
     both compressor paths (S3S_OPT_SNAPPY_VARIANT: 0 general batch only / 1 exact windows first)."""
     d_dec, d_cmp = gpu_codec.get_option(5), gpu_codec.get_option(6)
     gpu_codec.set_option(5, request.param[0])

@@ -8,7 +8,7 @@ from s3shuffle import datagen
 
 def main():
     size = int(sys.argv[1]) if len(sys.argv) > 1 else (128 << 20)
-    variants = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 3, 4]
+    variants = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 10]
     dev = torch.device("cuda:0")
     torch.zeros(1, device=dev)
     c = s3shuffle.Codec(0)
