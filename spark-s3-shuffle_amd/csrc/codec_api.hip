@@ -11,6 +11,16 @@
 
 using namespace s3s;
 
+namespace {
+// S3S_DEBUG_SYNC=1: wait after every stage of the batched call and say which one finished (fault triage)
+inline void dbg_sync(s3s_ctx* ctx, const char* what) {
+  static const bool on = getenv("S3S_DEBUG_SYNC") != nullptr;
+  if (!on) return;
+  const hipError_t e = hipStreamSynchronize(ctx->stream);
+  fprintf(stderr, "[s3s] %s: %s\n", what, hipGetErrorString(e));
+}
+}  // namespace
+
 extern "C" {
 
 const char* s3s_version(void) { return "s3shuffle-codec-mi355x 0.1.0 (gfx950)"; }
@@ -523,6 +533,7 @@ int s3s_compress_map_outputs_batch_device(s3s_ctx* ctx, int codec, int checksum_
                            dev<uint32_t>(ctx, B_ITEM_SIZE), ctx->snappy_variant, ctx->stream);
   }
   HIP_TRY(ctx, hipGetLastError());
+  dbg_sync(ctx, "batch codec");
   record(ctx, 1);
   // ---- per task: offsets, .data image, checksums ------------------------------------------------------------
   for (int32_t t = 0; t < n_tasks; t++) {
@@ -531,9 +542,11 @@ int s3s_compress_map_outputs_batch_device(s3s_ctx* ctx, int codec, int checksum_
     launch_scan_items(dev<Item>(ctx, B_ITEMS) + fi, dev<uint32_t>(ctx, B_ITEM_SIZE) + fi, ni,
                       dev<int64_t>(ctx, B_ITEM_OFF) + fi + t, dev<int32_t>(ctx, B_PART_FIRST) + pp, k.num_partitions,
                       dev<int64_t>(ctx, B_INDEX) + pp, ctx->stream);
+    dbg_sync(ctx, "batch scan");
     launch_gather_items(base, dev<Item>(ctx, B_ITEMS) + fi, ni, dev<uint8_t>(ctx, B_SLOTS), slot_stride,
                         dev<uint32_t>(ctx, B_ITEM_SIZE) + fi, dev<int64_t>(ctx, B_ITEM_OFF) + fi + t, k.d_dst,
                         k.dst_capacity, dev<int32_t>(ctx, B_STATUS) + t, ctx->stream);
+    dbg_sync(ctx, "batch gather");
   }
   HIP_TRY(ctx, hipGetLastError());
   record(ctx, 2);

@@ -105,8 +105,9 @@ __device__ __forceinline__ int emit_sequence(uint8_t* out, int cap, int op, cons
     if (op + total > cap) return -1;
     uint32_t b = lit_byte;
     if (!lit_in_regs) {
-      int lp = anchor + lane - 1;  // lanes 1..lit carry the literals
-      lp = lp < anchor ? anchor : lp;
+      // lanes 1..lit carry the literals; every other lane re-reads the first one (never past the chunk: it
+      // may end the caller's allocation)
+      const int lp = (lane >= 1 && lane <= lit) ? anchor + lane - 1 : anchor;
       b = in.rd8(lp);
     }
     b = (lane == 0) ? ((uint32_t)(lit << 4) | (uint32_t)(mcode < 15 ? mcode : 15)) : b;

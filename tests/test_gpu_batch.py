@@ -67,3 +67,29 @@ def test_batch_capacity_error_is_per_task(gpu_codec, oracle):
             assert total == r[0].size and np.array_equal(index, r[1]) and np.array_equal(sums, r[2])
     finally:
         dev.free()
+
+
+def test_sources_that_end_their_allocation(gpu_codec):
+    """Regression (round 2 block-size sweep): the general emit path read up to ~60 bytes past the last literal
+    of a chunk; with a source buffer that ends exactly at the end of its HIP allocation (128 MiB single-partition
+    blocks) that was a GPU memory fault.  Two such tasks in one batch, round trip checked."""
+    from s3shuffle import datagen
+
+    dev = _Dev()
+    try:
+        tasks, host = [], []
+        for t in range(2):
+            data, offs = datagen.skew_block(128 << 20, "terasort", seed=5, map_id=t)
+            cap = gpu_codec.max_compressed_size(LZ4, offs)
+            d_src = dev.upload(data)  # hipMalloc of exactly data.size bytes
+            d_dst = dev.alloc(cap)
+            tasks.append((d_src, offs, d_dst, cap))
+            host.append(data)
+        res = gpu_codec.compress_map_outputs_batch_device(LZ4, ADLER, tasks)
+        for t, (total, index, sums) in enumerate(res):
+            d_out = dev.alloc(host[t].size)
+            n = gpu_codec.decompress_range_device(LZ4, ADLER, tasks[t][2], total, index, sums, d_out, host[t].size)
+            assert n == host[t].size
+            assert np.array_equal(dev.download(d_out, n), host[t])
+    finally:
+        dev.free()
