@@ -292,6 +292,20 @@ def main():
                         acc[4] += c.stage_ms(s3shuffle.codec.STAGE_TOTAL)
                         n += 1
                 mine = []
+            if batch_n > 1 and decompress:
+                for b0 in range(0, len(mine), batch_n):
+                    grp = mine[b0:b0 + batch_n]
+                    res = c.decompress_ranges_batch_device(
+                        codec_id, algo_id, [(tasks[i]["dst"].data_ptr(), tasks[i]["total"], tasks[i]["index"], tasks[i]["sums"],
+                                             tasks[i]["out"].data_ptr(), tasks[i]["u"]) for i in grp])
+                    for i, r in zip(grp, res):
+                        assert r[0] == 0 and r[1] == tasks[i]["u"]
+                    if record:
+                        acc[0] += c.stage_ms(s3shuffle.codec.STAGE_CODEC)
+                        acc[3] += c.stage_ms(s3shuffle.codec.STAGE_CHECKSUM)
+                        acc[4] += c.stage_ms(s3shuffle.codec.STAGE_TOTAL)
+                        n += 1
+                mine = []
             for i in mine:
                 t = tasks[i]
                 if decompress:
@@ -358,7 +372,7 @@ def main():
         value = u_all * args.steps / elapsed / 1e9
         launches = max(stage["launches"], 1)
         codec_ms = stage["codec"] / launches          # the LZ4 block-compress kernel alone
-        tasks_per_launch = batch_n if (batch_n > 0 and not decompress) else 1
+        tasks_per_launch = batch_n if batch_n > 0 else 1
         u_launch = u_rank / len(tasks) * tasks_per_launch
         c_launch = c_rank / len(tasks) * tasks_per_launch
         if codec_name == "lz4" and not decompress:

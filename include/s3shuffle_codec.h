@@ -66,8 +66,9 @@
 extern "C" {
 #endif
 
-#define S3S_ABI_VERSION 3 /* 2: + segments entry points, page-locked staging, tuning options 6, 7;
-                             3: + s3s_compress_map_outputs_batch_device / s3s_decompress_ranges_batch_device */
+#define S3S_ABI_VERSION 4 /* 2: + segments entry points, page-locked staging, tuning options 6, 7;
+                             3: + s3s_compress_map_outputs_batch_device;
+                             4: + s3s_decompress_ranges_batch_device; decode variants {3, 4}, LZ4 parses {1, 9, 10} */
 
 /* spark.io.compression.codec (only when spark.shuffle.compress=true) */
 enum { S3S_CODEC_NONE = 0, S3S_CODEC_LZ4 = 1, S3S_CODEC_SNAPPY = 2 };
@@ -207,6 +208,27 @@ int s3s_decompress_range_device(s3s_ctx* ctx, int codec, int checksum_algo,
                                 const int64_t* part_offsets, const int64_t* ref_checksums,
                                 int32_t nparts, uint8_t* d_dst, int64_t dst_capacity,
                                 int64_t* out_len, int32_t* out_bad_partition);
+/* Batched reduce side: many fetched ranges (the blocks a reduce task's prefetcher has staged — reference
+ * buffers of 8 MiB..128 MiB, S3ShuffleDispatcher.scala:55-57, S3BufferedPrefetchIterator.scala:102-153) in ONE
+ * call: checksums and frame discovery of all ranges are queued back to back, ONE decode launch covers the
+ * frames of every range, and the host waits three times per batch instead of three times per range.  Every
+ * range gets exactly what s3s_decompress_range_device would have reported for it alone (status, out_len,
+ * bad_partition).  Returns S3S_OK or the first failing range's error. */
+typedef struct s3s_fetch_range {
+  const uint8_t* d_comp;         /* in: device memory, comp_len bytes */
+  int64_t comp_len;              /* in */
+  const int64_t* part_offsets;   /* in: host array [num_partitions + 1], relative to the range start */
+  const int64_t* ref_checksums;  /* in: host array [num_partitions] (may be NULL iff checksum NONE) */
+  int32_t num_partitions;        /* in */
+  uint8_t* d_dst;                /* in: device buffer for the decoded bytes */
+  int64_t dst_capacity;          /* in */
+  int64_t out_len;               /* out: decoded bytes */
+  int32_t bad_partition;         /* out: first partition with a wrong checksum, or -1 */
+  int32_t status;                /* out: S3S_OK / S3S_E_CHECKSUM / S3S_E_BAD_FRAME / S3S_E_CAPACITY / ... */
+} s3s_fetch_range;
+int s3s_decompress_ranges_batch_device(s3s_ctx* ctx, int codec, int checksum_algo,
+                                       s3s_fetch_range* ranges, int32_t n_ranges);
+
 /* Multi-spill map tasks.  When a map task spilled N times, Spark's merge hands every partition to the
  * partition writer as the concatenation of N independently written pieces, and on the JVM each piece is
  * one COMPLETE codec stream (LZ4Block end frame / Snappy stream header included) — see the writers that

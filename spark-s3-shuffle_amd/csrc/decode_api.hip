@@ -320,3 +320,264 @@ int s3s_decompress_range(s3s_ctx* ctx, int codec, int checksum_algo, const uint8
 }
 
 }  // extern "C"
+
+// ---- batched reduce side -----------------------------------------------------------------------------------
+namespace {
+// frames of one range: payload offsets and output offsets become absolute addresses, so that ONE decode launch
+// (comp = dst = nullptr) covers the frames of every range; a range that failed an earlier check gets empty frames
+__global__ void rebase_frames_kernel(Frame* frames, const int64_t* out_rel, int64_t* out_abs, int32_t n,
+                                     int64_t comp_base, int64_t dst_base, int32_t skip) {
+  const int32_t i = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= n) return;
+  if (skip) {
+    frames[i].comp_off = 0;
+    frames[i].comp_len = 0;
+    frames[i].orig_len = 0;
+    frames[i].method = 0x10;
+    out_abs[i] = dst_base;
+    return;
+  }
+  frames[i].comp_off += comp_base;
+  out_abs[i] = out_rel[i] + dst_base;
+}
+}  // namespace
+
+extern "C" int s3s_decompress_ranges_batch_device(s3s_ctx* ctx, int codec, int checksum_algo, s3s_fetch_range* R,
+                                                  int32_t n_ranges) {
+  if (!ctx) return S3S_E_INVALID;
+  ctx->err[0] = 0;
+  if (n_ranges < 0 || (n_ranges > 0 && !R)) return fail(ctx, S3S_E_INVALID, "null range array or negative count");
+  if (codec != S3S_CODEC_NONE && codec != S3S_CODEC_LZ4 && codec != S3S_CODEC_SNAPPY)
+    return fail(ctx, S3S_E_INVALID, "unknown codec %d", codec);
+  if (checksum_algo != S3S_CHECKSUM_NONE && checksum_algo != S3S_CHECKSUM_ADLER32 && checksum_algo != S3S_CHECKSUM_CRC32)
+    return fail(ctx, S3S_E_INVALID, "Unsupported shuffle checksum algorithm: %d", checksum_algo);
+  auto single = [&](s3s_fetch_range& r) {
+    r.status = s3s_decompress_range_device(ctx, codec, checksum_algo, r.d_comp, r.comp_len, r.part_offsets,
+                                           r.ref_checksums, r.num_partitions, r.d_dst, r.dst_capacity, &r.out_len,
+                                           &r.bad_partition);
+  };
+  auto first_error = [&]() -> int {
+    for (int32_t r = 0; r < n_ranges; r++)
+      if (R[r].status != S3S_OK)
+        return fail(ctx, R[r].status, "range %d of the batch failed (%s)", r,
+                    R[r].status == S3S_E_CHECKSUM ? "Invalid checksum detected" : R[r].status == S3S_E_CAPACITY ? "dst_capacity too small" : "Stream is corrupted");
+    return S3S_OK;
+  };
+  if (n_ranges == 0) return S3S_OK;
+  if (codec == S3S_CODEC_NONE || n_ranges == 1) {  // nothing to batch
+    for (int32_t r = 0; r < n_ranges; r++) single(R[r]);
+    return first_error();
+  }
+  // ---- validate, count ------------------------------------------------------------------------------------------
+  int64_t n_parts = 0, n_segs = 0;
+  for (int32_t r = 0; r < n_ranges; r++) {
+    s3s_fetch_range& k = R[r];
+    k.status = S3S_OK;
+    k.out_len = 0;
+    k.bad_partition = -1;
+    if (k.num_partitions < 0 || !k.part_offsets || k.comp_len < 0 || k.dst_capacity < 0)
+      return fail(ctx, S3S_E_INVALID, "range %d: null/invalid argument", r);
+    if (k.part_offsets[0] != 0 || k.part_offsets[k.num_partitions] != k.comp_len)
+      return fail(ctx, S3S_E_INVALID, "range %d: part_offsets must span [0, comp_len]", r);
+    for (int32_t p = 0; p < k.num_partitions; p++) {
+      if (k.part_offsets[p + 1] < k.part_offsets[p]) return fail(ctx, S3S_E_INVALID, "range %d: part_offsets not monotonic at %d", r, p);
+      n_segs += worst_segs(k.part_offsets[p + 1] - k.part_offsets[p]);
+    }
+    if (checksum_algo != S3S_CHECKSUM_NONE && k.num_partitions > 0 && !k.ref_checksums)
+      return fail(ctx, S3S_E_INVALID, "range %d: ref_checksums is null but a checksum algorithm is selected", r);
+    if ((k.comp_len > 0 && !k.d_comp) || (k.dst_capacity > 0 && !k.d_dst)) return fail(ctx, S3S_E_INVALID, "range %d: null data pointer", r);
+    n_parts += k.num_partitions;
+  }
+  if (n_segs > 0x7fffff00ll || n_parts > 0x7fffff00ll) return fail(ctx, S3S_E_UNSUPPORTED, "batch too large for one call");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  for (auto& v : ctx->stage_ms) v = 0;
+  const bool do_sum = checksum_algo != S3S_CHECKSUM_NONE;
+  const size_t np1 = (size_t)n_parts + (size_t)n_ranges;  // sum of (n_r + 1)
+  auto al = [](size_t x) { return (x + 15) & ~size_t(15); };
+  // pinned staging: [offsets][seg_start][sums][n_frames per range][total per range][status: n_ranges + 1]
+  const size_t o_off = 0, o_seg = al(o_off + 8 * np1), o_sums = al(o_seg + 4 * np1), o_nf = al(o_sums + 8 * ((size_t)n_parts + 1)),
+               o_tot = al(o_nf + 8 * (size_t)n_ranges), o_st = al(o_tot + 8 * (size_t)n_ranges),
+               stage_total = o_st + 4 * ((size_t)n_ranges + 1) + 16;
+  int rc;
+  if ((rc = ensure_stage(ctx, stage_total))) return rc;
+  uint8_t* hs = static_cast<uint8_t*>(ctx->h_stage);
+  int64_t* h_off = reinterpret_cast<int64_t*>(hs + o_off);
+  int32_t* h_seg = reinterpret_cast<int32_t*>(hs + o_seg);
+  int64_t* h_sums = reinterpret_cast<int64_t*>(hs + o_sums);
+  int64_t* h_nf = reinterpret_cast<int64_t*>(hs + o_nf);
+  int64_t* h_tot = reinterpret_cast<int64_t*>(hs + o_tot);
+  int32_t* h_st = reinterpret_cast<int32_t*>(hs + o_st);
+  // device workspaces, all sized up front (no reallocation between the queued kernels)
+  // discovery workspace per range: LZ4 4 x (tiles + 1) int64 + (tiles + 1) int32; Snappy (n + 1) u32 + (n + 2) int64
+  std::vector<size_t> ws_off((size_t)n_ranges + 1), first_part((size_t)n_ranges + 1), first_seg((size_t)n_ranges + 1);
+  {
+    size_t w = 0, pp = 0, sg = 0;
+    for (int32_t r = 0; r < n_ranges; r++) {
+      ws_off[(size_t)r] = w;
+      first_part[(size_t)r] = pp;
+      first_seg[(size_t)r] = sg;
+      const s3s_fetch_range& k = R[r];
+      if (codec == S3S_CODEC_LZ4) {
+        const size_t t1 = (size_t)lz4_tile_count(k.comp_len) + 1;
+        w += al(4 * 8 * t1 + 4 * t1);
+      } else {
+        w += al(al(4 * ((size_t)k.num_partitions + 1)) + 8 * ((size_t)k.num_partitions + 2));
+      }
+      int32_t seg_r = 0;
+      for (int32_t p = 0; p < k.num_partitions; p++) {
+        h_off[pp + (size_t)r + (size_t)p] = k.part_offsets[p];
+        h_seg[pp + (size_t)r + (size_t)p] = seg_r;
+        seg_r += worst_segs(k.part_offsets[p + 1] - k.part_offsets[p]);
+      }
+      h_off[pp + (size_t)r + (size_t)k.num_partitions] = k.comp_len;
+      h_seg[pp + (size_t)r + (size_t)k.num_partitions] = seg_r;
+      pp += (size_t)k.num_partitions;
+      sg += (size_t)seg_r;
+    }
+    ws_off[(size_t)n_ranges] = w;
+    first_part[(size_t)n_ranges] = pp;
+    first_seg[(size_t)n_ranges] = sg;
+  }
+  if ((rc = ensure(ctx, B_OFFSETS, 8 * np1))) return rc;
+  if ((rc = ensure(ctx, B_SEG_START, 4 * np1))) return rc;
+  if ((rc = ensure(ctx, B_SUMS, 8 * ((size_t)n_parts + 1)))) return rc;
+  if ((rc = ensure(ctx, B_PARTIAL, 16 * (first_seg[(size_t)n_ranges] > 0 ? first_seg[(size_t)n_ranges] : 1)))) return rc;
+  if ((rc = ensure(ctx, B_PART_NFRAMES, ws_off[(size_t)n_ranges] + 16))) return rc;
+  if ((rc = ensure(ctx, B_STATUS, 4 * ((size_t)n_ranges + 1) + 16))) return rc;
+  HIP_TRY(ctx, hipMemsetAsync(ctx->buf[B_STATUS].p, 0, 4 * ((size_t)n_ranges + 1) + 16, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_OFFSETS].p, h_off, 8 * np1, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_SEG_START].p, h_seg, 4 * np1, hipMemcpyHostToDevice, ctx->stream));
+  record(ctx, 0);
+  int32_t* d_status = dev<int32_t>(ctx, B_STATUS);
+  // ---- phase 1: checksums + frame discovery of every range, one wait ---------------------------------------------
+  for (int32_t r = 0; r < n_ranges; r++) {
+    const s3s_fetch_range& k = R[r];
+    const size_t pp = first_part[(size_t)r] + (size_t)r;
+    if (do_sum && k.num_partitions > 0)
+      launch_checksum_with_tables(checksum_algo, k.d_comp, dev<int64_t>(ctx, B_OFFSETS) + pp, k.num_partitions,
+                                  dev<int32_t>(ctx, B_SEG_START) + pp, (int32_t)(first_seg[(size_t)r + 1] - first_seg[(size_t)r]),
+                                  ctx->buf[B_TABLES].p, dev<uint32_t>(ctx, B_PARTIAL) + 4 * first_seg[(size_t)r],
+                                  dev<int64_t>(ctx, B_SUMS) + first_part[(size_t)r], k.comp_len, ctx->stream);
+  }
+  record(ctx, 1);
+  for (int32_t r = 0; r < n_ranges; r++) {
+    const s3s_fetch_range& k = R[r];
+    h_nf[r] = 0;
+    if (k.comp_len == 0 || k.num_partitions == 0) continue;
+    uint8_t* ws = dev<uint8_t>(ctx, B_PART_NFRAMES) + ws_off[(size_t)r];
+    if (codec == S3S_CODEC_LZ4) {
+      const int32_t nt = lz4_tile_count(k.comp_len);
+      int64_t* d_spec_entry = reinterpret_cast<int64_t*>(ws);
+      int64_t* d_spec_exit = d_spec_entry + (nt + 1);
+      int64_t* d_true_entry = d_spec_exit + (nt + 1);
+      int64_t* d_frame_base = d_true_entry + (nt + 1);
+      int32_t* d_spec_count = reinterpret_cast<int32_t*>(d_frame_base + (nt + 1));
+      launch_lz4_discover(k.d_comp, k.comp_len, nt, d_spec_entry, d_spec_exit, d_spec_count, d_true_entry, d_frame_base,
+                          d_status + r, ctx->stream);
+      HIP_TRY(ctx, hipMemcpyAsync(&h_nf[r], d_frame_base + nt, 8, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+      const size_t pp = first_part[(size_t)r] + (size_t)r;
+      uint32_t* d_cnt = reinterpret_cast<uint32_t*>(ws);
+      int64_t* d_base = reinterpret_cast<int64_t*>(ws + al(4 * ((size_t)k.num_partitions + 1)));
+      launch_snappy_count_frames(k.d_comp, dev<int64_t>(ctx, B_OFFSETS) + pp, k.num_partitions, d_cnt, d_status + r, ctx->stream);
+      launch_scan_u32(d_cnt, k.num_partitions, d_base, ctx->stream);
+      HIP_TRY(ctx, hipMemcpyAsync(&h_nf[r], d_base + k.num_partitions, 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  if (do_sum && n_parts > 0)
+    HIP_TRY(ctx, hipMemcpyAsync(h_sums, ctx->buf[B_SUMS].p, 8 * (size_t)n_parts, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(h_st, d_status, 4 * (size_t)n_ranges, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  int64_t total_frames = 0;
+  std::vector<int64_t> first_frame((size_t)n_ranges + 1);
+  for (int32_t r = 0; r < n_ranges; r++) {
+    s3s_fetch_range& k = R[r];
+    first_frame[(size_t)r] = total_frames;
+    if (do_sum)
+      for (int32_t p = 0; p < k.num_partitions; p++)
+        if (h_sums[first_part[(size_t)r] + (size_t)p] != k.ref_checksums[p]) {
+          k.status = S3S_E_CHECKSUM;
+          k.bad_partition = p;
+          break;
+        }
+    if (k.status == S3S_OK && h_st[r] != 0) k.status = S3S_E_BAD_FRAME;
+    if (k.status != S3S_OK) h_nf[r] = 0;  // no frames of this range take part in what follows
+    total_frames += h_nf[r];
+  }
+  first_frame[(size_t)n_ranges] = total_frames;
+  if (total_frames > 0x7fffff00ll) return fail(ctx, S3S_E_UNSUPPORTED, "too many frames in one call");
+  // ---- phase 2: frame records + output offsets of every range, one wait ----------------------------------------------
+  const size_t nf1 = (size_t)total_frames + (size_t)n_ranges + 1;
+  if ((rc = ensure(ctx, B_FRAMES, sizeof(Frame) * nf1))) return rc;
+  if ((rc = ensure(ctx, B_ITEM_SIZE, 4 * nf1))) return rc;
+  if ((rc = ensure(ctx, B_FRAME_OUT, 8 * nf1))) return rc;
+  if ((rc = ensure(ctx, B_ITEM_OFF, 8 * nf1))) return rc;
+  for (int32_t r = 0; r < n_ranges; r++) {
+    const s3s_fetch_range& k = R[r];
+    h_tot[r] = 0;
+    const int64_t nf = h_nf[r], f0 = first_frame[(size_t)r];
+    if (nf == 0) continue;
+    uint8_t* ws = dev<uint8_t>(ctx, B_PART_NFRAMES) + ws_off[(size_t)r];
+    Frame* d_fr = dev<Frame>(ctx, B_FRAMES) + f0;
+    uint32_t* d_orig = dev<uint32_t>(ctx, B_ITEM_SIZE) + f0 + r;
+    int64_t* d_out_rel = dev<int64_t>(ctx, B_FRAME_OUT) + f0 + r;
+    if (codec == S3S_CODEC_LZ4) {
+      const int32_t nt = lz4_tile_count(k.comp_len);
+      int64_t* d_true_entry = reinterpret_cast<int64_t*>(ws) + 2 * (nt + 1);
+      int64_t* d_frame_base = d_true_entry + (nt + 1);
+      launch_lz4_emit_frames(k.d_comp, k.comp_len, nt, d_true_entry, d_frame_base, d_fr, d_orig, nf, d_out_rel, d_status + r, ctx->stream);
+    } else {
+      const size_t pp = first_part[(size_t)r] + (size_t)r;
+      int64_t* d_base = reinterpret_cast<int64_t*>(ws + al(4 * ((size_t)k.num_partitions + 1)));
+      launch_snappy_emit_frames(k.d_comp, dev<int64_t>(ctx, B_OFFSETS) + pp, k.num_partitions, d_base, d_fr, d_orig, d_status + r, ctx->stream);
+      launch_scan_u32(d_orig, nf, d_out_rel, ctx->stream);
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(&h_tot[r], d_out_rel + nf, 8, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(h_st, d_status, 4 * (size_t)n_ranges, hipMemcpyDeviceToHost, ctx->stream));
+  record(ctx, 2);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  // ---- phase 3: ONE decode launch over the frames of every range ------------------------------------------------------
+  for (int32_t r = 0; r < n_ranges; r++) {
+    s3s_fetch_range& k = R[r];
+    const int64_t nf = h_nf[r], f0 = first_frame[(size_t)r];
+    if (k.status == S3S_OK && h_st[r] != 0) k.status = S3S_E_BAD_FRAME;
+    if (k.status == S3S_OK) {
+      k.out_len = h_tot[r];
+      if (h_tot[r] > k.dst_capacity) k.status = S3S_E_CAPACITY;
+    }
+    if (nf == 0) continue;
+    hipLaunchKernelGGL(rebase_frames_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, ctx->stream,
+                       dev<Frame>(ctx, B_FRAMES) + f0, dev<int64_t>(ctx, B_FRAME_OUT) + f0 + r, dev<int64_t>(ctx, B_ITEM_OFF) + f0,
+                       (int32_t)nf, (int64_t)reinterpret_cast<uintptr_t>(k.d_comp), (int64_t)reinterpret_cast<uintptr_t>(k.d_dst),
+                       k.status != S3S_OK ? 1 : 0);
+  }
+  int32_t* d_dec_status = d_status + n_ranges;
+  if (total_frames > 0) {
+    if (codec == S3S_CODEC_LZ4)
+      launch_lz4_decompress(nullptr, dev<Frame>(ctx, B_FRAMES), (int32_t)total_frames, dev<int64_t>(ctx, B_ITEM_OFF), nullptr,
+                            d_dec_status, ctx->lz4_decode_variant, ctx->stream);
+    else
+      launch_snappy_decompress(nullptr, dev<Frame>(ctx, B_FRAMES), (int32_t)total_frames, dev<int64_t>(ctx, B_ITEM_OFF), nullptr,
+                               d_dec_status, ctx->lz4_decode_variant, ctx->stream);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  record(ctx, 3);
+  HIP_TRY(ctx, hipMemcpyAsync(&h_st[n_ranges], d_dec_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->profile) {
+    float ms = 0;
+    hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]); ctx->stage_ms[S3S_STAGE_TOTAL] = ms;
+    hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); ctx->stage_ms[S3S_STAGE_CHECKSUM] = ms;
+    hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]); ctx->stage_ms[S3S_STAGE_DISCOVER] = ms;
+    hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); ctx->stage_ms[S3S_STAGE_CODEC] = ms;
+  }
+  if (h_st[n_ranges] != 0) {
+    // some frame of the batch is corrupt (or unsupported): decode the ranges one by one to say which
+    for (int32_t r = 0; r < n_ranges; r++)
+      if (R[r].status == S3S_OK) single(R[r]);
+  }
+  return first_error();
+}

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
     if (lane == 0) atomicExch(status, S3S_E_UNSUPPORTED);
     return;
   }
-  if (kFmt == kFmtLz4 && olen == 0) return;
+  if (olen == 0 && (kFmt == kFmtLz4 || clen == 0)) return;  // (end-of-stream frame; a frame the batched call skips)
   const uint8_t* c = comp + fr.comp_off;
   uint8_t* out = dst + frame_out[f];
   bool bad = false;

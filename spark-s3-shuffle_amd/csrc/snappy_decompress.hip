@@ -104,6 +104,7 @@ __global__ __launch_bounds__(kWave) void snappy_decompress_valu_kernel(
   const Frame fr = frames[f];
   const int olen = fr.orig_len, clen = fr.comp_len;
   const int lane = threadIdx.x;
+  if (olen == 0 && clen == 0) return;  // a frame the batched call skips
   if (olen > kMaxBlock) {
     if (lane == 0) atomicExch(status, S3S_E_UNSUPPORTED);
     return;

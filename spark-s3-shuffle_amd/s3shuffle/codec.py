@@ -61,6 +61,14 @@ class MapTask(ctypes.Structure):
 _LIB = None
 
 
+class FetchRange(ctypes.Structure):
+    """s3s_fetch_range (include/s3shuffle_codec.h)."""
+    _fields_ = [("d_comp", ctypes.c_void_p), ("comp_len", ctypes.c_int64),
+                ("part_offsets", ctypes.POINTER(ctypes.c_int64)), ("ref_checksums", ctypes.POINTER(ctypes.c_int64)),
+                ("num_partitions", ctypes.c_int32), ("d_dst", ctypes.c_void_p), ("dst_capacity", ctypes.c_int64),
+                ("out_len", ctypes.c_int64), ("bad_partition", ctypes.c_int32), ("status", ctypes.c_int32)]
+
+
 def load_library() -> ctypes.CDLL:
     """Loads the HIP codec library.  Fails loudly if it has not been built."""
     global _LIB
@@ -118,6 +126,8 @@ def load_library() -> ctypes.CDLL:
     lib.s3s_compress_map_output_segments_device.argtypes = seg_args
     lib.s3s_compress_map_outputs_batch_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(MapTask),
                                                           ctypes.c_int32]
+    lib.s3s_decompress_ranges_batch_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(FetchRange),
+                                                       ctypes.c_int32]
     lib.s3s_host_alloc.restype = vp
     lib.s3s_host_alloc.argtypes = [ctypes.c_int64]
     lib.s3s_host_free.argtypes = [vp]
@@ -339,6 +349,30 @@ class Codec:
         self._check(rc, bad.value)
         return int(out_len.value)
 
+
+
+    def decompress_ranges_batch_device(self, codec: int, checksum: int, ranges, raise_on_error: bool = True):
+        """Batched device form: `ranges` = [(d_comp, comp_len, part_offsets, ref_checksums, d_dst, dst_capacity), ...]
+        -> per range (status, decoded bytes, bad partition).  One decode launch for all, three stream syncs."""
+        arr = (FetchRange * len(ranges))()
+        keep = []
+        for i, (d_comp, comp_len, part_offsets, refs, d_dst, cap) in enumerate(ranges):
+            offs = _i64(part_offsets)
+            r = _i64(refs) if refs is not None else None
+            keep.append((offs, r))
+            arr[i].d_comp = d_comp
+            arr[i].comp_len = int(comp_len)
+            arr[i].part_offsets = _p64(offs)
+            arr[i].ref_checksums = _p64(r) if r is not None else None
+            arr[i].num_partitions = len(offs) - 1
+            arr[i].d_dst = d_dst
+            arr[i].dst_capacity = int(cap)
+        rc = self._lib.s3s_decompress_ranges_batch_device(self._h, codec, checksum, arr, len(ranges))
+        out = [(int(arr[i].status), int(arr[i].out_len), int(arr[i].bad_partition)) for i in range(len(ranges))]
+        if raise_on_error:
+            bad = next((i for i, o in enumerate(out) if o[0] != 0), -1)
+            self._check(rc, out[bad][2] if bad >= 0 else -1)
+        return out
 
 
 class PinnedBuffer:
