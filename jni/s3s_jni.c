@@ -1,0 +1,143 @@
+/* s3s_jni.c — JNI translation unit between org.apache.spark.shuffle.gpu.S3SCodec (scala/…/S3SCodec.scala) and the
+ * C-ABI in include/s3shuffle_codec.h.  Logic-free on purpose: every function pins its arrays, forwards to the
+ * entry point of the same name and releases the arrays; error codes go back as the int result and are mapped to
+ * the reference's exceptions by the Scala side.
+ *
+ * What it binds into:
+ *   map side     S3ShuffleMapOutputWriter.commitAllPartitions      shuffle/S3ShuffleMapOutputWriter.scala:91-118
+ *                S3ShuffleOutputStream.write (staging)             shuffle/S3ShuffleMapOutputWriter.scala:168-202
+ *                S3SingleSpillShuffleMapOutputWriter.transferMapSpillFile
+ *                                                                  shuffle/S3SingleSpillShuffleMapOutputWriter.scala:24-64
+ *   reduce side  S3ShuffleReader.read (validation + wrapStream)    storage/S3ShuffleReader.scala:98-110
+ *
+ * Build (with a JDK):  cc -O2 -fPIC -shared -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -Iinclude \
+ *                         jni/s3s_jni.c -Lspark-s3-shuffle_amd/lib -ls3shuffle_codec -o libs3s_jni.so
+ * This image has no JDK: tests/test_jni_shim.py compiles the file against tests/mock_jni/jni.h instead, so the
+ * signatures stay in step with the header.
+ *
+ * Buffers: `src` / `dst` / `comp` are DIRECT ByteBuffers — page-locked ones from hostAlloc() (below) — so there is
+ * no GetPrimitiveArrayCritical section around a GPU call.  long[] / int[] arguments are small (N + 1 entries). */
+#include <jni.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "s3shuffle_codec.h"
+
+#define CTX(h) ((s3s_ctx*)(intptr_t)(h))
+#define FN(name) Java_org_apache_spark_shuffle_gpu_S3SCodec_##name
+
+static jlong* pin(JNIEnv* e, jlongArray a) { return a ? (*e)->GetLongArrayElements(e, a, NULL) : NULL; }
+static void unpin(JNIEnv* e, jlongArray a, jlong* p, jint mode) {
+  if (a && p) (*e)->ReleaseLongArrayElements(e, a, p, mode);
+}
+static uint8_t* addr(JNIEnv* e, jobject buf) { return buf ? (uint8_t*)(*e)->GetDirectBufferAddress(e, buf) : NULL; }
+
+/* ---- lifecycle, options, errors ---------------------------------------------------------------------------- */
+JNIEXPORT jint JNICALL FN(abiVersion)(JNIEnv* e, jclass c) { (void)e; (void)c; return s3s_abi_version(); }
+JNIEXPORT jint JNICALL FN(deviceCount)(JNIEnv* e, jclass c) { (void)e; (void)c; return s3s_device_count(); }
+JNIEXPORT jlong JNICALL FN(create)(JNIEnv* e, jclass c, jint device, jlong scratch) {
+  (void)e; (void)c;
+  return (jlong)(intptr_t)s3s_create(device, scratch);
+}
+JNIEXPORT void JNICALL FN(destroy)(JNIEnv* e, jclass c, jlong h) { (void)e; (void)c; s3s_destroy(CTX(h)); }
+JNIEXPORT jint JNICALL FN(setOption)(JNIEnv* e, jclass c, jlong h, jint key, jlong v) {
+  (void)e; (void)c;
+  return s3s_set_option(CTX(h), key, v);
+}
+JNIEXPORT jlong JNICALL FN(getOption)(JNIEnv* e, jclass c, jlong h, jint key) {
+  (void)e; (void)c;
+  return s3s_get_option(CTX(h), key);
+}
+JNIEXPORT jstring JNICALL FN(lastError)(JNIEnv* e, jclass c, jlong h) {
+  (void)c;
+  return (*e)->NewStringUTF(e, s3s_last_error(CTX(h)));
+}
+
+/* ---- page-locked staging: the shim's direct ByteBuffers come from here, never from allocateDirect ------------ */
+JNIEXPORT jobject JNICALL FN(hostAlloc)(JNIEnv* e, jclass c, jlong bytes) {
+  (void)c;
+  void* p = s3s_host_alloc(bytes);
+  return p ? (*e)->NewDirectByteBuffer(e, p, bytes) : NULL;
+}
+JNIEXPORT void JNICALL FN(hostFree)(JNIEnv* e, jclass c, jobject buf) {
+  (void)c;
+  s3s_host_free(addr(e, buf));
+}
+
+/* ---- sizing -------------------------------------------------------------------------------------------------- */
+JNIEXPORT jlong JNICALL FN(maxCompressedSize)(JNIEnv* e, jclass c, jlong h, jint codec, jlongArray srcOffsets, jint n) {
+  (void)c;
+  jlong* o = pin(e, srcOffsets);
+  const jlong r = s3s_max_compressed_size(CTX(h), codec, (const int64_t*)o, n);
+  unpin(e, srcOffsets, o, JNI_ABORT);
+  return r;
+}
+JNIEXPORT jint JNICALL FN(decompressedSize)(JNIEnv* e, jclass c, jlong h, jint codec, jobject comp, jlong compLen,
+                                            jlongArray outLen) {
+  (void)c;
+  jlong* ol = pin(e, outLen);
+  const int rc = s3s_decompressed_size(CTX(h), codec, addr(e, comp), compLen, (int64_t*)ol);
+  unpin(e, outLen, ol, 0);
+  return rc;
+}
+
+/* ---- map side: compress + checksum of one map task (commitAllPartitions / transferMapSpillFile) ---------------- */
+JNIEXPORT jint JNICALL FN(compressMapOutput)(JNIEnv* e, jclass c, jlong h, jint codec, jint algo, jobject src,
+                                             jlongArray srcOffsets, jint n, jobject dst, jlong dstCap,
+                                             jlongArray outIndex, jlongArray outChecksums, jlongArray outTotal) {
+  (void)c;
+  jlong *so = pin(e, srcOffsets), *oi = pin(e, outIndex), *oc = pin(e, outChecksums), *ot = pin(e, outTotal);
+  const int rc = s3s_compress_map_output(CTX(h), codec, algo, addr(e, src), (const int64_t*)so, n, addr(e, dst), dstCap,
+                                         (int64_t*)oi, (int64_t*)oc, (int64_t*)ot);
+  unpin(e, srcOffsets, so, JNI_ABORT);
+  unpin(e, outIndex, oi, 0);
+  unpin(e, outChecksums, oc, 0);
+  unpin(e, outTotal, ot, 0);
+  return rc;
+}
+
+/* multi-spill map tasks: one codec stream per spill piece (UnsafeShuffleWriter / SortShuffleWriter merges) */
+JNIEXPORT jint JNICALL FN(compressMapOutputSegments)(JNIEnv* e, jclass c, jlong h, jint codec, jint algo, jobject src,
+                                                     jlongArray segOffsets, jint nSegs, jintArray partFirstSeg, jint n,
+                                                     jobject dst, jlong dstCap, jlongArray outIndex,
+                                                     jlongArray outChecksums, jlongArray outTotal) {
+  (void)c;
+  jlong *so = pin(e, segOffsets), *oi = pin(e, outIndex), *oc = pin(e, outChecksums), *ot = pin(e, outTotal);
+  jint* pf = (*e)->GetIntArrayElements(e, partFirstSeg, NULL);
+  const int rc = s3s_compress_map_output_segments(CTX(h), codec, algo, addr(e, src), (const int64_t*)so, nSegs,
+                                                  (const int32_t*)pf, n, addr(e, dst), dstCap, (int64_t*)oi,
+                                                  (int64_t*)oc, (int64_t*)ot);
+  (*e)->ReleaseIntArrayElements(e, partFirstSeg, pf, JNI_ABORT);
+  unpin(e, segOffsets, so, JNI_ABORT);
+  unpin(e, outIndex, oi, 0);
+  unpin(e, outChecksums, oc, 0);
+  unpin(e, outTotal, ot, 0);
+  return rc;
+}
+
+/* ---- checksum only (S3ShuffleHelper.createChecksumAlgorithm users) ------------------------------------------------ */
+JNIEXPORT jint JNICALL FN(checksumRanges)(JNIEnv* e, jclass c, jlong h, jint algo, jobject data, jlongArray offsets,
+                                          jint n, jlongArray out) {
+  (void)c;
+  jlong *of = pin(e, offsets), *o = pin(e, out);
+  const int rc = s3s_checksum_ranges(CTX(h), algo, addr(e, data), (const int64_t*)of, n, (int64_t*)o);
+  unpin(e, offsets, of, JNI_ABORT);
+  unpin(e, out, o, 0);
+  return rc;
+}
+
+/* ---- reduce side: verify + decompress one fetched block range (S3ShuffleReader.read) ------------------------------- */
+JNIEXPORT jint JNICALL FN(decompressRange)(JNIEnv* e, jclass c, jlong h, jint codec, jint algo, jobject comp,
+                                           jlong compLen, jlongArray partOffsets, jlongArray refChecksums, jint nparts,
+                                           jobject dst, jlong dstCap, jlongArray outLen, jintArray outBadPartition) {
+  (void)c;
+  jlong *po = pin(e, partOffsets), *rs = pin(e, refChecksums), *ol = pin(e, outLen);
+  jint* ob = (*e)->GetIntArrayElements(e, outBadPartition, NULL);
+  const int rc = s3s_decompress_range(CTX(h), codec, algo, addr(e, comp), compLen, (const int64_t*)po,
+                                      (const int64_t*)rs, nparts, addr(e, dst), dstCap, (int64_t*)ol, (int32_t*)ob);
+  unpin(e, partOffsets, po, JNI_ABORT);
+  unpin(e, refChecksums, rs, JNI_ABORT);
+  unpin(e, outLen, ol, 0);
+  (*e)->ReleaseIntArrayElements(e, outBadPartition, ob, 0);
+  return rc;
+}

@@ -1,0 +1,102 @@
+//
+// S3SCodec — JVM side of the JNI binding (jni/s3s_jni.c) to include/s3shuffle_codec.h.
+//
+// One native context (HIP stream + device workspace + page-locked staging) per task thread, created lazily on the
+// device `mapId % nGpu` (the rule the plugin already uses for folder prefixes, S3ShuffleDispatcher.scala:142-143).
+// Return codes are turned into the exceptions the reference raises today, so the callers in S3GpuMapOutput.scala /
+// S3GpuBlockDecoder.scala behave like the code they replace:
+//   S3S_E_INVALID    RuntimeException            (S3ShuffleMapOutputWriter.scala:69-73, 96-100 preconditions)
+//   S3S_E_CHECKSUM   SparkException("Invalid checksum detected for …")   (S3ChecksumValidationStream.scala:72-74)
+//   S3S_E_BAD_FRAME  IOException("Stream is corrupted")                   ([EXT] LZ4BlockInputStream.refill)
+//   anything else    IOException(lastError) -> Spark task retry
+//
+// NOT COMPILED IN THIS REPOSITORY'S IMAGE (no JDK / scalac): kept as source so that the binding is reviewable and
+// `tests/test_jni_shim.py` can check that every @native method below has its C counterpart with the same arity.
+//
+package org.apache.spark.shuffle.gpu
+
+import java.io.IOException
+import java.nio.ByteBuffer
+
+import org.apache.spark.SparkException
+
+object S3SCodec {
+  // ---- constants of include/s3shuffle_codec.h ----------------------------------------------------------------
+  val CODEC_NONE = 0; val CODEC_LZ4 = 1; val CODEC_SNAPPY = 2
+  val CHECKSUM_NONE = 0; val CHECKSUM_ADLER32 = 1; val CHECKSUM_CRC32 = 2
+  val OK = 0; val E_INVALID = -1; val E_CAPACITY = -2; val E_BAD_FRAME = -3; val E_CHECKSUM = -4
+  val OPT_LZ4_BLOCK_SIZE = 1; val OPT_SNAPPY_BLOCK_SIZE = 2
+  val ABI_VERSION = 4
+
+  // ---- native entry points (jni/s3s_jni.c, one line each) -------------------------------------------------------
+  @native def abiVersion(): Int
+  @native def deviceCount(): Int
+  @native def create(device: Int, scratchBytes: Long): Long
+  @native def destroy(handle: Long): Unit
+  @native def setOption(handle: Long, key: Int, value: Long): Int
+  @native def getOption(handle: Long, key: Int): Long
+  @native def lastError(handle: Long): String
+  @native def hostAlloc(bytes: Long): ByteBuffer
+  @native def hostFree(buffer: ByteBuffer): Unit
+  @native def maxCompressedSize(handle: Long, codec: Int, srcOffsets: Array[Long], n: Int): Long
+  @native def decompressedSize(handle: Long, codec: Int, comp: ByteBuffer, compLen: Long, outLen: Array[Long]): Int
+  @native def compressMapOutput(handle: Long, codec: Int, algo: Int, src: ByteBuffer, srcOffsets: Array[Long], n: Int,
+                                dst: ByteBuffer, dstCap: Long, outIndex: Array[Long], outChecksums: Array[Long],
+                                outTotal: Array[Long]): Int
+  @native def compressMapOutputSegments(handle: Long, codec: Int, algo: Int, src: ByteBuffer, segOffsets: Array[Long],
+                                        nSegs: Int, partFirstSeg: Array[Int], n: Int, dst: ByteBuffer, dstCap: Long,
+                                        outIndex: Array[Long], outChecksums: Array[Long], outTotal: Array[Long]): Int
+  @native def checksumRanges(handle: Long, algo: Int, data: ByteBuffer, offsets: Array[Long], n: Int,
+                             out: Array[Long]): Int
+  @native def decompressRange(handle: Long, codec: Int, algo: Int, comp: ByteBuffer, compLen: Long,
+                              partOffsets: Array[Long], refChecksums: Array[Long], nparts: Int, dst: ByteBuffer,
+                              dstCap: Long, outLen: Array[Long], outBadPartition: Array[Int]): Int
+
+  // ---- loading + per-thread contexts -------------------------------------------------------------------------------
+  @volatile private var loaded = false
+
+  def load(libraryPath: String): Unit = synchronized {
+    if (!loaded) {
+      System.load(libraryPath) // spark.shuffle.s3.gpu.library
+      require(abiVersion() == ABI_VERSION, s"libs3shuffle_codec ABI ${abiVersion()} != $ABI_VERSION")
+      loaded = true
+    }
+  }
+
+  /** A context is not thread-safe: one per task thread and device, kept for the life of the executor. */
+  private val contexts = new ThreadLocal[scala.collection.mutable.Map[Int, Long]] {
+    override def initialValue() = scala.collection.mutable.Map.empty[Int, Long]
+  }
+
+  def forThread(device: Int): Long = contexts.get().getOrElseUpdate(device, {
+    val h = create(device, 0L)
+    if (h == 0L) throw new IOException(s"s3s_create($device) failed: no HIP device (there is no CPU fallback)")
+    h
+  })
+
+  /** mapId % nGpu — S3ShuffleDispatcher.getPath shards folder prefixes the same way. */
+  def deviceFor(mapId: Long, devices: Int): Int = (mapId % math.max(devices, 1)).toInt
+
+  def check(handle: Long, rc: Int, what: => String, badPartition: Int = -1): Unit = rc match {
+    case OK => ()
+    case E_INVALID => throw new RuntimeException(s"Precondition: ${lastError(handle)}")
+    case E_CHECKSUM => throw new SparkException(s"Invalid checksum detected for $what (partition $badPartition)")
+    case E_BAD_FRAME => throw new IOException("Stream is corrupted")
+    case _ => throw new IOException(s"$what: ${lastError(handle)} (code $rc)")
+  }
+
+  def codecId(sparkCodecShortName: String): Int = sparkCodecShortName.toLowerCase match {
+    case "lz4" => CODEC_LZ4
+    case "snappy" => CODEC_SNAPPY
+    case other => throw new IllegalArgumentException(s"spark.io.compression.codec=$other stays on the JVM codecs")
+  }
+
+  def checksumId(enabled: Boolean, algorithm: String): Int =
+    if (!enabled) CHECKSUM_NONE
+    else algorithm.toUpperCase match {
+      case "ADLER32" => CHECKSUM_ADLER32
+      case "CRC32" => CHECKSUM_CRC32
+      // S3ShuffleHelper.createChecksumAlgorithm (S3ShuffleHelper.scala:94-103) rejects everything else too
+      case other => throw new UnsupportedOperationException(s"Unsupported shuffle checksum algorithm: $other")
+    }
+}
