@@ -74,6 +74,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU leg")
     ap.add_argument("--verify", action="store_true", help="check one map task against the oracle first")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no timing: every rank reports (rank, local rank, device, its map ids); rank 0 checks that "
+                         "mapId % nGPU covers every map task exactly once and prints the table as one JSON line "
+                         "(backend nccl on GPUs, gloo without)")
     return ap.parse_args()
 
 
@@ -178,6 +182,44 @@ def cpu_baseline_decompress(workload: str, target_s: float):
     }
 
 
+def dry_run(args, rank: int, local_rank: int, world: int, launched: bool):
+    """Validate rank <-> device <-> mapId without touching the codec (S3ShuffleDispatcher.scala:142-143 rule)."""
+    import torch
+    from s3shuffle import sharding
+
+    has_gpu = torch.cuda.is_available()
+    mine = {"rank": rank, "local_rank": local_rank, "device": f"cuda:{local_rank}" if has_gpu else "cpu",
+            "visible_devices": torch.cuda.device_count() if has_gpu else 0,
+            "map_ids": [int(m) for m in sharding.map_ids_for_rank(rank, world, args.maps_per_gpu)]}
+    table = [mine]
+    if launched:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if has_gpu:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
+        table = [None] * world
+        dist.all_gather_object(table, mine)
+        t = torch.ones(1, device=f"cuda:{local_rank}" if has_gpu else "cpu")
+        dist.all_reduce(t)  # the collective the timed run uses (MAX of elapsed, SUM of bytes)
+        assert int(t.item()) == world
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        all_ids = sorted(m for r in table for m in r["map_ids"])
+        ok = all_ids == list(range(world * args.maps_per_gpu))
+        ok = ok and all(sharding.device_for_map(m, world) == r["rank"] for r in table for m in r["map_ids"])
+        ok = ok and (not has_gpu or all(r["local_rank"] < max(r["visible_devices"], 1) for r in table))
+        print(json.dumps({"dry_run": True, "world": world, "maps_per_gpu": args.maps_per_gpu,
+                          "backend": ("nccl" if has_gpu else "gloo") if launched else None, "ranks": table, "ok": ok}))
+        if not ok:
+            raise SystemExit(2)
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -192,14 +234,20 @@ def main():
     import s3shuffle
     from s3shuffle import sharding
 
+    # one rank per GPU; under torch.distributed.run the process group is ALWAYS created (also with one rank), so the
+    # single-GPU launch line exercises the same RCCL barrier / all_reduce code the N-GPU runs use
+    launched = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or "GROUP_RANK" in os.environ
+    if args.dry_run:
+        return dry_run(args, rank, local_rank, world, launched)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the codec library has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if launched:
         import torch.distributed as dist_mod
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         dist = dist_mod
 

@@ -99,3 +99,24 @@ def test_sharding_helpers():
         "file:///tmp/spark-s3-shuffle/3/app-1/4/shuffle_4_23_0.data"
     assert sharding.block_name(0, 7, "checksum") == "shuffle_0_7_0.checksum"  # no .ADLER32 suffix
     assert struct.pack(">q", 1) == b"\x00" * 7 + b"\x01"
+
+
+def test_bench_dry_run_two_ranks_gloo():
+    """bench.py --gpus 2 --dry-run under torch.distributed.run on the CPU box (gloo): the launch line the driver
+    uses for the scaling runs must come up, agree on mapId % nGPU and cover every map task exactly once."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--dry-run", "--maps-per-gpu", "3"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["ok"] and d["world"] == 2 and d["backend"] == "gloo"
+    assert sorted(m for r in d["ranks"] for m in r["map_ids"]) == list(range(6))
+    assert [r["map_ids"] for r in sorted(d["ranks"], key=lambda r: r["rank"])] == [[0, 2, 4], [1, 3, 5]]
