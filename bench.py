@@ -108,7 +108,7 @@ def usable_cores() -> int:
     return n
 
 
-def cpu_baseline(workload: str, target_s: float):
+def cpu_baseline(workload: str, target_s: float, map_mib: int = 128):
     """The CPU path timed beside the GPU one: one map task per host thread (how Spark runs the
     reference: one task per executor core), each doing LZ4Block framing around liblz4 1.9.3's
     LZ4_compress_default + xxh32 + per-partition checksum + index (oracle/s3s_oracle_mt.c)."""
@@ -116,8 +116,8 @@ def cpu_baseline(workload: str, target_s: float):
 
     _, nparts, codec, algo = WORKLOADS[workload]
     cores = usable_cores()
-    sample_mib = 32
-    parts = max(1, nparts * sample_mib // 128)  # same bytes per partition as the GPU workload
+    sample_mib = map_mib  # the whole map task the GPU leg runs (not a slice)
+    parts = nparts
     from s3shuffle import datagen
     if WORKLOADS[workload][0] == "terasort":
         data, offs = datagen.terasort_map_output(sample_mib << 20, parts, seed=2, map_id=0)
@@ -137,7 +137,7 @@ def cpu_baseline(workload: str, target_s: float):
     one = data.size * 2 / t1 / 1e9
     return {
         "value": round(value, 3), "unit": "GB/s", "cores": cores, "kind": "port",
-        "sample": f"{cores} threads x {reps} reps x one {sample_mib} MiB map-task slice of the workload "
+        "sample": f"{cores} threads x {reps} reps x one whole {sample_mib} MiB map task of the workload "
                   f"({parts} partitions), {codec}+{algo}, map-side compress+checksum; block compressor = "
                   f"{'liblz4 1.9.3 LZ4_compress_default (the code lz4-java JNI binds)' if have_liblz4 else 'oracle restatement'}; "
                   f"JVM/JNI overheads not included (upper bound on the reference path); "
@@ -146,7 +146,7 @@ def cpu_baseline(workload: str, target_s: float):
     }
 
 
-def cpu_baseline_decompress(workload: str, target_s: float):
+def cpu_baseline_decompress(workload: str, target_s: float, map_mib: int = 128):
     """Reduce side on the host cores: one fetched block range per thread, per-partition checksum validation
     (S3ChecksumValidationStream) + LZ4BlockInputStream over liblz4 1.9.3's LZ4_decompress_safe + xxh32 frame
     checks (oracle/s3s_oracle_mt.c) — what the JVM reader does per task, without JVM/JNI overheads."""
@@ -155,8 +155,8 @@ def cpu_baseline_decompress(workload: str, target_s: float):
 
     gen, nparts, codec, algo = WORKLOADS[workload]
     cores = usable_cores()
-    sample_mib = 32
-    parts = max(1, nparts * sample_mib // 128)
+    sample_mib = map_mib
+    parts = nparts
     if gen == "terasort":
         data, offs = datagen.terasort_map_output(sample_mib << 20, parts, seed=2, map_id=0)
     elif gen == "tpcds":
@@ -174,7 +174,7 @@ def cpu_baseline_decompress(workload: str, target_s: float):
     t1, _ = oracle.mt_decompress_bench(codec_o, algo_id, img, index, sums, data.size, 1, reps=4)
     return {
         "value": round(data.size * cores * reps / s / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
-        "sample": f"{cores} threads x {reps} reps x one {sample_mib} MiB map-task slice of the workload ({parts} partitions), "
+        "sample": f"{cores} threads x {reps} reps x one whole {sample_mib} MiB map task of the workload ({parts} partitions), "
                   f"{codec}+{algo}, reduce-side verify+decompress; block decoder = "
                   f"{'liblz4 1.9.3 LZ4_decompress_safe (the code lz4-java JNI binds)' if codec == 'lz4' else 'oracle restatement'}; "
                   f"JVM/JNI overheads not included; os.cpu_count()={os.cpu_count()}, cgroup/affinity limit={cores}",
@@ -463,7 +463,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": ("%s_decompress (one workgroup per frame)" if decompress else "%s_compress (one wavefront per 32 KiB block)") % codec_name,
+                "kernel": ("%s batch decoder (one wavefront per frame, one sequence per lane)" if decompress
+                           else "%s_compress (one wavefront per 32 KiB block)") % codec_name,
                 "achieved": round(achieved, 3),
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
@@ -479,19 +480,28 @@ def main():
             "stages_ms_per_library_call": {k: round(stage[k] / launches, 4) for k in ("hash", "codec", "assemble", "checksum", "total")},
         }
         if world == 1 and not args.no_cpu_baseline:
-            cb = (cpu_baseline_decompress if decompress else cpu_baseline)(args.workload, args.cpu_seconds)
+            cb = (cpu_baseline_decompress if decompress else cpu_baseline)(args.workload, args.cpu_seconds, args.map_mib)
             out["cpu_baseline"] = cb
             if cb:
                 out["speedup_vs_cpu_all_cores"] = round(value / cb["value"], 3)
                 out["speedup_vs_cpu_1_core"] = round(value / cb["single_thread_GBps"], 3)
         else:
             out["cpu_baseline"] = None
-        traffic_file = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(traffic_file):
-            try:
-                out["roofline"]["traffic"] = json.load(open(traffic_file)).get("lz4_compress_hbm_bytes_per_launch")
-            except Exception:
-                pass
+        # roofline.traffic is HBM bytes per launch from PMC counters — only when THIS run was the profiled one (the
+        # profiling script passes the figure in); otherwise null, with a pointer to the tracked PMC pass
+        if os.environ.get("S3S_BENCH_TRAFFIC_BYTES"):
+            out["roofline"]["traffic"] = int(os.environ["S3S_BENCH_TRAFFIC_BYTES"])
+            out["roofline"]["traffic_source"] = os.environ.get("S3S_BENCH_TRAFFIC_SOURCE", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command")
+        else:
+            traffic_file = os.path.join(ROOT, "profiles", "traffic_latest.json")
+            if os.path.exists(traffic_file):
+                try:
+                    ref = json.load(open(traffic_file))
+                    key = f"{args.workload}:{args.direction}"
+                    if key in ref:
+                        out["roofline"]["traffic_reference"] = dict(ref[key], note="PMC pass of an earlier profiled run of this workload (tracked under profiles/); not measured by this run")
+                except Exception:
+                    pass
         print(json.dumps(out), flush=True)
     for c in codecs:
         c.close()

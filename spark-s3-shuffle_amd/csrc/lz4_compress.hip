@@ -381,6 +381,200 @@ __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t*
           {
             DBG_T(tl0);
             for (;;) {
+#ifndef S3S_NO_ASM_RUN_LOOP  // (-DS3S_NO_ASM_RUN_LOOP: the compiled loop alone, for A/B runs)
+              if ((ED & valid & (~0ull << rs)) == 0ull) { why = kNoEvent; break; }  // nothing to do: skip the block
+              // Hand-scheduled gfx950 code for the COMMON event (candidate matches, no earlier same-candidate lane,
+              // extension of at most one cooperative round, short-form sequence): the same arithmetic as the C++
+              // body below in ~95 (no extension) / ~130 (with it) instructions instead of the ~135 / ~190 hipcc emits
+              // (it turns the multi-exit loop into a state machine with exit codes and 64-bit boolean masks).  Any
+              // other event leaves the block untouched (code 2) and is handled by the C++ body, once.
+              {
+                int code;
+                const int anchor_in = anchor;
+                asm volatile(
+                    ".Lrl_top_%=:\n\t"
+                    "s_lshl_b64 s[80:81], -1, %[rs]\n\t"
+                    "s_and_b64 s[80:81], s[80:81], %[valid]\n\t"
+                    "s_and_b64 s[82:83], s[80:81], %[ED]\n\t"
+                    "s_cbranch_scc0 .Lrl_x0_%=\n\t"
+                    "s_ff1_i32_b64 s86, s[82:83]\n\t"
+                    "s_nop 0\n\t"
+                    "v_readlane_b32 s87, %[info], s86\n\t"
+                    "s_bitcmp0_b32 s87, 30\n\t"
+                    "s_cbranch_scc1 .Lrl_nomatch_%=\n\t"
+                    "s_and_b32 s88, s87, 0xffff\n\t"
+                    "v_cmp_eq_u32_e64 s[82:83], s88, %[cp]\n\t"
+                    "s_or_b64 s[84:85], s[80:81], %[K]\n\t"
+                    "s_and_b64 s[82:83], s[82:83], s[84:85]\n\t"
+                    "s_and_b64 s[82:83], s[82:83], %[Dp]\n\t"
+                    "s_lshl_b64 s[84:85], -1, s86\n\t"
+                    "s_andn2_b64 s[82:83], s[82:83], s[84:85]\n\t"
+                    "s_cbranch_scc1 .Lrl_x2_%=\n\t"
+                    "s_add_i32 s89, %[wbase], s86\n\t"
+                    "s_bfe_u32 s90, s87, 0x40010\n\t"
+                    "s_bfe_u32 s91, s87, 0x30014\n\t"
+                    "s_sub_i32 s92, s89, %[anchor]\n\t"
+                    "s_sub_i32 s97, 7, s90\n\t"
+                    "s_sub_i32 s98, 3, s91\n\t"
+                    "s_sub_i32 s99, 4, s92\n\t"
+                    "s_and_b32 s98, s98, s99\n\t"
+                    "s_or_b32 s97, s97, s98\n\t"
+                    "s_min_i32 s91, s91, s92\n\t"
+                    "s_cmp_lt_i32 s97, 0\n\t"
+                    "s_cbranch_scc0 .Lrl_len_%=\n\t"
+                    // ---- cooperative extension, one round: 256 B forward, 64 B backward
+                    "s_add_i32 s97, s89, 4\n\t"
+                    "v_lshl_add_u32 v125, %[lane], 2, s97\n\t"
+                    "v_min_i32_e32 v125, %[last4], v125\n\t"
+                    "s_sub_i32 s98, s89, s88\n\t"
+                    "v_subrev_u32_e32 v126, s98, v125\n\t"
+                    "global_load_dword v125, v125, %[inp]\n\t"
+                    "global_load_dword v126, v126, %[inp]\n\t"
+                    "s_min_i32 s99, s92, s88\n\t"
+                    "v_mov_b32_e32 v127, 0\n\t"
+                    "v_mov_b32_e32 v128, 1\n\t"
+                    "v_cmp_gt_i32_e64 s[82:83], s99, %[lane]\n\t"
+                    "s_add_i32 s97, s89, -1\n\t"
+                    "s_add_i32 s98, s88, -1\n\t"
+                    "s_and_saveexec_b64 s[84:85], s[82:83]\n\t"
+                    "v_sub_u32_e32 v123, s97, %[lane]\n\t"
+                    "v_sub_u32_e32 v124, s98, %[lane]\n\t"
+                    "global_load_ubyte v127, v123, %[inp]\n\t"
+                    "global_load_ubyte v128, v124, %[inp]\n\t"
+                    "s_mov_b64 exec, s[84:85]\n\t"
+                    "s_sub_i32 s99, %[mlimit], s89\n\t"
+                    "s_add_i32 s99, s99, -4\n\t"
+                    "s_waitcnt vmcnt(0)\n\t"
+                    "v_cmp_ne_u32_e64 s[82:83], v125, v126\n\t"
+                    "v_cmp_ne_u32_e64 s[84:85], v127, v128\n\t"
+                    "v_xor_b32_e32 v123, v125, v126\n\t"
+                    "s_ff1_i32_b64 s97, s[84:85]\n\t"
+                    "s_min_u32 s97, s97, 63\n\t"
+                    "s_cmp_eq_u32 s97, 63\n\t"
+                    "s_cbranch_scc1 .Lrl_x2_%=\n\t"
+                    "s_cmp_eq_u64 s[82:83], 0\n\t"
+                    "s_cbranch_scc1 .Lrl_full_%=\n\t"
+                    "s_ff1_i32_b64 s98, s[82:83]\n\t"
+                    "s_nop 0\n\t"
+                    "v_readlane_b32 s90, v123, s98\n\t"
+                    "s_lshl_b32 s98, s98, 2\n\t"
+                    "s_ff1_i32_b32 s90, s90\n\t"
+                    "s_lshr_b32 s90, s90, 3\n\t"
+                    "s_add_i32 s90, s90, s98\n\t"
+                    "s_branch .Lrl_got_%=\n\t"
+                    ".Lrl_full_%=:\n\t"
+                    "s_cmpk_gt_i32 s99, 0x100\n\t"
+                    "s_cbranch_scc1 .Lrl_x2_%=\n\t"
+                    "s_movk_i32 s90, 0x100\n\t"
+                    ".Lrl_got_%=:\n\t"
+                    "s_min_i32 s90, s90, s99\n\t"
+                    "s_mov_b32 s91, s97\n\t"
+                    // ---- lengths, short-form test
+                    ".Lrl_len_%=:\n\t"
+                    "s_sub_i32 s93, s92, s91\n\t"
+                    "s_add_i32 s94, s91, s90\n\t"
+                    "s_cmp_gt_i32 s94, 14\n\t"
+                    "s_cselect_b32 s95, 4, 3\n\t"
+                    "s_add_i32 s95, s95, s93\n\t"
+                    "s_add_i32 s96, s89, 4\n\t"
+                    "s_add_i32 s96, s96, s90\n\t"
+                    "s_sub_i32 s97, %[anchor], %[litfloor]\n\t"
+                    "s_sub_i32 s98, 14, s93\n\t"
+                    "s_or_b32 s97, s97, s98\n\t"
+                    "s_sub_i32 s98, 0x10d, s94\n\t"
+                    "s_or_b32 s97, s97, s98\n\t"
+                    "s_sub_i32 s98, %[len], %[op]\n\t"
+                    "s_sub_i32 s98, s98, s95\n\t"
+                    "s_or_b32 s97, s97, s98\n\t"
+                    "s_cmp_lt_i32 s97, 0\n\t"
+                    "s_cbranch_scc1 .Lrl_x2_%=\n\t"
+                    // ---- emit: token | literals (low bytes of v / vp) | offset | [match-length byte], one byte per lane
+                    "v_subrev_u32_e32 v120, %[anchor], %[lane]\n\t"
+                    "s_min_i32 s97, s94, 15\n\t"
+                    "s_lshl_b32 s98, s93, 4\n\t"
+                    "v_and_b32_e32 v120, 63, v120\n\t"
+                    "s_or_b32 s97, s97, s98\n\t"
+                    "s_sub_i32 s98, s89, s88\n\t"
+                    "v_subrev_u32_e32 v121, s93, v120\n\t"
+                    "s_lshl_b32 s98, s98, 8\n\t"
+                    "v_add_u32_e32 v123, %[anchor], v120\n\t"
+                    "s_or_b32 s97, s97, s98\n\t"
+                    "v_cmp_gt_i32_e32 vcc, %[wbase], v123\n\t"
+                    "s_add_i32 s98, s94, -15\n\t"
+                    "s_lshl_b32 s98, s98, 24\n\t"
+                    "v_cndmask_b32_e32 v122, %[v], %[vp], vcc\n\t"
+                    "s_or_b32 s99, s97, s98\n\t"
+                    "v_lshlrev_b32_e32 v123, 3, v121\n\t"
+                    "v_lshrrev_b32_e64 v123, v123, s99\n\t"
+                    "v_cmp_gt_u32_e32 vcc, 4, v121\n\t"
+                    "s_nop 1\n\t"
+                    "v_cndmask_b32_e32 v122, v122, v123, vcc\n\t"
+                    "v_cmp_gt_u32_e32 vcc, s93, v120\n\t"
+                    "s_nop 1\n\t"
+                    "v_addc_co_u32_e32 v124, vcc, 0, v120, vcc\n\t"
+                    "v_cmp_ne_u32_e32 vcc, s93, v120\n\t"
+                    "v_cmp_gt_u32_e64 s[82:83], s95, v120\n\t"
+                    "s_nop 0\n\t"
+                    "v_cndmask_b32_e32 v124, 0, v124, vcc\n\t"
+                    "v_add_u32_e32 v124, %[op], v124\n\t"
+                    "s_and_saveexec_b64 s[84:85], s[82:83]\n\t"
+                    "global_store_byte v124, v122, %[outp]\n\t"
+                    "s_mov_b64 exec, s[84:85]\n\t"
+                    "s_add_i32 %[op], %[op], s95\n\t"
+                    // ---- state update
+                    "s_lshl_b64 s[82:83], -2, s86\n\t"
+                    "s_andn2_b64 s[82:83], s[80:81], s[82:83]\n\t"
+                    "s_or_b64 %[K], %[K], s[82:83]\n\t"
+                    "s_mov_b32 %[anchor], s96\n\t"
+                    "s_sub_i32 s97, s96, %[wbase]\n\t"
+                    "s_add_i32 s98, s97, -2\n\t"
+                    "s_add_i32 s99, s96, -2\n\t"
+                    "s_lshl_b64 s[82:83], 1, s98\n\t"
+                    "s_cmp_lt_i32 s98, 64\n\t"
+                    "s_cselect_b64 s[82:83], s[82:83], 0\n\t"
+                    "s_cselect_b32 %[pendq], %[pendq], s99\n\t"
+                    "s_or_b64 %[K], %[K], s[82:83]\n\t"
+                    "s_mov_b32 %[rs], s97\n\t"
+                    "s_mov_b64 %[valid], -1\n\t"
+                    "s_cmp_lt_i32 s97, 64\n\t"
+                    "s_cbranch_scc1 .Lrl_top_%=\n\t"
+                    "s_mov_b32 %[code], 1\n\t"
+                    "s_branch .Lrl_end_%=\n\t"
+                    // ---- a duplicate-hash lane whose table candidate does not match: a plain no-match probe unless an
+                    //      earlier kept / in-run lane of the window shares its HASH (then the exact C++ path decides)
+                    ".Lrl_nomatch_%=:\n\t"
+                    "v_readlane_b32 s88, %[h], s86\n\t"
+                    "s_or_b64 s[84:85], s[80:81], %[K]\n\t"
+                    "v_cmp_eq_u32_e64 s[82:83], s88, %[h]\n\t"
+                    "s_and_b64 s[82:83], s[82:83], s[84:85]\n\t"
+                    "s_lshl_b64 s[84:85], -1, s86\n\t"
+                    "s_andn2_b64 s[82:83], s[82:83], s[84:85]\n\t"
+                    "s_cbranch_scc1 .Lrl_x2_%=\n\t"
+                    "s_lshl_b64 s[84:85], 1, s86\n\t"
+                    "s_andn2_b64 %[ED], %[ED], s[84:85]\n\t"
+                    "s_branch .Lrl_top_%=\n\t"
+                    ".Lrl_x0_%=:\n\t"
+                    "s_mov_b32 %[code], 0\n\t"
+                    "s_branch .Lrl_end_%=\n\t"
+                    ".Lrl_x2_%=:\n\t"
+                    "s_mov_b32 %[code], 2\n\t"
+                    ".Lrl_end_%=:\n\t"
+                    : [valid] "+s"(valid), [rs] "+s"(rs), [anchor] "+s"(anchor), [K] "+s"(K), [pendq] "+s"(pend_q),
+                      [op] "+s"(op), [ED] "+s"(ED), [code] "=&s"(code)
+                    : [Dp] "s"(Dp), [h] "v"(h), [wbase] "s"(wbase), [litfloor] "s"(lit_floor), [len] "s"(len),
+                      [mlimit] "s"(matchlimit), [last4] "s"(last4), [inp] "s"(in.base), [outp] "s"(out), [info] "v"(info),
+                      [cp] "v"(cp), [v] "v"(v), [vp] "v"(vp), [lane] "v"(lane)
+                    : "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93",
+                      "s94", "s95", "s96", "s97", "s98", "s99", "v120", "v121", "v122", "v123", "v124", "v125", "v126",
+                      "v127", "v128", "vcc", "scc", "memory");
+                if (anchor != anchor_in) {
+                  rt = 0;
+                  elim = kWave;
+                }
+                if (code == 0) { why = kNoEvent; break; }
+                if (code == 1) { why = kLeft; break; }
+              }
+#endif
               const uint64_t live_m = valid & (~0ull << rs);
               const uint64_t cm = ED & live_m;
               if (cm == 0ull) { why = kNoEvent; break; }
