@@ -85,6 +85,9 @@ void s3s_destroy(s3s_ctx* ctx) {
   if (ctx->ev_hash) hipEventDestroy(ctx->ev_hash);
   for (auto& ev : ctx->ev_auto)
     if (ev) hipEventDestroy(ev);
+  for (auto& ev : ctx->ev_up)
+    if (ev) hipEventDestroy(ev);
+  if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -271,7 +274,7 @@ static int compress_core(s3s_ctx* ctx, int codec, int checksum_algo, const uint8
   HIP_TRY(ctx, hipMemsetAsync(ctx->buf[B_STATUS].p, 0, 16, ctx->stream));
   record(ctx, 0);
   bool auto_timed = false;
-  int auto_which = 0;
+  int auto_which = 0, lz4_variant_run = 10;
   constexpr int64_t kAutoMinBytes = 4 << 20;
 
   if (codec == S3S_CODEC_NONE) {
@@ -315,13 +318,53 @@ static int compress_core(s3s_ctx* ctx, int codec, int checksum_algo, const uint8
         if (auto_timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_auto[0], ctx->stream));
       }
       ctx->lz4_variant_used = variant;
-      launch_lz4_compress(d_src, dev<Item>(ctx, B_ITEMS), n_items, dev<uint32_t>(ctx, B_ITEM_CHECK),
-                          dev<uint8_t>(ctx, B_SLOTS), dev<uint32_t>(ctx, B_ITEM_SIZE),
-                          variant, ctx->stream, ctx->profile ? ctx->ev_hash : nullptr);
-      if (auto_timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_auto[1], ctx->stream));
-    } else
-      launch_snappy_compress(d_src, dev<Item>(ctx, B_ITEMS), n_items, dev<uint8_t>(ctx, B_SLOTS),
-                             slot_stride, dev<uint32_t>(ctx, B_ITEM_SIZE), ctx->snappy_variant, ctx->stream);
+      lz4_variant_run = variant;
+    }
+    // One launch over all blocks — or, when the source is still on the host (up_host), one launch per uploaded
+    // chunk: the copy engine brings chunk g+1 while the blocks of chunk g are compressed.
+    auto launch_codec = [&](int32_t i0, int32_t i1) {
+      if (i1 <= i0) return;
+      if (codec == S3S_CODEC_LZ4)
+        launch_lz4_compress(d_src, dev<Item>(ctx, B_ITEMS) + i0, i1 - i0, dev<uint32_t>(ctx, B_ITEM_CHECK) + i0,
+                            dev<uint8_t>(ctx, B_SLOTS), dev<uint32_t>(ctx, B_ITEM_SIZE) + i0, lz4_variant_run, ctx->stream,
+                            ctx->profile && i1 == n_items ? ctx->ev_hash : nullptr);
+      else
+        launch_snappy_compress(d_src, dev<Item>(ctx, B_ITEMS) + i0, i1 - i0, dev<uint8_t>(ctx, B_SLOTS), slot_stride,
+                               dev<uint32_t>(ctx, B_ITEM_SIZE) + i0, ctx->snappy_variant, ctx->stream);
+    };
+    constexpr int64_t kUpChunk = 64ll << 20;  // one launch should fill the chip (2560 resident blocks = 80 MiB): 16 MiB chunks were slower than no overlap
+    if (ctx->up_host && total_u > kUpChunk + (kUpChunk >> 1)) {
+      const int64_t base0 = seg_offsets[0];
+      const int32_t n_up = (int32_t)((total_u + kUpChunk - 1) / kUpChunk);
+      if (!ctx->copy_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+      while ((int32_t)ctx->ev_up.size() < n_up + 1) {
+        hipEvent_t ev = nullptr;
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        ctx->ev_up.push_back(ev);
+      }
+      // the copy stream must not overtake work of this stream that still reads the buffer (previous call): order it
+      HIP_TRY(ctx, hipEventRecord(ctx->ev_up[(size_t)n_up], ctx->stream));
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_up[(size_t)n_up], 0));
+      int32_t i0 = 0;
+      for (int32_t g = 0; g < n_up; g++) {
+        const int64_t b0 = (int64_t)g * kUpChunk, b1 = b0 + kUpChunk < total_u ? b0 + kUpChunk : total_u;
+        HIP_TRY(ctx, hipMemcpyAsync(const_cast<uint8_t*>(d_src) + base0 + b0, ctx->up_host + b0, (size_t)(b1 - b0),
+                                    hipMemcpyHostToDevice, ctx->copy_stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_up[(size_t)g], ctx->copy_stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_up[(size_t)g], 0));
+        int32_t i1 = i0;  // items are in ascending source order: take those whose bytes have all arrived
+        while (i1 < n_items && (h_items[i1].len == 0 || h_items[i1].src_off + h_items[i1].len <= base0 + b1)) i1++;
+        if (g == n_up - 1) i1 = n_items;
+        launch_codec(i0, i1);
+        i0 = i1;
+      }
+    } else {
+      if (ctx->up_host && total_u > 0)
+        HIP_TRY(ctx, hipMemcpyAsync(const_cast<uint8_t*>(d_src) + seg_offsets[0], ctx->up_host, (size_t)total_u,
+                                    hipMemcpyHostToDevice, ctx->stream));
+      launch_codec(0, n_items);
+    }
+    if (codec == S3S_CODEC_LZ4 && auto_timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_auto[1], ctx->stream));
     HIP_TRY(ctx, hipGetLastError());
     record(ctx, 1);
     launch_scan_items(dev<Item>(ctx, B_ITEMS), dev<uint32_t>(ctx, B_ITEM_SIZE), n_items,
@@ -666,14 +709,17 @@ int s3s_compress_map_output(s3s_ctx* ctx, int codec, int checksum_algo, const ui
   int rc;
   if ((rc = ensure(ctx, B_SRC, (size_t)total_u + 64))) return rc;
   if ((rc = ensure(ctx, B_DST, (size_t)dcap + 64))) return rc;
-  if (total_u > 0)
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_SRC].p, src + first, (size_t)total_u, hipMemcpyHostToDevice, ctx->stream));
-  // rebase the offsets so partition 0 starts at device offset 0
+  // rebase the offsets so partition 0 starts at device offset 0; the upload itself happens inside the device path,
+  // in chunks that overlap with the codec kernels (ctx->up_host)
   std::vector<int64_t> rebased((size_t)n + 1);
   for (int32_t p = 0; p <= n; p++) rebased[(size_t)p] = src_offsets[p] - first;
   int64_t total = 0;
+  ctx->up_host = total_u > 0 ? src + first : nullptr;
+  if (codec == S3S_CODEC_NONE && total_u > 0)  // (no codec kernel to overlap with)
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_SRC].p, src + first, (size_t)total_u, hipMemcpyHostToDevice, ctx->stream));
   rc = s3s_compress_map_output_device(ctx, codec, checksum_algo, dev<uint8_t>(ctx, B_SRC), rebased.data(), n,
                                       dev<uint8_t>(ctx, B_DST), dcap, out_index, out_checksums, &total);
+  ctx->up_host = nullptr;
   if (out_total) *out_total = total;
   if (rc != S3S_OK) return rc;
   if (total > 0) HIP_TRY(ctx, hipMemcpy(dst, ctx->buf[B_DST].p, (size_t)total, hipMemcpyDeviceToHost));

@@ -305,14 +305,26 @@ int s3s_decompress_range(s3s_ctx* ctx, int codec, int checksum_algo, const uint8
     return fail(ctx, S3S_E_INVALID, "null/invalid host buffer");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   int rc;
+  // size the device destination from the DECODED size (a walk over the frame headers on the host), not from the
+  // caller's capacity: a large reusable output buffer must not turn into an equally large hipMalloc
+  int64_t need = dst_capacity;
+  {
+    int64_t decoded = 0;
+    if (codec != S3S_CODEC_NONE && s3s_decompressed_size(ctx, codec, comp, comp_len, &decoded) == S3S_OK && decoded < need)
+      need = decoded;
+    else if (codec == S3S_CODEC_NONE && comp_len < need)
+      need = comp_len;
+    ctx->err[0] = 0;  // (a corrupt chain is reported by the device path below, with its own message)
+  }
   if ((rc = ensure(ctx, B_SRC, (size_t)comp_len + 64))) return rc;
-  if ((rc = ensure(ctx, B_DST, (size_t)dst_capacity + 64))) return rc;
+  if ((rc = ensure(ctx, B_DST, (size_t)need + 64))) return rc;
   if (comp_len > 0)
     HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_SRC].p, comp, (size_t)comp_len, hipMemcpyHostToDevice, ctx->stream));
   int64_t total = 0;
   rc = s3s_decompress_range_device(ctx, codec, checksum_algo, dev<uint8_t>(ctx, B_SRC), comp_len, part_offsets,
-                                   ref_checksums, nparts, dev<uint8_t>(ctx, B_DST), dst_capacity, &total,
+                                   ref_checksums, nparts, dev<uint8_t>(ctx, B_DST), need, &total,
                                    out_bad_partition);
+  if (rc == S3S_E_CAPACITY && need < dst_capacity) rc = fail(ctx, S3S_E_BAD_FRAME, "Stream is corrupted (decoded size changed)");
   if (out_len) *out_len = total;
   if (rc != S3S_OK) return rc;
   if (total > 0) HIP_TRY(ctx, hipMemcpy(dst, ctx->buf[B_DST].p, (size_t)total, hipMemcpyDeviceToHost));

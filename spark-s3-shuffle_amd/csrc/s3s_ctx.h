@@ -51,6 +51,11 @@ struct s3s_ctx {
   size_t h_stage_cap = 0;
   hipEvent_t ev[S3S_STAGE_COUNT + 1] = {};
   hipEvent_t ev_hash = nullptr;  // between the xxHash32 pre-pass and the LZ4 compress kernel
+  // host-buffer map side: the upload of the source runs in chunks on its own stream, the codec kernels of a chunk's
+  // blocks start as soon as the chunk has landed (s3s_compress_map_output sets up_host for the duration of the call)
+  hipStream_t copy_stream = nullptr;
+  std::vector<hipEvent_t> ev_up;
+  const uint8_t* up_host = nullptr;  // host source of d_src[0, total_u), or nullptr (source already on the device)
   double stage_ms[S3S_STAGE_COUNT] = {};
 };
 

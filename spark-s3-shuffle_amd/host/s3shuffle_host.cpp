@@ -303,11 +303,15 @@ std::vector<int64_t> S3ShuffleMapOutputWriter::commitAllPartitions() {
   const auto t1 = now();
   std::vector<int64_t> partitionLengths((size_t)numPartitions_);
   for (int p = 0; p < numPartitions_; p++) partitionLengths[(size_t)p] = index[(size_t)p + 1] - index[(size_t)p];
-  // the .data object: one block per map task, partitions in ascending order (:43-49, :58)
-  if (total > 0 || d_.conf().alwaysCreateIndex) d_.createBlock(BlockId::ShuffleDataBlockId(shuffleId_, mapId_), data.p, (size_t)total);
+  // the .data object: one block per map task, partitions in ascending order (:58).  The reference opens it lazily
+  // on the first write (initStream, :43-49), so a map task that wrote nothing leaves no .data object — also with
+  // alwaysCreateIndex, which only adds the .index / .checksum pair
+  if (total > 0) d_.createBlock(BlockId::ShuffleDataBlockId(shuffleId_, mapId_), data.p, (size_t)total);
   // index and checksum (:111-116)
   if (total > 0 || d_.conf().alwaysCreateIndex) {
-    if (numPartitions_ > 0) S3ShuffleHelper::writePartitionLengths(d_, shuffleId_, mapId_, partitionLengths);
+    // (the reference's writePartitionLengths calls .head on the lengths, S3ShuffleHelper.scala:45: zero partitions throw)
+    if (numPartitions_ == 0) throw std::runtime_error("Precondition: writePartitionLengths needs at least one partition");
+    S3ShuffleHelper::writePartitionLengths(d_, shuffleId_, mapId_, partitionLengths);
     if (d_.conf().checksumEnabled) {
       sums.resize((size_t)numPartitions_);
       S3ShuffleHelper::writeChecksum(d_, shuffleId_, mapId_, sums);
