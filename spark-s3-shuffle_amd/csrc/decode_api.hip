@@ -289,7 +289,17 @@ int s3s_decompress_range_device(s3s_ctx* ctx, int codec, int checksum_algo, cons
   HIP_TRY(ctx, hipMemcpyAsync(&h_misc[1], ctx->buf[B_STATUS].p, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   finish_profile(3);
-  const int32_t st = *reinterpret_cast<int32_t*>(&h_misc[1]);
+  int32_t st = *reinterpret_cast<int32_t*>(&h_misc[1]);
+  if (st == S3S_E_UNSUPPORTED && ctx->lz4_decode_variant != 3) {
+    // a frame above 32 KiB (written with a larger spark.io.compression.lz4.blockSize): the ring decoder takes any size
+    HIP_TRY(ctx, hipMemsetAsync(ctx->buf[B_STATUS].p, 0, 16, ctx->stream));
+    launch_lz4_decompress(d_comp, dev<Frame>(ctx, B_FRAMES), (int32_t)n_frames, dev<int64_t>(ctx, B_FRAME_OUT), d_dst,
+                          dev<int32_t>(ctx, B_STATUS), 3, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(&h_misc[1], ctx->buf[B_STATUS].p, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    st = *reinterpret_cast<int32_t*>(&h_misc[1]);
+  }
   if (st == S3S_E_UNSUPPORTED) return fail(ctx, S3S_E_UNSUPPORTED, "LZ4Block frame larger than %d bytes", kMaxBlock);
   if (st != 0) return fail(ctx, S3S_E_BAD_FRAME, "Stream is corrupted");
   return S3S_OK;

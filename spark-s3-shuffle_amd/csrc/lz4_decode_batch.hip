@@ -76,7 +76,9 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
   const Frame fr = frames[f];
   const int olen = fr.orig_len, clen = fr.comp_len;
   const int lane = threadIdx.x;
-  if (kFmt == kFmtSnappy && olen > kMaxBlock) {
+  // blocks above 32 KiB (a writer configured with a larger codec block size): not for this kernel — its sequence
+  // records keep stream offsets in 16 bits.  The host retries LZ4 ranges with the ring decoder, which has no limit.
+  if (olen > kMaxBlock && (kFmt == kFmtSnappy || fr.method != 0x10)) {
     if (lane == 0) atomicExch(status, S3S_E_UNSUPPORTED);
     return;
   }

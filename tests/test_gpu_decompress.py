@@ -153,3 +153,14 @@ def test_codec_none_passthrough(gpu_codec, oracle):
     img, index, sums = _oracle_image(oracle, NONE, CRC, data, offsets)
     out = gpu_codec.decompress_range(NONE, CRC, img, index, sums)
     assert np.array_equal(out, data)
+
+
+def test_blocks_above_32k_from_a_foreign_writer(gpu_codec, oracle):
+    """A JVM writer configured with spark.io.compression.lz4.blockSize=64k produces 64 KiB LZ4Block frames.  The
+    batch decoder keeps stream offsets in 16 bits and reports such frames as unsupported; the library retries the
+    range with the ring decoder, so the caller gets the bytes either way (also through the batched entry point)."""
+    rng = np.random.default_rng(41)
+    data, offsets = corpus.ragged_map_output(rng, 6, 400_000)
+    img, index, sums = oracle.compress_map_output(LZ4, ADLER, data, offsets, 65536)
+    out = gpu_codec.decompress_range(LZ4, ADLER, img, index, sums)
+    assert np.array_equal(out, data)
