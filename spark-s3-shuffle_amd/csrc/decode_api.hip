@@ -417,9 +417,16 @@ extern "C" int s3s_decompress_ranges_batch_device(s3s_ctx* ctx, int codec, int c
   const size_t np1 = (size_t)n_parts + (size_t)n_ranges;  // sum of (n_r + 1)
   auto al = [](size_t x) { return (x + 15) & ~size_t(15); };
   // pinned staging: [offsets][seg_start][sums][n_frames per range][total per range][status: n_ranges + 1]
+  //                 [range descriptors][tile -> range map][results: 2 per range]      (LZ4: batched discovery)
+  int64_t total_tiles64 = 0;
+  if (codec == S3S_CODEC_LZ4)
+    for (int32_t r = 0; r < n_ranges; r++) total_tiles64 += lz4_tile_count(R[r].comp_len);
+  if (total_tiles64 > 0x7fffff00ll) return fail(ctx, S3S_E_UNSUPPORTED, "batch too large for one call");
+  const int32_t total_tiles = (int32_t)total_tiles64;
   const size_t o_off = 0, o_seg = al(o_off + 8 * np1), o_sums = al(o_seg + 4 * np1), o_nf = al(o_sums + 8 * ((size_t)n_parts + 1)),
                o_tot = al(o_nf + 8 * (size_t)n_ranges), o_st = al(o_tot + 8 * (size_t)n_ranges),
-               stage_total = o_st + 4 * ((size_t)n_ranges + 1) + 16;
+               o_desc = al(o_st + 4 * ((size_t)n_ranges + 1)), o_map = al(o_desc + sizeof(LzRange) * (size_t)n_ranges),
+               o_res = al(o_map + 4 * ((size_t)total_tiles + 1)), stage_total = o_res + 16 * (size_t)n_ranges + 16;
   int rc;
   if ((rc = ensure_stage(ctx, stage_total))) return rc;
   uint8_t* hs = static_cast<uint8_t*>(ctx->h_stage);
@@ -429,6 +436,9 @@ extern "C" int s3s_decompress_ranges_batch_device(s3s_ctx* ctx, int codec, int c
   int64_t* h_nf = reinterpret_cast<int64_t*>(hs + o_nf);
   int64_t* h_tot = reinterpret_cast<int64_t*>(hs + o_tot);
   int32_t* h_st = reinterpret_cast<int32_t*>(hs + o_st);
+  LzRange* h_desc = reinterpret_cast<LzRange*>(hs + o_desc);
+  int32_t* h_map = reinterpret_cast<int32_t*>(hs + o_map);
+  int64_t* h_res = reinterpret_cast<int64_t*>(hs + o_res);
   // device workspaces, all sized up front (no reallocation between the queued kernels)
   // discovery workspace per range: LZ4 4 x (tiles + 1) int64 + (tiles + 1) int32; Snappy (n + 1) u32 + (n + 2) int64
   std::vector<size_t> ws_off((size_t)n_ranges + 1), first_part((size_t)n_ranges + 1), first_seg((size_t)n_ranges + 1);
@@ -466,6 +476,9 @@ extern "C" int s3s_decompress_ranges_batch_device(s3s_ctx* ctx, int codec, int c
   if ((rc = ensure(ctx, B_PARTIAL, 16 * (first_seg[(size_t)n_ranges] > 0 ? first_seg[(size_t)n_ranges] : 1)))) return rc;
   if ((rc = ensure(ctx, B_PART_NFRAMES, ws_off[(size_t)n_ranges] + 16))) return rc;
   if ((rc = ensure(ctx, B_STATUS, 4 * ((size_t)n_ranges + 1) + 16))) return rc;
+  if ((rc = ensure(ctx, B_RANGES, sizeof(LzRange) * (size_t)n_ranges + 16))) return rc;
+  if ((rc = ensure(ctx, B_TILE_RANGE, 4 * ((size_t)total_tiles + 1) + 16))) return rc;
+  if ((rc = ensure(ctx, B_REF_SUMS, 16 * (size_t)n_ranges + 16))) return rc;
   HIP_TRY(ctx, hipMemsetAsync(ctx->buf[B_STATUS].p, 0, 4 * ((size_t)n_ranges + 1) + 16, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_OFFSETS].p, h_off, 8 * np1, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_SEG_START].p, h_seg, 4 * np1, hipMemcpyHostToDevice, ctx->stream));
@@ -482,22 +495,45 @@ extern "C" int s3s_decompress_ranges_batch_device(s3s_ctx* ctx, int codec, int c
                                   dev<int64_t>(ctx, B_SUMS) + first_part[(size_t)r], k.comp_len, ctx->stream);
   }
   record(ctx, 1);
-  for (int32_t r = 0; r < n_ranges; r++) {
-    const s3s_fetch_range& k = R[r];
-    h_nf[r] = 0;
-    if (k.comp_len == 0 || k.num_partitions == 0) continue;
-    uint8_t* ws = dev<uint8_t>(ctx, B_PART_NFRAMES) + ws_off[(size_t)r];
-    if (codec == S3S_CODEC_LZ4) {
-      const int32_t nt = lz4_tile_count(k.comp_len);
-      int64_t* d_spec_entry = reinterpret_cast<int64_t*>(ws);
-      int64_t* d_spec_exit = d_spec_entry + (nt + 1);
-      int64_t* d_true_entry = d_spec_exit + (nt + 1);
-      int64_t* d_frame_base = d_true_entry + (nt + 1);
-      int32_t* d_spec_count = reinterpret_cast<int32_t*>(d_frame_base + (nt + 1));
-      launch_lz4_discover(k.d_comp, k.comp_len, nt, d_spec_entry, d_spec_exit, d_spec_count, d_true_entry, d_frame_base,
-                          d_status + r, ctx->stream);
-      HIP_TRY(ctx, hipMemcpyAsync(&h_nf[r], d_frame_base + nt, 8, hipMemcpyDeviceToHost, ctx->stream));
-    } else {
+  if (codec == S3S_CODEC_LZ4) {
+    // one speculate launch over the tiles of every range, one resolve + count launch with a wavefront per range
+    int32_t t0 = 0;
+    for (int32_t r = 0; r < n_ranges; r++) {
+      const s3s_fetch_range& k = R[r];
+      const int32_t nt = (k.comp_len > 0 && k.num_partitions > 0) ? lz4_tile_count(k.comp_len) : 0;
+      uint8_t* ws = dev<uint8_t>(ctx, B_PART_NFRAMES) + ws_off[(size_t)r];
+      LzRange& d = h_desc[r];
+      memset(&d, 0, sizeof(d));
+      d.comp = k.d_comp;
+      d.comp_len = k.comp_len;
+      d.n_tiles = nt;
+      d.tile0 = t0;
+      const int32_t cap_t = lz4_tile_count(k.comp_len) + 1;
+      d.spec_entry = reinterpret_cast<int64_t*>(ws);
+      d.spec_exit = d.spec_entry + cap_t;
+      d.true_entry = d.spec_exit + cap_t;
+      d.frame_base = d.true_entry + cap_t;
+      d.spec_count = reinterpret_cast<int32_t*>(d.frame_base + cap_t);
+      d.status = d_status + r;
+      d.result = dev<int64_t>(ctx, B_REF_SUMS) + 2 * (size_t)r;
+      d.dst_base = (int64_t)reinterpret_cast<uintptr_t>(k.d_dst);
+      d.dst_capacity = k.dst_capacity;
+      for (int32_t t = 0; t < nt; t++) h_map[t0 + t] = r;
+      t0 += nt;
+    }
+    const int32_t used_tiles = t0;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_RANGES].p, h_desc, sizeof(LzRange) * (size_t)n_ranges, hipMemcpyHostToDevice, ctx->stream));
+    if (used_tiles > 0)
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_TILE_RANGE].p, h_map, 4 * (size_t)used_tiles, hipMemcpyHostToDevice, ctx->stream));
+    launch_lz4_discover_batch(dev<LzRange>(ctx, B_RANGES), n_ranges, dev<int32_t>(ctx, B_TILE_RANGE), used_tiles, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(h_res, ctx->buf[B_REF_SUMS].p, 16 * (size_t)n_ranges, hipMemcpyDeviceToHost, ctx->stream));
+  } else {
+    for (int32_t r = 0; r < n_ranges; r++) {
+      const s3s_fetch_range& k = R[r];
+      h_nf[r] = 0;
+      if (k.comp_len == 0 || k.num_partitions == 0) continue;
+      uint8_t* ws = dev<uint8_t>(ctx, B_PART_NFRAMES) + ws_off[(size_t)r];
       const size_t pp = first_part[(size_t)r] + (size_t)r;
       uint32_t* d_cnt = reinterpret_cast<uint32_t*>(ws);
       int64_t* d_base = reinterpret_cast<int64_t*>(ws + al(4 * ((size_t)k.num_partitions + 1)));
@@ -516,6 +552,7 @@ extern "C" int s3s_decompress_ranges_batch_device(s3s_ctx* ctx, int codec, int c
   for (int32_t r = 0; r < n_ranges; r++) {
     s3s_fetch_range& k = R[r];
     first_frame[(size_t)r] = total_frames;
+    if (codec == S3S_CODEC_LZ4) h_nf[r] = h_res[2 * r];
     if (do_sum)
       for (int32_t p = 0; p < k.num_partitions; p++)
         if (h_sums[first_part[(size_t)r] + (size_t)p] != k.ref_checksums[p]) {
@@ -529,66 +566,87 @@ extern "C" int s3s_decompress_ranges_batch_device(s3s_ctx* ctx, int codec, int c
   }
   first_frame[(size_t)n_ranges] = total_frames;
   if (total_frames > 0x7fffff00ll) return fail(ctx, S3S_E_UNSUPPORTED, "too many frames in one call");
-  // ---- phase 2: frame records + output offsets of every range, one wait ----------------------------------------------
+  // ---- phase 2: frame records + output offsets of every range, then ONE decode launch ----------------------------------
   const size_t nf1 = (size_t)total_frames + (size_t)n_ranges + 1;
   if ((rc = ensure(ctx, B_FRAMES, sizeof(Frame) * nf1))) return rc;
   if ((rc = ensure(ctx, B_ITEM_SIZE, 4 * nf1))) return rc;
   if ((rc = ensure(ctx, B_FRAME_OUT, 8 * nf1))) return rc;
   if ((rc = ensure(ctx, B_ITEM_OFF, 8 * nf1))) return rc;
-  for (int32_t r = 0; r < n_ranges; r++) {
-    const s3s_fetch_range& k = R[r];
-    h_tot[r] = 0;
-    const int64_t nf = h_nf[r], f0 = first_frame[(size_t)r];
-    if (nf == 0) continue;
-    uint8_t* ws = dev<uint8_t>(ctx, B_PART_NFRAMES) + ws_off[(size_t)r];
-    Frame* d_fr = dev<Frame>(ctx, B_FRAMES) + f0;
-    uint32_t* d_orig = dev<uint32_t>(ctx, B_ITEM_SIZE) + f0 + r;
-    int64_t* d_out_rel = dev<int64_t>(ctx, B_FRAME_OUT) + f0 + r;
-    if (codec == S3S_CODEC_LZ4) {
-      const int32_t nt = lz4_tile_count(k.comp_len);
-      int64_t* d_true_entry = reinterpret_cast<int64_t*>(ws) + 2 * (nt + 1);
-      int64_t* d_frame_base = d_true_entry + (nt + 1);
-      launch_lz4_emit_frames(k.d_comp, k.comp_len, nt, d_true_entry, d_frame_base, d_fr, d_orig, nf, d_out_rel, d_status + r, ctx->stream);
-    } else {
+  int32_t* d_dec_status = d_status + n_ranges;
+  if (codec == S3S_CODEC_LZ4) {
+    int32_t used_tiles = 0;
+    for (int32_t r = 0; r < n_ranges; r++) {
+      LzRange& d = h_desc[r];
+      const int64_t f0 = first_frame[(size_t)r];
+      d.n_frames = h_nf[r];
+      d.skip = R[r].status != S3S_OK ? 1 : 0;
+      d.frames = dev<Frame>(ctx, B_FRAMES) + f0;
+      d.frame_orig = dev<uint32_t>(ctx, B_ITEM_SIZE) + f0 + r;
+      d.frame_out = dev<int64_t>(ctx, B_FRAME_OUT) + f0 + r;
+      d.out_abs = dev<int64_t>(ctx, B_ITEM_OFF) + f0;
+      used_tiles += d.n_tiles;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_RANGES].p, h_desc, sizeof(LzRange) * (size_t)n_ranges, hipMemcpyHostToDevice, ctx->stream));
+    launch_lz4_frames_batch(dev<LzRange>(ctx, B_RANGES), n_ranges, dev<int32_t>(ctx, B_TILE_RANGE), used_tiles, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    record(ctx, 2);
+    if (total_frames > 0)
+      launch_lz4_decompress(nullptr, dev<Frame>(ctx, B_FRAMES), (int32_t)total_frames, dev<int64_t>(ctx, B_ITEM_OFF), nullptr,
+                            d_dec_status, ctx->lz4_decode_variant, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    record(ctx, 3);
+    HIP_TRY(ctx, hipMemcpyAsync(h_res, ctx->buf[B_REF_SUMS].p, 16 * (size_t)n_ranges, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(h_st, d_status, 4 * ((size_t)n_ranges + 1), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int32_t r = 0; r < n_ranges; r++) {
+      s3s_fetch_range& k = R[r];
+      if (k.status != S3S_OK) continue;
+      if (h_st[r] != 0) { k.status = S3S_E_BAD_FRAME; continue; }
+      k.out_len = h_res[2 * r + 1];
+      if (k.out_len > k.dst_capacity) k.status = S3S_E_CAPACITY;
+    }
+  } else {
+    for (int32_t r = 0; r < n_ranges; r++) {
+      const s3s_fetch_range& k = R[r];
+      h_tot[r] = 0;
+      const int64_t nf = h_nf[r], f0 = first_frame[(size_t)r];
+      if (nf == 0) continue;
+      uint8_t* ws = dev<uint8_t>(ctx, B_PART_NFRAMES) + ws_off[(size_t)r];
+      Frame* d_fr = dev<Frame>(ctx, B_FRAMES) + f0;
+      uint32_t* d_orig = dev<uint32_t>(ctx, B_ITEM_SIZE) + f0 + r;
+      int64_t* d_out_rel = dev<int64_t>(ctx, B_FRAME_OUT) + f0 + r;
       const size_t pp = first_part[(size_t)r] + (size_t)r;
       int64_t* d_base = reinterpret_cast<int64_t*>(ws + al(4 * ((size_t)k.num_partitions + 1)));
       launch_snappy_emit_frames(k.d_comp, dev<int64_t>(ctx, B_OFFSETS) + pp, k.num_partitions, d_base, d_fr, d_orig, d_status + r, ctx->stream);
       launch_scan_u32(d_orig, nf, d_out_rel, ctx->stream);
+      HIP_TRY(ctx, hipMemcpyAsync(&h_tot[r], d_out_rel + nf, 8, hipMemcpyDeviceToHost, ctx->stream));
     }
-    HIP_TRY(ctx, hipMemcpyAsync(&h_tot[r], d_out_rel + nf, 8, hipMemcpyDeviceToHost, ctx->stream));
-  }
-  HIP_TRY(ctx, hipGetLastError());
-  HIP_TRY(ctx, hipMemcpyAsync(h_st, d_status, 4 * (size_t)n_ranges, hipMemcpyDeviceToHost, ctx->stream));
-  record(ctx, 2);
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  // ---- phase 3: ONE decode launch over the frames of every range ------------------------------------------------------
-  for (int32_t r = 0; r < n_ranges; r++) {
-    s3s_fetch_range& k = R[r];
-    const int64_t nf = h_nf[r], f0 = first_frame[(size_t)r];
-    if (k.status == S3S_OK && h_st[r] != 0) k.status = S3S_E_BAD_FRAME;
-    if (k.status == S3S_OK) {
-      k.out_len = h_tot[r];
-      if (h_tot[r] > k.dst_capacity) k.status = S3S_E_CAPACITY;
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(h_st, d_status, 4 * (size_t)n_ranges, hipMemcpyDeviceToHost, ctx->stream));
+    record(ctx, 2);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int32_t r = 0; r < n_ranges; r++) {
+      s3s_fetch_range& k = R[r];
+      const int64_t nf = h_nf[r], f0 = first_frame[(size_t)r];
+      if (k.status == S3S_OK && h_st[r] != 0) k.status = S3S_E_BAD_FRAME;
+      if (k.status == S3S_OK) {
+        k.out_len = h_tot[r];
+        if (h_tot[r] > k.dst_capacity) k.status = S3S_E_CAPACITY;
+      }
+      if (nf == 0) continue;
+      hipLaunchKernelGGL(rebase_frames_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, ctx->stream,
+                         dev<Frame>(ctx, B_FRAMES) + f0, dev<int64_t>(ctx, B_FRAME_OUT) + f0 + r, dev<int64_t>(ctx, B_ITEM_OFF) + f0,
+                         (int32_t)nf, (int64_t)reinterpret_cast<uintptr_t>(k.d_comp), (int64_t)reinterpret_cast<uintptr_t>(k.d_dst),
+                         k.status != S3S_OK ? 1 : 0);
     }
-    if (nf == 0) continue;
-    hipLaunchKernelGGL(rebase_frames_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, ctx->stream,
-                       dev<Frame>(ctx, B_FRAMES) + f0, dev<int64_t>(ctx, B_FRAME_OUT) + f0 + r, dev<int64_t>(ctx, B_ITEM_OFF) + f0,
-                       (int32_t)nf, (int64_t)reinterpret_cast<uintptr_t>(k.d_comp), (int64_t)reinterpret_cast<uintptr_t>(k.d_dst),
-                       k.status != S3S_OK ? 1 : 0);
-  }
-  int32_t* d_dec_status = d_status + n_ranges;
-  if (total_frames > 0) {
-    if (codec == S3S_CODEC_LZ4)
-      launch_lz4_decompress(nullptr, dev<Frame>(ctx, B_FRAMES), (int32_t)total_frames, dev<int64_t>(ctx, B_ITEM_OFF), nullptr,
-                            d_dec_status, ctx->lz4_decode_variant, ctx->stream);
-    else
+    if (total_frames > 0)
       launch_snappy_decompress(nullptr, dev<Frame>(ctx, B_FRAMES), (int32_t)total_frames, dev<int64_t>(ctx, B_ITEM_OFF), nullptr,
                                d_dec_status, ctx->lz4_decode_variant, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    record(ctx, 3);
+    HIP_TRY(ctx, hipMemcpyAsync(&h_st[n_ranges], d_dec_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   }
-  HIP_TRY(ctx, hipGetLastError());
-  record(ctx, 3);
-  HIP_TRY(ctx, hipMemcpyAsync(&h_st[n_ranges], d_dec_status, 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->profile) {
     float ms = 0;
     hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]); ctx->stage_ms[S3S_STAGE_TOTAL] = ms;

@@ -95,13 +95,9 @@ __device__ int64_t walk_tile(const uint8_t* comp, int64_t comp_len, int64_t pos,
 }
 
 // per tile: spec[k] = {entry, exit, count}
-__global__ __launch_bounds__(kWave) void tile_speculate_kernel(const uint8_t* __restrict__ comp,
-                                                              int64_t comp_len, int32_t n_tiles,
-                                                              int64_t* __restrict__ spec_entry,
-                                                              int64_t* __restrict__ spec_exit,
-                                                              int32_t* __restrict__ spec_count) {
-  const int k = blockIdx.x, lane = threadIdx.x;
-  if (k >= n_tiles) return;
+__device__ __forceinline__ void speculate_tile(const uint8_t* __restrict__ comp, int64_t comp_len, int k, int lane,
+                                               int64_t* __restrict__ spec_entry, int64_t* __restrict__ spec_exit,
+                                               int32_t* __restrict__ spec_count) {
   const int64_t t0 = (int64_t)k * kTileBytes;
   const int64_t t1 = (t0 + kTileBytes) < comp_len ? (t0 + kTileBytes) : comp_len;
   int64_t entry = -1;
@@ -130,13 +126,31 @@ __global__ __launch_bounds__(kWave) void tile_speculate_kernel(const uint8_t* __
   }
 }
 
+__global__ __launch_bounds__(kWave) void tile_speculate_kernel(const uint8_t* __restrict__ comp,
+                                                              int64_t comp_len, int32_t n_tiles,
+                                                              int64_t* __restrict__ spec_entry,
+                                                              int64_t* __restrict__ spec_exit,
+                                                              int32_t* __restrict__ spec_count) {
+  const int k = blockIdx.x;
+  if (k >= n_tiles) return;
+  speculate_tile(comp, comp_len, k, threadIdx.x, spec_entry, spec_exit, spec_count);
+}
+
+__global__ __launch_bounds__(kWave) void tile_speculate_batch_kernel(const LzRange* __restrict__ ranges,
+                                                                    const int32_t* __restrict__ tile_range,
+                                                                    int32_t total_tiles) {
+  const int b = blockIdx.x;
+  if (b >= total_tiles) return;
+  const LzRange r = ranges[tile_range[b]];
+  speculate_tile(r.comp, r.comp_len, b - r.tile0, threadIdx.x, r.spec_entry, r.spec_exit, r.spec_count);
+}
+
 // one wavefront: turn speculation into the true chain.  true_entry[k] = position where the
 // chain enters tile k (-1: no frame starts in tile k), count[k] = frames starting in tile k.
-__global__ __launch_bounds__(kWave) void tile_resolve_kernel(
+__device__ __forceinline__ void resolve_chain(
     const uint8_t* __restrict__ comp, int64_t comp_len, int32_t n_tiles,
     const int64_t* __restrict__ spec_entry, int64_t* __restrict__ spec_exit,
-    int32_t* __restrict__ spec_count, int64_t* __restrict__ true_entry, int32_t* __restrict__ status) {
-  const int lane = threadIdx.x;
+    int32_t* __restrict__ spec_count, int64_t* __restrict__ true_entry, int32_t* __restrict__ status, int lane) {
   int64_t e = 0;  // chain position entering the next unresolved tile
   int k = 0;
   while (k < n_tiles) {
@@ -184,12 +198,17 @@ __global__ __launch_bounds__(kWave) void tile_resolve_kernel(
   if (e != comp_len && lane == 0) atomicExch(status, S3S_E_BAD_FRAME);
 }
 
-__global__ __launch_bounds__(kWave) void tile_emit_kernel(
+__global__ __launch_bounds__(kWave) void tile_resolve_kernel(
     const uint8_t* __restrict__ comp, int64_t comp_len, int32_t n_tiles,
-    const int64_t* __restrict__ true_entry, const int64_t* __restrict__ frame_base,
-    Frame* __restrict__ frames, uint32_t* __restrict__ frame_orig, int32_t* __restrict__ status) {
-  const int k = blockIdx.x * kWave + threadIdx.x;
-  if (k >= n_tiles) return;
+    const int64_t* __restrict__ spec_entry, int64_t* __restrict__ spec_exit,
+    int32_t* __restrict__ spec_count, int64_t* __restrict__ true_entry, int32_t* __restrict__ status) {
+  resolve_chain(comp, comp_len, n_tiles, spec_entry, spec_exit, spec_count, true_entry, status, threadIdx.x);
+}
+
+__device__ __forceinline__ void emit_tile(const uint8_t* __restrict__ comp, int64_t comp_len, int k,
+                                          const int64_t* __restrict__ true_entry, const int64_t* __restrict__ frame_base,
+                                          Frame* __restrict__ frames, uint32_t* __restrict__ frame_orig,
+                                          int32_t* __restrict__ status) {
   const int64_t entry = true_entry[k];
   if (entry < 0) return;
   const int64_t t0 = (int64_t)k * kTileBytes;
@@ -200,12 +219,30 @@ __global__ __launch_bounds__(kWave) void tile_emit_kernel(
     atomicExch(status, S3S_E_BAD_FRAME);
 }
 
+__global__ __launch_bounds__(kWave) void tile_emit_kernel(
+    const uint8_t* __restrict__ comp, int64_t comp_len, int32_t n_tiles,
+    const int64_t* __restrict__ true_entry, const int64_t* __restrict__ frame_base,
+    Frame* __restrict__ frames, uint32_t* __restrict__ frame_orig, int32_t* __restrict__ status) {
+  const int k = blockIdx.x * kWave + threadIdx.x;
+  if (k >= n_tiles) return;
+  emit_tile(comp, comp_len, k, true_entry, frame_base, frames, frame_orig, status);
+}
+
+__global__ __launch_bounds__(kWave) void tile_emit_batch_kernel(const LzRange* __restrict__ ranges,
+                                                               const int32_t* __restrict__ tile_range,
+                                                               int32_t total_tiles) {
+  const int b = blockIdx.x * kWave + threadIdx.x;
+  if (b >= total_tiles) return;
+  const LzRange r = ranges[tile_range[b]];
+  if (r.skip || r.n_frames == 0) return;
+  emit_tile(r.comp, r.comp_len, b - r.tile0, r.true_entry, r.frame_base, r.frames, r.frame_orig, r.status);
+}
+
 // generic exclusive scan of uint32 -> int64 (n+1 outputs): ONE wavefront, NO LDS — the decode kernels of
 // the other task threads book the whole LDS of every CU (20 x 8 KiB rings), and a workgroup that needs
 // any of it waits for one of their frames to finish (see scan_items_kernel in assemble.hip)
-__global__ __launch_bounds__(kWave) void scan_u32_kernel(const uint32_t* __restrict__ in, int64_t n,
-                                                         int64_t* __restrict__ out) {
-  const int lane = threadIdx.x;
+__device__ __forceinline__ void scan_u32_wave(const uint32_t* __restrict__ in, int64_t n, int64_t* __restrict__ out,
+                                              int lane) {
   int64_t carry = 0;
   for (int64_t tile = 0; tile < n; tile += 4 * kWave) {
     const int64_t i0 = tile + 4 * lane;
@@ -228,6 +265,60 @@ __global__ __launch_bounds__(kWave) void scan_u32_kernel(const uint32_t* __restr
     carry += __shfl(inc, kWave - 1);
   }
   if (lane == 0) out[n] = carry;
+}
+
+__global__ __launch_bounds__(kWave) void scan_u32_kernel(const uint32_t* __restrict__ in, int64_t n,
+                                                         int64_t* __restrict__ out) {
+  scan_u32_wave(in, n, out, threadIdx.x);
+}
+
+// batched call, phase 1 (one wavefront per range): speculation -> true chain -> frames per tile -> frame count
+__global__ __launch_bounds__(kWave) void tile_resolve_batch_kernel(const LzRange* __restrict__ ranges, int32_t n_ranges) {
+  const int ri = blockIdx.x;
+  if (ri >= n_ranges) return;
+  const LzRange r = ranges[ri];
+  const int lane = threadIdx.x;
+  if (r.n_tiles <= 0) {
+    if (lane == 0) r.result[0] = 0;
+    return;
+  }
+  resolve_chain(r.comp, r.comp_len, r.n_tiles, r.spec_entry, r.spec_exit, r.spec_count, r.true_entry, r.status, lane);
+  __threadfence();
+  scan_u32_wave(reinterpret_cast<const uint32_t*>(r.spec_count), (int64_t)r.n_tiles, r.frame_base, lane);
+  __threadfence();
+  if (lane == 0) r.result[0] = __builtin_nontemporal_load(&r.frame_base[r.n_tiles]);
+}
+
+// batched call, phase 2 (one wavefront per range): output offsets of the range's frames, its decoded size, the
+// capacity check, and the rebase of its frame records to absolute addresses (empty frames for a range that failed)
+__global__ __launch_bounds__(kWave) void frames_finish_batch_kernel(LzRange* __restrict__ ranges, int32_t n_ranges) {
+  const int ri = blockIdx.x;
+  if (ri >= n_ranges) return;
+  const LzRange r = ranges[ri];
+  const int lane = threadIdx.x;
+  if (r.n_frames <= 0) {
+    if (lane == 0) r.result[1] = 0;
+    return;
+  }
+  int64_t total = 0;
+  bool skip = r.skip != 0;
+  if (!skip) {
+    scan_u32_wave(r.frame_orig, r.n_frames, r.frame_out, lane);
+    __threadfence();
+    total = __builtin_nontemporal_load(&r.frame_out[r.n_frames]);
+    skip = total > r.dst_capacity || __builtin_nontemporal_load(r.status) != 0;
+  }
+  if (lane == 0) r.result[1] = total;
+  const int64_t comp_base = (int64_t)reinterpret_cast<uintptr_t>(r.comp);
+  for (int64_t i = lane; i < r.n_frames; i += kWave) {
+    if (skip) {
+      r.frames[i] = Frame{0, 0, 0, 0u, 0x10};
+      r.out_abs[i] = r.dst_base;
+    } else {
+      r.frames[i].comp_off += comp_base;
+      r.out_abs[i] = __builtin_nontemporal_load(&r.frame_out[i]) + r.dst_base;
+    }
+  }
 }
 
 // ---- frame decode: ring decoder written for the VALU (decode variant 3; the batch decoder, variant 4 and
@@ -538,6 +629,24 @@ void launch_lz4_emit_frames(const uint8_t* d_comp, int64_t comp_len, int32_t n_t
                      d_frame_orig, d_status);
   hipLaunchKernelGGL(scan_u32_kernel, dim3(1), dim3(kWave), 0, st, d_frame_orig, n_frames,
                      d_frame_out);
+}
+
+void launch_lz4_discover_batch(const LzRange* d_ranges, int32_t n_ranges, const int32_t* d_tile_range,
+                               int32_t total_tiles, hipStream_t st) {
+  if (total_tiles > 0)
+    hipLaunchKernelGGL(tile_speculate_batch_kernel, dim3((unsigned)total_tiles), dim3(kWave), 0, st, d_ranges,
+                       d_tile_range, total_tiles);
+  if (n_ranges > 0)
+    hipLaunchKernelGGL(tile_resolve_batch_kernel, dim3((unsigned)n_ranges), dim3(kWave), 0, st, d_ranges, n_ranges);
+}
+
+void launch_lz4_frames_batch(LzRange* d_ranges, int32_t n_ranges, const int32_t* d_tile_range, int32_t total_tiles,
+                             hipStream_t st) {
+  if (total_tiles > 0)
+    hipLaunchKernelGGL(tile_emit_batch_kernel, dim3((unsigned)((total_tiles + kWave - 1) / kWave)), dim3(kWave), 0, st,
+                       d_ranges, d_tile_range, total_tiles);
+  if (n_ranges > 0)
+    hipLaunchKernelGGL(frames_finish_batch_kernel, dim3((unsigned)n_ranges), dim3(kWave), 0, st, d_ranges, n_ranges);
 }
 
 void launch_scan_u32(const uint32_t* d_in, int64_t n, int64_t* d_out, hipStream_t st) {

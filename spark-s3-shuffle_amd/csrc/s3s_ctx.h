@@ -22,7 +22,7 @@ struct DevBuf {
 enum BufId {
   B_ITEMS, B_PART_FIRST, B_SLOTS, B_ITEM_SIZE, B_ITEM_OFF, B_INDEX, B_SUMS, B_SEG_START,
   B_PARTIAL, B_STATUS, B_TABLES, B_SRC, B_DST, B_OFFSETS, B_FRAMES, B_PART_NFRAMES,
-  B_FRAME_OUT, B_REF_SUMS, B_ITEM_CHECK, B_COUNT
+  B_FRAME_OUT, B_REF_SUMS, B_ITEM_CHECK, B_RANGES, B_TILE_RANGE, B_COUNT
 };
 
 }  // namespace s3s

@@ -89,6 +89,29 @@ struct Frame {        // one discovered codec frame
 // walked speculatively, resolved into the true chain, then emitted in stream order.
 //   d_spec_count[n_tiles] (as uint32) -> d_frame_base[n_tiles+1] (exclusive scan; last = n_frames)
 int32_t lz4_tile_count(int64_t comp_len);
+// one fetched range of a batched reduce-side call (s3s_decompress_ranges_batch_device): the discovery kernels of ALL
+// ranges run as one launch each (block -> range through a host-built tile map)
+struct LzRange {
+  const uint8_t* comp;
+  int64_t comp_len;
+  int32_t n_tiles, tile0;  // tiles of this range, index of its first tile in the batch-wide tile list
+  int64_t *spec_entry, *spec_exit, *true_entry, *frame_base;
+  int32_t* spec_count;
+  int32_t* status;         // per-range status word
+  int64_t* result;         // [0] = frames of the range (phase 1), [1] = decoded bytes (phase 2)
+  // phase 2, filled by the host once the frame counts are known
+  Frame* frames;
+  uint32_t* frame_orig;
+  int64_t* frame_out;      // n_frames + 1 offsets relative to the range's destination
+  int64_t* out_abs;        // absolute output address per frame (the one decode launch runs with dst = nullptr)
+  int64_t n_frames;
+  int64_t dst_base, dst_capacity;
+  int32_t skip, pad;       // the range failed an earlier check: its frames become empty
+};
+void launch_lz4_discover_batch(const LzRange* d_ranges, int32_t n_ranges, const int32_t* d_tile_range,
+                               int32_t total_tiles, hipStream_t st);
+void launch_lz4_frames_batch(LzRange* d_ranges, int32_t n_ranges, const int32_t* d_tile_range, int32_t total_tiles,
+                             hipStream_t st);
 void launch_lz4_discover(const uint8_t* d_comp, int64_t comp_len, int32_t n_tiles,
                          int64_t* d_spec_entry, int64_t* d_spec_exit, int32_t* d_spec_count,
                          int64_t* d_true_entry, int64_t* d_frame_base, int32_t* d_status,
