@@ -350,6 +350,7 @@ def main():
                         assert r[0] == 0 and r[1] == tasks[i]["u"]
                     if record:
                         acc[0] += c.stage_ms(s3shuffle.codec.STAGE_CODEC)
+                        acc[1] += c.stage_ms(s3shuffle.codec.STAGE_HASH)
                         acc[3] += c.stage_ms(s3shuffle.codec.STAGE_CHECKSUM)
                         acc[4] += c.stage_ms(s3shuffle.codec.STAGE_TOTAL)
                         n += 1

@@ -283,12 +283,18 @@ int s3s_decompress_range_device(s3s_ctx* ctx, int codec, int checksum_algo, cons
     return fail(ctx, S3S_E_CAPACITY, "dst_capacity %lld < %lld decoded bytes", (long long)dst_capacity, (long long)total);
 
   launch_lz4_decompress(d_comp, dev<Frame>(ctx, B_FRAMES), (int32_t)n_frames, dev<int64_t>(ctx, B_FRAME_OUT),
-                        d_dst, dev<int32_t>(ctx, B_STATUS), ctx->lz4_decode_variant, ctx->stream);
+                        d_dst, dev<int32_t>(ctx, B_STATUS), ctx->lz4_decode_variant, ctx->stream,
+                        ctx->profile ? ctx->ev_hash : nullptr);
   HIP_TRY(ctx, hipGetLastError());
   record(ctx, 3);  // ev3: decode done
   HIP_TRY(ctx, hipMemcpyAsync(&h_misc[1], ctx->buf[B_STATUS].p, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   finish_profile(3);
+  if (ctx->profile) {  // codec = the decode kernel alone, hash = the frame checks (ev_hash sits between them)
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev_hash) == hipSuccess) ctx->stage_ms[S3S_STAGE_CODEC] = ms;
+    if (hipEventElapsedTime(&ms, ctx->ev_hash, ctx->ev[3]) == hipSuccess) ctx->stage_ms[S3S_STAGE_HASH] = ms;
+  }
   int32_t st = *reinterpret_cast<int32_t*>(&h_misc[1]);
   if (st == S3S_E_UNSUPPORTED && ctx->lz4_decode_variant != 3) {
     // a frame above 32 KiB (written with a larger spark.io.compression.lz4.blockSize): the ring decoder takes any size
@@ -573,6 +579,7 @@ extern "C" int s3s_decompress_ranges_batch_device(s3s_ctx* ctx, int codec, int c
   if ((rc = ensure(ctx, B_FRAME_OUT, 8 * nf1))) return rc;
   if ((rc = ensure(ctx, B_ITEM_OFF, 8 * nf1))) return rc;
   int32_t* d_dec_status = d_status + n_ranges;
+  bool lz4_split = false;  // profile: ev_hash sits between the decode kernel and the frame-check kernel
   if (codec == S3S_CODEC_LZ4) {
     int32_t used_tiles = 0;
     for (int32_t r = 0; r < n_ranges; r++) {
@@ -592,7 +599,10 @@ extern "C" int s3s_decompress_ranges_batch_device(s3s_ctx* ctx, int codec, int c
     record(ctx, 2);
     if (total_frames > 0)
       launch_lz4_decompress(nullptr, dev<Frame>(ctx, B_FRAMES), (int32_t)total_frames, dev<int64_t>(ctx, B_ITEM_OFF), nullptr,
-                            d_dec_status, ctx->lz4_decode_variant, ctx->stream);
+                            d_dec_status, ctx->lz4_decode_variant, ctx->stream, ctx->profile ? ctx->ev_hash : nullptr);
+    else if (ctx->profile)
+      HIP_TRY(ctx, hipEventRecord(ctx->ev_hash, ctx->stream));
+    lz4_split = ctx->profile != 0;
     HIP_TRY(ctx, hipGetLastError());
     record(ctx, 3);
     HIP_TRY(ctx, hipMemcpyAsync(h_res, ctx->buf[B_REF_SUMS].p, 16 * (size_t)n_ranges, hipMemcpyDeviceToHost, ctx->stream));
@@ -653,6 +663,10 @@ extern "C" int s3s_decompress_ranges_batch_device(s3s_ctx* ctx, int codec, int c
     hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); ctx->stage_ms[S3S_STAGE_CHECKSUM] = ms;
     hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]); ctx->stage_ms[S3S_STAGE_DISCOVER] = ms;
     hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); ctx->stage_ms[S3S_STAGE_CODEC] = ms;
+    if (lz4_split) {  // codec = the decode kernel alone, hash = the frame checks
+      hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev_hash); ctx->stage_ms[S3S_STAGE_CODEC] = ms;
+      hipEventElapsedTime(&ms, ctx->ev_hash, ctx->ev[3]); ctx->stage_ms[S3S_STAGE_HASH] = ms;
+    }
   }
   if (h_st[n_ranges] != 0) {
     // some frame of the batch is corrupt (or unsupported): decode the ranges one by one to say which

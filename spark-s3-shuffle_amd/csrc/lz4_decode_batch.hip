@@ -685,10 +685,14 @@ __global__ __launch_bounds__(kWave) void lz4_verify_frames_kernel(
 
 void launch_lz4_decompress_batch(const uint8_t* d_comp, const Frame* d_frames, int32_t n_frames,
                                  const int64_t* d_frame_out, uint8_t* d_dst, int32_t* d_status,
-                                 hipStream_t st) {
-  if (n_frames <= 0) return;
+                                 hipStream_t st, hipEvent_t after_decode) {
+  if (n_frames <= 0) {
+    if (after_decode) (void)hipEventRecord(after_decode, st);
+    return;
+  }
   hipLaunchKernelGGL(batch_decode_kernel<kFmtLz4>, dim3((unsigned)n_frames), dim3(kWave), 0, st, d_comp, d_frames,
                      n_frames, d_frame_out, d_dst, d_status);
+  if (after_decode) (void)hipEventRecord(after_decode, st);
   hipLaunchKernelGGL(lz4_verify_frames_kernel, dim3((unsigned)((n_frames + kWave / 4 - 1) / (kWave / 4))), dim3(kWave),
                      0, st, d_frames, n_frames, d_frame_out, d_dst, d_status);
 }

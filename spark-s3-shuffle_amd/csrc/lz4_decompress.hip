@@ -655,14 +655,18 @@ void launch_scan_u32(const uint32_t* d_in, int64_t n, int64_t* d_out, hipStream_
 
 void launch_lz4_decompress(const uint8_t* d_comp, const Frame* d_frames, int32_t n_frames,
                            const int64_t* d_frame_out, uint8_t* d_dst, int32_t* d_status,
-                           int variant, hipStream_t st) {
-  if (n_frames <= 0) return;
+                           int variant, hipStream_t st, hipEvent_t after_decode) {
+  if (n_frames <= 0) {
+    if (after_decode) (void)hipEventRecord(after_decode, st);
+    return;
+  }
   if (variant == 3) {
     hipLaunchKernelGGL(lz4_decompress_valu_kernel, dim3((unsigned)n_frames), dim3(kWave), 0, st, d_comp,
                        d_frames, n_frames, d_frame_out, d_dst, d_status);
+    if (after_decode) (void)hipEventRecord(after_decode, st);
     return;
   }
-  launch_lz4_decompress_batch(d_comp, d_frames, n_frames, d_frame_out, d_dst, d_status, st);
+  launch_lz4_decompress_batch(d_comp, d_frames, n_frames, d_frame_out, d_dst, d_status, st, after_decode);
 }
 
 }  // namespace s3s

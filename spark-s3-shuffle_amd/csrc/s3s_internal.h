@@ -123,13 +123,14 @@ void launch_lz4_emit_frames(const uint8_t* d_comp, int64_t comp_len, int32_t n_t
                             Frame* d_frames, uint32_t* d_frame_orig, int64_t n_frames,
                             int64_t* d_frame_out, int32_t* d_status, hipStream_t st);
 //   variant 0: frame staged in LDS (3 frames per CU); 1: straight to global memory (no LDS)
+//   after_decode (optional): recorded between the decode kernel and the frame-check kernel of variant 4
 void launch_lz4_decompress(const uint8_t* d_comp, const Frame* d_frames, int32_t n_frames,
                            const int64_t* d_frame_out, uint8_t* d_dst, int32_t* d_status,
-                           int variant, hipStream_t st);
+                           int variant, hipStream_t st, hipEvent_t after_decode = nullptr);
 //   variant 4: batches of sequences, one lane per sequence (lz4_decode_batch.hip)
 void launch_lz4_decompress_batch(const uint8_t* d_comp, const Frame* d_frames, int32_t n_frames,
                                  const int64_t* d_frame_out, uint8_t* d_dst, int32_t* d_status,
-                                 hipStream_t st);
+                                 hipStream_t st, hipEvent_t after_decode = nullptr);
 void launch_snappy_decompress_batch(const uint8_t* d_comp, const Frame* d_frames, int32_t n_frames,
                                     const int64_t* d_frame_out, uint8_t* d_dst, int32_t* d_status,
                                     hipStream_t st);
