@@ -17,7 +17,7 @@
 //            dependency rounds: lanes whose source ends before the round's first output byte copy
 //            their (short) matches side by side, a long / overlapping / far match is copied by the
 //            whole wave, 64 bytes per step
-//   output   is staged in a sliding LDS window (7.5 KiB, 4 KiB of history survive a slide): match
+//   output   is staged in a sliding LDS window (5.4 KiB, 4 KiB of history survive a slide): match
 //            sources are LDS reads, the block leaves in 16-byte coalesced stores; a source older than
 //            the window is read back from L2 (after the flush that wrote it has drained)
 //   tokens the fast parse does not take (lengths with a 255 chain, the block's last sequence) go
@@ -30,8 +30,16 @@
 namespace s3s {
 namespace {
 
-constexpr int kBWin = 7616;   // staged output bytes (multiple of 16); with pad + records = 8 KiB -> 20 wavefronts / CU
-constexpr int kBHist = 4096;  // history a slide keeps
+#ifndef S3S_BWIN
+#define S3S_BWIN 5568
+#endif
+#ifndef S3S_BHIST
+#define S3S_BHIST 4096
+#endif
+constexpr int kBWin = S3S_BWIN;    // staged output bytes (multiple of 16); with pad + records = 6 KiB -> 26 wavefronts / CU
+                                   // (measured: 7616 / 4096 = 20 per CU 278 GB/s, 5568 / 4096 298, 4544 / 3072 284, 3520 / 2048 292)
+constexpr int kBHist = S3S_BHIST;  // history a slide keeps
+static_assert(kBWin % 16 == 0 && kBHist % 16 == 0 && kBWin >= kBHist + 1024, "window geometry");
 constexpr int kBPad = 64;
 constexpr int kSmallMl = 16;  // matches up to this length are copied one lane per sequence
 constexpr int kSmallLit = 16; // literal runs up to this length are copied one lane per sequence

@@ -17,7 +17,7 @@
 namespace {
 
 constexpr int W = 64;
-constexpr int kWin = 8192;    // bytes of output held in the staging window
+constexpr int kWin = 5568;    // bytes of output held in the staging window (= kBWin of the kernel)
 constexpr int kHist = 4096;   // history kept by a slide
 constexpr int kPad = 64;
 constexpr int kSmallMl = 16;  // per-lane match copies up to this length, longer ones cooperatively
