@@ -41,7 +41,10 @@ constexpr int kBWin = S3S_BWIN;    // staged output bytes (multiple of 16); with
 constexpr int kBHist = S3S_BHIST;  // history a slide keeps
 static_assert(kBWin % 16 == 0 && kBHist % 16 == 0 && kBWin >= kBHist + 1024, "window geometry");
 constexpr int kBPad = 64;
-constexpr int kSmallMl = 16;  // matches up to this length are copied one lane per sequence
+#ifndef S3S_SMALL_ML
+#define S3S_SMALL_ML 16
+#endif
+constexpr int kSmallMl = S3S_SMALL_ML;  // matches up to this length are copied one lane per sequence (4 dwords + tail in registers)
 constexpr int kSmallLit = 16; // literal runs up to this length are copied one lane per sequence
 
 constexpr uint32_t XP1 = 2654435761u, XP2 = 2246822519u, XP3 = 3266489917u, XP4 = 668265263u, XP5 = 374761393u;
@@ -125,6 +128,7 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
     const int sh = (int)(reinterpret_cast<uintptr_t>(out) & 15u);  // window index of output byte o: o + sh - wb
     int wb = 0, flushed = 0, op = 0, ip = ip_start, nseq = 0;      // wave-uniform
     bool need_drain = false;  // stores of a flush may still be in flight (matters to far matches only)
+    bool open_lit = false;    // Snappy: the batch's last record is a literal element that a following copy may join
 
     // ---- window management ---------------------------------------------------------------------------
     auto flush_to = [&](int upto) __attribute__((always_inline)) {  // window -> out for output bytes [flushed, upto)
@@ -513,7 +517,7 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
     // ---- main loop: parse windows of 64 stream bytes ---------------------------------------------------
     for (;;) {
       bool eob = false;
-      bool cx = true;
+      bool cx = true, is_lit = false;
       int nxt = 0;
       uint32_t r0 = 0, r1 = 0;
       if (ip >= clen) {
@@ -537,6 +541,7 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
               }
               nxt = cpos + hdr + len;
               cx = n6 > 61u || nxt > clen || len > kMaxBlock;
+              is_lit = true;
               r0 = (uint32_t)len;
               r1 = (uint32_t)(cpos + hdr) << 16;
             } else if (ty == 1u) {
@@ -582,19 +587,66 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
       const int nrel = cx ? -1 : nxt - ip;
       uint64_t mask = 0;
       int rel = 0;
-      for (;;) {
-        const int n = __builtin_amdgcn_readlane(nrel, rel);
-        if (n < 0) break;
-        mask |= 1ull << rel;
-        rel = n;
-        if (rel >= kWave) break;
+      if constexpr (kFmt == kFmtSnappy) {
+        // Snappy elements are 2-3 bytes long on match-dense data (25 per window): the scalar walk (8 instructions
+        // per token) would dominate, so the chain is followed by pointer doubling instead — six rounds of "lanes on
+        // the chain mark the lane 2^k tokens behind them" through 64 bytes of LDS (the window's pad), whatever the
+        // number of tokens.
+        uint8_t* mark = win + kBWin;  // (only ever over-read otherwise)
+        int jmp = cx ? kWave : (nrel < kWave ? nrel : kWave);
+        bool reach = lane == 0;
+        mark[lane] = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          if (reach && jmp < kWave) mark[jmp] = 1;
+          reach = reach || mark[lane] != 0;
+          const int j2 = __shfl(jmp, jmp & 63);
+          jmp = jmp < kWave ? j2 : kWave;
+        }
+        const uint64_t RM = __ballot(reach);
+        const uint64_t CXR = __ballot(reach && cx);  // the (at most one) complex token the chain runs into
+        mask = RM & ~CXR;
+        if (CXR) rel = __builtin_ctzll(CXR);
+        else rel = __builtin_amdgcn_readlane(nrel, 63 - __builtin_clzll(mask));  // (lane 0 is on the chain: mask != 0)
+      } else {
+        for (;;) {
+          const int n = __builtin_amdgcn_readlane(nrel, rel);
+          if (n < 0) break;
+          mask |= 1ull << rel;
+          rel = n;
+          if (rel >= kWave) break;
+        }
       }
       const int cur = ip + rel;
-      const int cnt = __builtin_popcountll(mask);
+      // Snappy: a copy element that directly follows a literal element shares the literal's record (literal run +
+      // match = one sequence, as in LZ4): half as many records, batches and round lanes.  S = tokens that start a
+      // record, J = copy tokens that join the record in front of them (`open`: the batch's last record is a
+      // literal whose successor is this window's first token).
+      uint64_t S = mask, J = 0ull;
+      bool joined = false;
+      if constexpr (kFmt == kFmtSnappy) {
+        const uint64_t LM = __ballot(is_lit) & mask;
+        const uint64_t below = mask & ((1ull << lane) - 1ull);
+        const bool prev_lit = below ? ((LM >> (63 - __builtin_clzll(below))) & 1ull) != 0ull : open_lit;
+        joined = ((mask >> lane) & 1ull) != 0ull && !is_lit && prev_lit;
+        J = __ballot(joined);
+        S = mask & ~J;
+      }
+      int cnt = __builtin_popcountll(S);
       // the batch is flushed when this window's sequences do not fit any more, and in front of every
       // sequence of the byte-wise path (so in particular in front of the block's last sequence)
       if (mask == 0ull || nseq + cnt > kWave) {
         if (!flush_batch()) { bad = true; break; }
+        if constexpr (kFmt == kFmtSnappy) {
+          if (open_lit && (J & mask & (0ull - mask)) != 0ull) {  // the first token cannot join a flushed record any more
+            const uint64_t first = mask & (0ull - mask);
+            J &= ~first;
+            S |= first;
+            joined = joined && ((first >> lane) & 1ull) == 0ull;
+            cnt = __builtin_popcountll(S);
+          }
+          open_lit = false;
+        }
       }
       if (eob) break;
       if (mask == 0ull) {
@@ -604,8 +656,18 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
         continue;
       }
       if ((mask >> lane) & 1ull) {
-        const int t = nseq + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        rec[t] = make_uint2(r0, r1);
+        const int t = nseq + __builtin_amdgcn_mbcnt_hi((uint32_t)(S >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)S, 0u));
+        if (!joined) rec[t] = make_uint2(r0, r1);
+      }
+      if constexpr (kFmt == kFmtSnappy) {
+        if (joined) {  // (after the record's first half has been stored by the literal's lane)
+          const int t = nseq + __builtin_amdgcn_mbcnt_hi((uint32_t)(S >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)S, 0u)) - 1;
+          uint16_t* h16 = reinterpret_cast<uint16_t*>(rec + t);
+          h16[1] = (uint16_t)(r0 >> 16);  // match length
+          h16[2] = (uint16_t)r1;          // offset
+        }
+        const uint64_t LM = __ballot(is_lit) & mask;
+        open_lit = ((LM >> (63 - __builtin_clzll(mask))) & 1ull) != 0ull;  // the window's last token is a literal
       }
       nseq += cnt;
       ip = cur;

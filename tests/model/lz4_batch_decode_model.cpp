@@ -40,6 +40,7 @@ struct Model {
   // batch records (one per lane)
   int r_lit[W], r_ml[W], r_off[W], r_src[W];
   int nseq = 0;
+  bool open_lit = false;  // Snappy: the batch's last record is a literal element that a following copy may join
   // statistics
   long st_seqs = 0, st_roundseqs = 0, st_brk_len = 0, st_brk_dep = 0, st_brk_far = 0, st_windows = 0, st_batches = 0, st_rounds = 0, st_single = 0, st_slow = 0, st_slides = 0, st_far = 0;
 
@@ -380,24 +381,51 @@ struct Model {
         mask |= 1ull << rel;
         cur = nxt[rel];
       }
-      if (mask != 0 && nseq + __builtin_popcountll(mask) > W && !flush_batch()) return -1;
+      // Snappy: a copy element directly behind a literal element shares the literal's record
+      auto plan = [&](bool open, uint64_t& S, uint64_t& J) {
+        S = 0; J = 0;
+        bool prev_lit = open;
+        for (int i = 0; i < W; i++)
+          if ((mask >> i) & 1ull) {
+            const bool lit_tok = fmt == 1 && p_ml[i] == 0;
+            if (fmt == 1 && !lit_tok && prev_lit) J |= 1ull << i; else S |= 1ull << i;
+            prev_lit = lit_tok;
+          }
+      };
+      uint64_t S, J;
+      plan(open_lit, S, J);
+      if (mask != 0 && nseq + __builtin_popcountll(S) > W) {
+        if (!flush_batch()) return -1;
+        open_lit = false;
+        plan(false, S, J);
+      }
       if (mask == 0) {  // the token at ip itself is complex
         if (!flush_batch()) return -1;
+        open_lit = false;
         const int r = slow_sequence();
         if (r < 0) return -1;
         if (r == 1) break;
         continue;
       }
       // ---- append the window's sequences to the batch -------------------------------------------------
+      bool last_lit = false;
       for (int i = 0; i < W; i++)
         if ((mask >> i) & 1ull) {
-          const int t = nseq + __builtin_popcountll(mask & ((1ull << i) - 1ull));
-          r_lit[t] = p_lit[i];
-          r_ml[t] = p_ml[i];
-          r_off[t] = p_off[i];
-          r_src[t] = p_src[i];
+          const int t = nseq + __builtin_popcountll(S & ((1ull << i) - 1ull));
+          if ((J >> i) & 1ull) {
+            if (t - 1 < 0 || t - 1 >= W) { oob = true; return -1; }
+            r_ml[t - 1] = p_ml[i];
+            r_off[t - 1] = p_off[i];
+          } else {
+            r_lit[t] = p_lit[i];
+            r_ml[t] = p_ml[i];
+            r_off[t] = p_off[i];
+            r_src[t] = p_src[i];
+          }
+          last_lit = fmt == 1 && p_ml[i] == 0;
         }
-      nseq += __builtin_popcountll(mask);
+      open_lit = last_lit;
+      nseq += __builtin_popcountll(S);
       ip = cur;
     }
     if (!flush_batch()) return -1;  // (empty: the slow path flushed before the last sequence)
