@@ -73,6 +73,12 @@ __device__ __forceinline__ void lds_st16(uint8_t* p, uint32_t v) {
 }
 
 enum { kFmtLz4 = 0, kFmtSnappy = 1 };
+#ifndef S3S_PWALK_TOKENS
+#define S3S_PWALK_TOKENS 12
+#endif
+// LZ4: windows are walked by pointer doubling when the previous window held at least this many tokens (measured:
+// always scalar 295 / 148 GB/s on TeraSort / wide rows, always doubling 291 / 164)
+constexpr int kParallelWalkTokens = S3S_PWALK_TOKENS;
 
 // kFmt selects the front end (token parse + byte-wise path); batches, rounds and the output window are the same:
 // a Snappy element is a sequence with either literals only (ml = 0) or a copy only (lit = 0).
@@ -128,6 +134,7 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
     const int sh = (int)(reinterpret_cast<uintptr_t>(out) & 15u);  // window index of output byte o: o + sh - wb
     int wb = 0, flushed = 0, op = 0, ip = ip_start, nseq = 0;      // wave-uniform
     bool need_drain = false;  // stores of a flush may still be in flight (matters to far matches only)
+    int last_tokens = 0;      // tokens found in the previous parse window (picks the walk for this one)
     bool open_lit = false;    // Snappy: the batch's last record is a literal element that a following copy may join
 
     // ---- window management ---------------------------------------------------------------------------
@@ -587,7 +594,7 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
       const int nrel = cx ? -1 : nxt - ip;
       uint64_t mask = 0;
       int rel = 0;
-      if constexpr (kFmt == kFmtSnappy) {
+      if (kFmt == kFmtSnappy || last_tokens >= kParallelWalkTokens) {
         // Snappy elements are 2-3 bytes long on match-dense data (25 per window): the scalar walk (8 instructions
         // per token) would dominate, so the chain is followed by pointer doubling instead — six rounds of "lanes on
         // the chain mark the lane 2^k tokens behind them" through 64 bytes of LDS (the window's pad), whatever the
@@ -617,6 +624,7 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
           if (rel >= kWave) break;
         }
       }
+      last_tokens = __builtin_popcountll(mask);
       const int cur = ip + rel;
       // Snappy: a copy element that directly follows a literal element shares the literal's record (literal run +
       // match = one sequence, as in LZ4): half as many records, batches and round lanes.  S = tokens that start a
