@@ -649,11 +649,7 @@ __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t*
               } else {
                 // every literal is the low byte of a lane's v (this window) or vp (the previous one): lane L
                 // stores its own byte, four otherwise idle lanes store token / offset / match-length byte
-#ifdef S3S_ABL_NOEMIT
-                if (false) {
-#else
                 {
-#endif
                 const uint32_t rel = (uint32_t)(lane - anchor) & 63u;
                 const uint32_t tok = (uint32_t)(lit << 4) | (uint32_t)(mcode < 15 ? mcode : 15);
                 const uint32_t d = rel - (uint32_t)lit;  // 0: token, 1/2: offset, 3: match-length byte
@@ -663,11 +659,7 @@ __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t*
                 bv = d == 2u ? (uint32_t)offset >> 8 : bv;
                 bv = d == 3u ? (uint32_t)(mcode - 15) : bv;
                 const uint32_t idx = d == 0u ? 0u : rel + (rel < (uint32_t)lit ? 1u : 0u);
-#if defined(S3S_ABL_NOSTORE)
-                asm volatile("" ::"v"(bv), "v"(idx));
-#else
                 if (rel < (uint32_t)total) out[(uint32_t)op + idx] = (uint8_t)bv;
-#endif
                 }
                 op += total;
               }
