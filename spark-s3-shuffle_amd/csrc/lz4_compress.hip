@@ -25,6 +25,8 @@
 // straight to the chunk's slot in HBM; compressed output never exceeds the chunk length (anything longer is
 // stored RAW by the frame rule compressedLength >= originalLength), so a slot is 32 B + 32 KiB.
 #include "s3s_internal.h"
+#include "lz4_run_loop.inc"
+#include "lz4_window_engine.inc"
 
 #ifdef S3S_LZ4_TIMING
 __device__ unsigned long long g_lz4_dbg[32];
@@ -272,14 +274,58 @@ __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t*
         //     backward count up to 4 — enough for the short matches of serialized rows; anything longer goes
         //     to the cooperative extension (one more round trip per LONG sequence only);
         //   * the duplicate-hash passes over the table run while that gather is in flight.
-        const int wbase = base & ~63;
+        int wbase = base & ~63;
         if (!force_general && t0 <= 48 && wbase >= 64 && wbase <= fast_limit) {
+          have_pre = false;
+          // window state: set by the preparation below, or by the hand-written block when it hands over in mid-window
+          uint32_t v, h, cp, info;
+          uint64_t Dp, ED, K, valid;
+          int rs, pend_q;
+          bool resumed = false;
+#ifndef S3S_NO_WINDOW_ENGINE
+          if ((uint32_t)reinterpret_cast<uintptr_t>(table) == 0u) {  // (the block addresses the table at LDS offset 0)
+            // Whole windows in one hand-written gfx950 block (lz4_window_engine.inc): it returns at a window
+            // boundary (codes 0, 3, 4) or at the first event it does not handle (code 2: the loop below resumes there).
+            int code, putp = __builtin_amdgcn_readfirstlane(put_pending ? 1 : 0);
+            const int base_in = base;
+            uint32_t vput_s = __builtin_amdgcn_readfirstlane(vput);
+            uint64_t p0l = pw0.x | ((uint64_t)pw0.y << 32), p0h = pw0.z | ((uint64_t)pw0.w << 32);
+            uint64_t p1l = pw1.x | ((uint64_t)pw1.y << 32), p1h = pw1.z | ((uint64_t)pw1.w << 32);
+            uint64_t p2l = pw2.x | ((uint64_t)pw2.y << 32), p2h = pw2.z | ((uint64_t)pw2.w << 32);
+            asm volatile(S3S_WINDOW_ENGINE_ASM
+                         : [code] "=&s"(code), [h] "=&v"(h), [cp] "=&v"(cp), [info] "=&v"(info), [base] "+s"(base),
+                           [t0] "+s"(t0), [anchor] "+s"(anchor), [op] "+s"(op), [pk] "+s"(pk), [kp] "+s"(kp),
+                           [vput] "+s"(vput_s), [putp] "+s"(putp), [K] "=&s"(K), [valid] "=&s"(valid), [ED] "=&s"(ED),
+                           [Dp] "=&s"(Dp), [rs] "=&s"(rs), [pendq] "=&s"(pend_q), [p0l] "+v"(p0l), [p0h] "+v"(p0h),
+                           [p1l] "+v"(p1l), [p1h] "+v"(p1h), [p2l] "+v"(p2l), [p2h] "+v"(p2h), [vp] "+v"(vp)
+                         : [len] "s"(len), [inp] "s"(in.base), [outp] "s"(out)
+                         : "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86",
+                           "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99",
+                           "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133",
+                           "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145",
+                           "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "vcc", "scc", "memory");
+            pw0 = make_uint4((uint32_t)p0l, (uint32_t)(p0l >> 32), (uint32_t)p0h, (uint32_t)(p0h >> 32));
+            pw1 = make_uint4((uint32_t)p1l, (uint32_t)(p1l >> 32), (uint32_t)p1h, (uint32_t)(p1h >> 32));
+            pw2 = make_uint4((uint32_t)p2l, (uint32_t)(p2l >> 32), (uint32_t)p2h, (uint32_t)(p2h >> 32));
+            vput = vput_s;
+            put_pending = putp != 0;
+            if (code == 3) break;  // last literals
+            if (code == 4) {
+              force_general = true;
+              continue;
+            }
+            if (code == 0 && base != base_in) continue;  // the conditions fail at the next window: re-dispatch
+            resumed = code == 2;
+            wbase = base & ~63;
+          }
+#endif
+          const int p = wbase + lane;
+          const int rs0 = base - wbase;
+          if (!resumed) {
           if (put_pending) T[hash13(vput)] = (uint16_t)(base - 2);  // LZ4_putPosition(ip - 2)
           put_pending = false;
-          have_pre = false;
           DBG_T(t4a);
           DBG_ADD(8, 1);
-          const int p = wbase + lane;
           if (pk != wbase) {
             if (pk + 64 == wbase) {
               vp = pw0.y;
@@ -300,23 +346,16 @@ __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t*
             }
             pk = wbase;
           }
-          const bool vp_ok = kp == wbase - 64;  // vp holds the previous window's dwords (literals may start there)
-          const uint32_t v = pw0.y;
-          const uint32_t h = hash13(v);
-          const int rs0 = base - wbase;
+          v = pw0.y;
+          h = hash13(v);
           const bool live = lane >= rs0;
-          const uint32_t cp = T[h];
+          cp = T[h];
 #ifdef S3S_LZ4_TIMING
           asm volatile("" ::"v"(cp));
 #endif
           DBG_T(t4b);
           const bool near0 = cp < 4u;  // (also every empty slot: it reads as position 0)
           const uint4 G = in.ld16(near0 ? 0 : (int)cp - 4);
-#ifdef S3S_G2_PREFETCH
-          // touch the candidate's next cache line too: a long match's cooperative extension then hits L1/L2
-          const int g2p = (int)cp + 64 + 60;
-          const uint32_t g2 = in.rd32(g2p < last4 ? g2p : last4);
-#endif
           // duplicate-hash groups among the live lanes (two speculative store passes, rolled back) — while G flies
           bool grp = false;
           if (live) {
@@ -337,13 +376,10 @@ __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t*
 #endif
           DBG_T(t4c);
           const uint32_t w = near0 ? __builtin_amdgcn_alignbyte(G.y, G.x, cp) : G.y;
-#ifdef S3S_G2_PREFETCH
-          asm volatile("" ::"v"(g2));
-#endif
           const bool em = live && (w == v);
           // per-lane event record: [15:0] table candidate, [19:16] forward length 0..8 (8 = at least),
-          // [22:20] backward equal bytes 0..4 (4 = at least), [30] candidate matches, [31] suspect lane
-          uint32_t info = grp ? 0x80000000u : 0u;
+          // [22:20] backward equal bytes 0..4 (4 = at least), [30] candidate matches
+          info = 0u;
           if (em) {
             uint32_t fl = 8u, be = 0u;  // near0: lengths by the cooperative extension
             if (!near0) {
@@ -351,26 +387,34 @@ __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t*
               fl = xz ? (uint32_t)(__builtin_ctz(xz) >> 3) : (xw ? 4u + (uint32_t)(__builtin_ctz(xw) >> 3) : 8u);
               be = xb ? (uint32_t)(__builtin_clz(xb) >> 3) : 4u;
             }
-            info |= cp | (fl << 16) | (be << 20) | 0x40000000u;
+            info = cp | (fl << 16) | (be << 20) | 0x40000000u;
           }
           const uint64_t Ecp = __ballot(em);
-          const uint64_t Dp = __ballot(grp);
-          uint64_t ED = Ecp | Dp;  // lanes the run loop has to look at
-          DBG_T(t4d);
+          Dp = __ballot(grp);
+          ED = Ecp | Dp;  // lanes the run loop has to look at
+          DBG_T(t4d0);
           DBG_ADD(0, t4b - t4a);
           DBG_ADD(1, t4c0 - t4b);
           DBG_ADD(2, t4c - t4c0);
-          DBG_ADD(6, t4d - t4c);
+          DBG_ADD(6, t4d0 - t4c);
+          K = 0;  // lanes the sequential code inserts: probes and ip-2 positions
+          rs = rs0;
+          pend_q = -1;
+          }
+          v = pw0.y;
+          const bool vp_ok = kp == wbase - 64;  // vp holds the previous window's dwords (literals may start there)
+          DBG_T(t4d);
           // ================= runs (scalar work) ========================================================
           // One loop with a single hot path: next event -> (rare: suspect lane) -> (cooperative extension)
           // -> short-form emit -> advance.  Conditions are folded into sign tests of small integer
           // expressions so that hipcc does not materialise 64-bit lane masks for every boolean.
-          uint64_t K = 0;      // lanes the sequential code inserts: probes and ip-2 positions
-          int rs = rs0, rt = t0, pend_q = -1;
+          const bool had_match = resumed && K != 0ull;  // (a match sets its lane in K)
+          int rt = had_match ? 0 : t0;
           int exit_kind = 0;   // 0: next window / batch, 1: last literals, 2: the general batch takes over
           const int e0 = rs0 + 66 - t0;  // the first run may continue an older one (t0 <= 48 => e0 >= rs0 + 18)
-          int elim = e0 < kWave ? e0 : kWave;
-          uint64_t valid = e0 < kWave ? ((1ull << e0) - 1ull) : ~0ull;  // consecutive probes of the current run
+          int elim = (had_match || e0 >= kWave) ? kWave : e0;
+          if (!resumed) valid = e0 < kWave ? ((1ull << e0) - 1ull) : ~0ull;  // consecutive probes of the current run
+          bool skip_block = resumed;  // the block above has just refused this event
           const int lit_floor = vp_ok ? wbase - 64 : wbase;  // literals in registers start here
           // Cost model measured on gfx950 (tools/probe/issue_probe.hip): a plain SALU / VALU instruction costs a
           // wave ~5 cycles, a taken branch ~25, a not-taken one ~11, a VALU -> SGPR -> SALU crossing ~+20.  So the
@@ -383,6 +427,7 @@ __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t*
             for (;;) {
 #ifndef S3S_NO_ASM_RUN_LOOP  // (-DS3S_NO_ASM_RUN_LOOP: the compiled loop alone, for A/B runs)
               if ((ED & valid & (~0ull << rs)) == 0ull) { why = kNoEvent; break; }  // nothing to do: skip the block
+              if (!skip_block)
               // Hand-scheduled gfx950 code for the COMMON event (candidate matches, no earlier same-candidate lane,
               // extension of at most one cooperative round, short-form sequence): the same arithmetic as the C++
               // body below in ~95 (no extension) / ~130 (with it) instructions instead of the ~135 / ~190 hipcc emits
@@ -391,174 +436,7 @@ __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t*
               {
                 int code;
                 const int anchor_in = anchor;
-                asm volatile(
-                    ".Lrl_top_%=:\n\t"
-                    "s_lshl_b64 s[80:81], -1, %[rs]\n\t"
-                    "s_and_b64 s[80:81], s[80:81], %[valid]\n\t"
-                    "s_and_b64 s[82:83], s[80:81], %[ED]\n\t"
-                    "s_cbranch_scc0 .Lrl_x0_%=\n\t"
-                    "s_ff1_i32_b64 s86, s[82:83]\n\t"
-                    "s_nop 0\n\t"
-                    "v_readlane_b32 s87, %[info], s86\n\t"
-                    "s_bitcmp0_b32 s87, 30\n\t"
-                    "s_cbranch_scc1 .Lrl_nomatch_%=\n\t"
-                    "s_and_b32 s88, s87, 0xffff\n\t"
-                    "v_cmp_eq_u32_e64 s[82:83], s88, %[cp]\n\t"
-                    "s_or_b64 s[84:85], s[80:81], %[K]\n\t"
-                    "s_and_b64 s[82:83], s[82:83], s[84:85]\n\t"
-                    "s_and_b64 s[82:83], s[82:83], %[Dp]\n\t"
-                    "s_lshl_b64 s[84:85], -1, s86\n\t"
-                    "s_andn2_b64 s[82:83], s[82:83], s[84:85]\n\t"
-                    "s_cbranch_scc1 .Lrl_x2_%=\n\t"
-                    "s_add_i32 s89, %[wbase], s86\n\t"
-                    "s_bfe_u32 s90, s87, 0x40010\n\t"
-                    "s_bfe_u32 s91, s87, 0x30014\n\t"
-                    "s_sub_i32 s92, s89, %[anchor]\n\t"
-                    "s_sub_i32 s97, 7, s90\n\t"
-                    "s_sub_i32 s98, 3, s91\n\t"
-                    "s_sub_i32 s99, 4, s92\n\t"
-                    "s_and_b32 s98, s98, s99\n\t"
-                    "s_or_b32 s97, s97, s98\n\t"
-                    "s_min_i32 s91, s91, s92\n\t"
-                    "s_cmp_lt_i32 s97, 0\n\t"
-                    "s_cbranch_scc0 .Lrl_len_%=\n\t"
-                    // ---- cooperative extension, one round: 256 B forward, 64 B backward
-                    "s_add_i32 s97, s89, 4\n\t"
-                    "v_lshl_add_u32 v125, %[lane], 2, s97\n\t"
-                    "v_min_i32_e32 v125, %[last4], v125\n\t"
-                    "s_sub_i32 s98, s89, s88\n\t"
-                    "v_subrev_u32_e32 v126, s98, v125\n\t"
-                    "global_load_dword v125, v125, %[inp]\n\t"
-                    "global_load_dword v126, v126, %[inp]\n\t"
-                    "s_min_i32 s99, s92, s88\n\t"
-                    "v_mov_b32_e32 v127, 0\n\t"
-                    "v_mov_b32_e32 v128, 1\n\t"
-                    "v_cmp_gt_i32_e64 s[82:83], s99, %[lane]\n\t"
-                    "s_add_i32 s97, s89, -1\n\t"
-                    "s_add_i32 s98, s88, -1\n\t"
-                    "s_and_saveexec_b64 s[84:85], s[82:83]\n\t"
-                    "v_sub_u32_e32 v123, s97, %[lane]\n\t"
-                    "v_sub_u32_e32 v124, s98, %[lane]\n\t"
-                    "global_load_ubyte v127, v123, %[inp]\n\t"
-                    "global_load_ubyte v128, v124, %[inp]\n\t"
-                    "s_mov_b64 exec, s[84:85]\n\t"
-                    "s_sub_i32 s99, %[mlimit], s89\n\t"
-                    "s_add_i32 s99, s99, -4\n\t"
-                    "s_waitcnt vmcnt(0)\n\t"
-                    "v_cmp_ne_u32_e64 s[82:83], v125, v126\n\t"
-                    "v_cmp_ne_u32_e64 s[84:85], v127, v128\n\t"
-                    "v_xor_b32_e32 v123, v125, v126\n\t"
-                    "s_ff1_i32_b64 s97, s[84:85]\n\t"
-                    "s_min_u32 s97, s97, 63\n\t"
-                    "s_cmp_eq_u32 s97, 63\n\t"
-                    "s_cbranch_scc1 .Lrl_x2_%=\n\t"
-                    "s_cmp_eq_u64 s[82:83], 0\n\t"
-                    "s_cbranch_scc1 .Lrl_full_%=\n\t"
-                    "s_ff1_i32_b64 s98, s[82:83]\n\t"
-                    "s_nop 0\n\t"
-                    "v_readlane_b32 s90, v123, s98\n\t"
-                    "s_lshl_b32 s98, s98, 2\n\t"
-                    "s_ff1_i32_b32 s90, s90\n\t"
-                    "s_lshr_b32 s90, s90, 3\n\t"
-                    "s_add_i32 s90, s90, s98\n\t"
-                    "s_branch .Lrl_got_%=\n\t"
-                    ".Lrl_full_%=:\n\t"
-                    "s_cmpk_gt_i32 s99, 0x100\n\t"
-                    "s_cbranch_scc1 .Lrl_x2_%=\n\t"
-                    "s_movk_i32 s90, 0x100\n\t"
-                    ".Lrl_got_%=:\n\t"
-                    "s_min_i32 s90, s90, s99\n\t"
-                    "s_mov_b32 s91, s97\n\t"
-                    // ---- lengths, short-form test
-                    ".Lrl_len_%=:\n\t"
-                    "s_sub_i32 s93, s92, s91\n\t"
-                    "s_add_i32 s94, s91, s90\n\t"
-                    "s_cmp_gt_i32 s94, 14\n\t"
-                    "s_cselect_b32 s95, 4, 3\n\t"
-                    "s_add_i32 s95, s95, s93\n\t"
-                    "s_add_i32 s96, s89, 4\n\t"
-                    "s_add_i32 s96, s96, s90\n\t"
-                    "s_sub_i32 s97, %[anchor], %[litfloor]\n\t"
-                    "s_sub_i32 s98, 14, s93\n\t"
-                    "s_or_b32 s97, s97, s98\n\t"
-                    "s_sub_i32 s98, 0x10d, s94\n\t"
-                    "s_or_b32 s97, s97, s98\n\t"
-                    "s_sub_i32 s98, %[len], %[op]\n\t"
-                    "s_sub_i32 s98, s98, s95\n\t"
-                    "s_or_b32 s97, s97, s98\n\t"
-                    "s_cmp_lt_i32 s97, 0\n\t"
-                    "s_cbranch_scc1 .Lrl_x2_%=\n\t"
-                    // ---- emit: token | literals (low bytes of v / vp) | offset | [match-length byte], one byte per lane
-                    "v_subrev_u32_e32 v120, %[anchor], %[lane]\n\t"
-                    "s_min_i32 s97, s94, 15\n\t"
-                    "s_lshl_b32 s98, s93, 4\n\t"
-                    "v_and_b32_e32 v120, 63, v120\n\t"
-                    "s_or_b32 s97, s97, s98\n\t"
-                    "s_sub_i32 s98, s89, s88\n\t"
-                    "v_subrev_u32_e32 v121, s93, v120\n\t"
-                    "s_lshl_b32 s98, s98, 8\n\t"
-                    "v_add_u32_e32 v123, %[anchor], v120\n\t"
-                    "s_or_b32 s97, s97, s98\n\t"
-                    "v_cmp_gt_i32_e32 vcc, %[wbase], v123\n\t"
-                    "s_add_i32 s98, s94, -15\n\t"
-                    "s_lshl_b32 s98, s98, 24\n\t"
-                    "v_cndmask_b32_e32 v122, %[v], %[vp], vcc\n\t"
-                    "s_or_b32 s99, s97, s98\n\t"
-                    "v_lshlrev_b32_e32 v123, 3, v121\n\t"
-                    "v_lshrrev_b32_e64 v123, v123, s99\n\t"
-                    "v_cmp_gt_u32_e32 vcc, 4, v121\n\t"
-                    "s_nop 1\n\t"
-                    "v_cndmask_b32_e32 v122, v122, v123, vcc\n\t"
-                    "v_cmp_gt_u32_e32 vcc, s93, v120\n\t"
-                    "s_nop 1\n\t"
-                    "v_addc_co_u32_e32 v124, vcc, 0, v120, vcc\n\t"
-                    "v_cmp_ne_u32_e32 vcc, s93, v120\n\t"
-                    "v_cmp_gt_u32_e64 s[82:83], s95, v120\n\t"
-                    "s_nop 0\n\t"
-                    "v_cndmask_b32_e32 v124, 0, v124, vcc\n\t"
-                    "v_add_u32_e32 v124, %[op], v124\n\t"
-                    "s_and_saveexec_b64 s[84:85], s[82:83]\n\t"
-                    "global_store_byte v124, v122, %[outp]\n\t"
-                    "s_mov_b64 exec, s[84:85]\n\t"
-                    "s_add_i32 %[op], %[op], s95\n\t"
-                    // ---- state update
-                    "s_lshl_b64 s[82:83], -2, s86\n\t"
-                    "s_andn2_b64 s[82:83], s[80:81], s[82:83]\n\t"
-                    "s_or_b64 %[K], %[K], s[82:83]\n\t"
-                    "s_mov_b32 %[anchor], s96\n\t"
-                    "s_sub_i32 s97, s96, %[wbase]\n\t"
-                    "s_add_i32 s98, s97, -2\n\t"
-                    "s_add_i32 s99, s96, -2\n\t"
-                    "s_lshl_b64 s[82:83], 1, s98\n\t"
-                    "s_cmp_lt_i32 s98, 64\n\t"
-                    "s_cselect_b64 s[82:83], s[82:83], 0\n\t"
-                    "s_cselect_b32 %[pendq], %[pendq], s99\n\t"
-                    "s_or_b64 %[K], %[K], s[82:83]\n\t"
-                    "s_mov_b32 %[rs], s97\n\t"
-                    "s_mov_b64 %[valid], -1\n\t"
-                    "s_cmp_lt_i32 s97, 64\n\t"
-                    "s_cbranch_scc1 .Lrl_top_%=\n\t"
-                    "s_mov_b32 %[code], 1\n\t"
-                    "s_branch .Lrl_end_%=\n\t"
-                    // ---- a duplicate-hash lane whose table candidate does not match: a plain no-match probe unless an
-                    //      earlier kept / in-run lane of the window shares its HASH (then the exact C++ path decides)
-                    ".Lrl_nomatch_%=:\n\t"
-                    "v_readlane_b32 s88, %[h], s86\n\t"
-                    "s_or_b64 s[84:85], s[80:81], %[K]\n\t"
-                    "v_cmp_eq_u32_e64 s[82:83], s88, %[h]\n\t"
-                    "s_and_b64 s[82:83], s[82:83], s[84:85]\n\t"
-                    "s_lshl_b64 s[84:85], -1, s86\n\t"
-                    "s_andn2_b64 s[82:83], s[82:83], s[84:85]\n\t"
-                    "s_cbranch_scc1 .Lrl_x2_%=\n\t"
-                    "s_lshl_b64 s[84:85], 1, s86\n\t"
-                    "s_andn2_b64 %[ED], %[ED], s[84:85]\n\t"
-                    "s_branch .Lrl_top_%=\n\t"
-                    ".Lrl_x0_%=:\n\t"
-                    "s_mov_b32 %[code], 0\n\t"
-                    "s_branch .Lrl_end_%=\n\t"
-                    ".Lrl_x2_%=:\n\t"
-                    "s_mov_b32 %[code], 2\n\t"
-                    ".Lrl_end_%=:\n\t"
+                asm volatile(S3S_RUN_LOOP_ASM
                     : [valid] "+s"(valid), [rs] "+s"(rs), [anchor] "+s"(anchor), [K] "+s"(K), [pendq] "+s"(pend_q),
                       [op] "+s"(op), [ED] "+s"(ED), [code] "=&s"(code)
                     : [Dp] "s"(Dp), [h] "v"(h), [wbase] "s"(wbase), [litfloor] "s"(lit_floor), [len] "s"(len),
@@ -566,7 +444,7 @@ __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t*
                       [cp] "v"(cp), [v] "v"(v), [vp] "v"(vp), [lane] "v"(lane)
                     : "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93",
                       "s94", "s95", "s96", "s97", "s98", "s99", "v120", "v121", "v122", "v123", "v124", "v125", "v126",
-                      "v127", "v128", "vcc", "scc", "memory");
+                      "v127", "v128", "v130", "v131", "vcc", "scc", "memory");
                 if (anchor != anchor_in) {
                   rt = 0;
                   elim = kWave;
@@ -574,6 +452,7 @@ __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t*
                 if (code == 0) { why = kNoEvent; break; }
                 if (code == 1) { why = kLeft; break; }
               }
+              skip_block = false;
 #endif
               const uint64_t live_m = valid & (~0ull << rs);
               const uint64_t cm = ED & live_m;

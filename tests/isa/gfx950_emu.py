@@ -1,0 +1,1378 @@
+"""A small gfx950 (CDNA4, wave64) ISA interpreter for the integer kernels of this repository.
+
+TEST INFRASTRUCTURE ONLY.  It executes the assembly text `hipcc -S --cuda-device-only` prints for a kernel
+(including the inline-asm blocks) one wavefront at a time on the CPU, so that the *compiled* HIP kernels can be
+checked bit for bit against the oracle without a GPU, every global / LDS access is bounds-checked, and the
+instructions, taken branches and memory round trips of a path can be counted.  It models what the kernels here
+use: the scalar and vector integer ALU, SDWA / DPP operand forms, LDS, global memory, SMEM loads, EXEC / VCC /
+SCC.  It does not model timing, the hardware's hazards (tests/isa/hazards.py checks the hand-written blocks for
+those), floating point, MFMA, or more than one wavefront per workgroup.
+"""
+import re
+import numpy as np
+
+M32 = 0xFFFFFFFF
+M64 = 0xFFFFFFFFFFFFFFFF
+LANES = np.arange(64, dtype=np.uint64)
+VCC = 106  # vcc lives in the SGPR array at 106/107
+_FLOAT_CONST = {"0.5": 0x3F000000, "1.0": 0x3F800000, "2.0": 0x40000000, "4.0": 0x40800000,
+                "-0.5": 0xBF000000, "-1.0": 0xBF800000, "-2.0": 0xC0000000, "-4.0": 0xC0800000}
+
+
+class EmuError(Exception):
+    pass
+
+
+class MemFault(EmuError):
+    pass
+
+
+def s32(x):
+    x &= M32
+    return x - (1 << 32) if x & 0x80000000 else x
+
+
+def s64(x):
+    x &= M64
+    return x - (1 << 64) if x & (1 << 63) else x
+
+
+class Memory:
+    """Flat 64-bit address space made of named regions; every access is bounds-checked."""
+
+    def __init__(self):
+        self.regions = []
+        self.next_base = 0x7F0000000000
+
+    def map(self, data, name, writable=True, guard=1 << 24):
+        arr = data if isinstance(data, np.ndarray) else np.frombuffer(bytearray(data), dtype=np.uint8)
+        arr = arr.view(np.uint8).reshape(-1)
+        base = self.next_base
+        self.next_base += ((arr.size + guard + 0xFFFF) >> 16) << 16
+        self.regions.append((base, arr, name, writable))
+        return base
+
+    def find(self, addr):
+        for base, arr, name, wr in self.regions:
+            if base <= addr < base + max(arr.size, 1):
+                return base, arr, name, wr
+        raise MemFault("address 0x%x is not mapped" % addr)
+
+    def _locate(self, addrs, active, n, write):
+        idx = np.flatnonzero(active)
+        if idx.size == 0:
+            return None, None
+        base, arr, name, wr = self.find(int(addrs[idx[0]]))
+        if write and not wr:
+            raise MemFault("write to read-only region %s" % name)
+        offs = addrs.astype(np.int64) - base
+        a = offs[idx]
+        if a.min() < 0 or a.max() + n > arr.size:
+            bad = idx[(a < 0) | (a + n > arr.size)][0]
+            raise MemFault("lane %d: %d-byte %s at %s%+d (region size %d)" % (
+                bad, n, "store" if write else "load", name, int(offs[bad]), arr.size))
+        return arr, np.where(active, offs, 0)
+
+    def load(self, addrs, active, n):
+        """-> uint8[64, n] (zeros for inactive lanes)"""
+        arr, offs = self._locate(addrs, active, n, False)
+        out = np.zeros((64, n), dtype=np.uint8)
+        if arr is None:
+            return out
+        got = arr[offs[:, None] + np.arange(n)]
+        out[active] = got[active]
+        return out
+
+    def store(self, addrs, active, data):
+        n = data.shape[1]
+        arr, offs = self._locate(addrs, active, n, True)
+        if arr is None:
+            return
+        for lane in np.flatnonzero(active):  # lane order: the highest lane wins a same-address race
+            o = int(offs[lane])
+            arr[o:o + n] = data[lane]
+
+    def load_scalar(self, addr, n):
+        base, arr, name, wr = self.find(addr)
+        o = addr - base
+        if o + n > arr.size:
+            raise MemFault("scalar load of %d bytes at %s+%d (size %d)" % (n, name, o, arr.size))
+        return bytes(arr[o:o + n])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# operands
+_REG_RE = re.compile(r"^([sva])(\d+)$")
+_RANGE_RE = re.compile(r"^([sva])\[(\d+):(\d+)\]$")
+
+
+def parse_operand(tok):
+    tok = tok.strip()
+    neg = False
+    m = _REG_RE.match(tok)
+    if m:
+        return (m.group(1), int(m.group(2)), 1)
+    m = _RANGE_RE.match(tok)
+    if m:
+        return (m.group(1), int(m.group(2)), int(m.group(3)) - int(m.group(2)) + 1)
+    if tok == "vcc":
+        return ("s", VCC, 2)
+    if tok == "vcc_lo":
+        return ("s", VCC, 1)
+    if tok == "vcc_hi":
+        return ("s", VCC + 1, 1)
+    if tok in ("exec", "exec_lo", "exec_hi", "scc", "m0", "off", "null"):
+        return (tok, 0, 2 if tok == "exec" else 1)
+    if tok in _FLOAT_CONST:
+        return ("lit", _FLOAT_CONST[tok], 1)
+    try:
+        return ("lit", int(tok, 0) & M64, 1)
+    except ValueError:
+        pass
+    m = re.match(r"^(sext)\((.*)\)$", tok)
+    if m:
+        inner = parse_operand(m.group(2))
+        return ("sext", inner, 1)
+    return ("label", tok, 0)
+
+
+class Inst:
+    __slots__ = ("op", "ops", "mods", "text", "line", "fn", "kind", "target")
+
+    def __init__(self, op, ops, mods, text, line):
+        self.op, self.ops, self.mods, self.text, self.line = op, ops, mods, text, line
+        self.fn = None
+        self.kind = None
+        self.target = None
+
+
+_MOD_RE = re.compile(r"\b(offset|dst_sel|dst_unused|src0_sel|src1_sel|row_shr|row_shl|row_ror|wave_shr|wave_shl|wave_ror|"
+                     r"wave_rol|row_mask|bank_mask|bound_ctrl|quad_perm|row_bcast|op_sel|op_sel_hi)\s*:\s*(\[[^\]]*\]|\S+)")
+_FLAG_RE = re.compile(r"\b(glc|slc|sc0|sc1|nt|row_mirror|row_half_mirror|clamp|lds)\b")
+
+
+def parse_program(text, entry=None):
+    """assembly text -> (list of Inst, {label: index}).  With `entry` (a symbol name), only that function."""
+    insts, labels = [], {}
+    active = entry is None
+    for ln, raw in enumerate(text.splitlines(), 1):
+        line = raw.split(";")[0].strip() if not raw.strip().startswith(";;#") else ""
+        if not line:
+            continue
+        if line.endswith(":") and not line.startswith("."):
+            name = line[:-1]
+            if entry is not None:
+                if name == entry:
+                    active = True
+                    labels[name] = len(insts)
+                    continue
+                if active and not name.startswith(".L"):
+                    break
+            if active:
+                labels[name] = len(insts)
+            continue
+        if not active:
+            continue
+        if line.startswith(".L") and line.endswith(":"):
+            labels[line[:-1]] = len(insts)
+            continue
+        if line.startswith("."):
+            if line.startswith(".section") and insts and entry is not None:
+                break
+            continue
+        parts = line.split(None, 1)
+        op = parts[0]
+        rest = parts[1] if len(parts) > 1 else ""
+        mods = {}
+        for m in _MOD_RE.finditer(rest):
+            mods[m.group(1)] = m.group(2)
+        rest = _MOD_RE.sub("", rest)
+        for m in _FLAG_RE.finditer(rest):
+            mods[m.group(1)] = True
+        rest = _FLAG_RE.sub("", rest)
+        if op == "s_waitcnt":
+            ops = []
+        else:
+            # split on commas that are not inside [...]
+            toks, depth, cur = [], 0, ""
+            for ch in rest:
+                if ch == "[":
+                    depth += 1
+                elif ch == "]":
+                    depth -= 1
+                if ch == "," and depth == 0:
+                    toks.append(cur)
+                    cur = ""
+                else:
+                    cur += ch
+            if cur.strip():
+                toks.append(cur)
+            ops = [parse_operand(t) for t in toks if t.strip()]
+        insts.append(Inst(op, ops, mods, line, ln))
+    return insts, labels
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def _ff1(x, bits):
+    if x == 0:
+        return M32  # -1
+    return (x & -x).bit_length() - 1
+
+
+def _flbit(x, bits):  # count leading zeros, -1 for 0
+    if x == 0:
+        return M32
+    return bits - x.bit_length()
+
+
+def _bfe_u32(v, spec):
+    off = spec & 31
+    width = (spec >> 16) & 0x7F
+    if width == 0:
+        return 0
+    return (v >> off) & ((1 << width) - 1) if width < 32 else (v >> off)
+
+
+class Wave:
+    def __init__(self, mem, lds_bytes=65536):
+        self.s = [0] * 128
+        self.v = np.zeros((512, 64), dtype=np.uint32)
+        self.scc = 0
+        self.exec = M64
+        self.m0 = 0
+        self.mem = mem
+        self.lds = np.zeros(lds_bytes, dtype=np.uint8)
+        self._em_cache = {}
+        self.count = {}
+        self.n_inst = 0
+        self.n_taken = 0
+        self.n_salu = self.n_valu = self.n_lds = self.n_vmem = self.n_smem = 0
+        self.clock = 0
+        self.trace = None
+        self.region_counts = None
+
+    # ---- helpers
+    def em(self, mask=None):
+        mask = self.exec if mask is None else mask
+        r = self._em_cache.get(mask)
+        if r is None:
+            r = ((np.uint64(mask) >> LANES) & np.uint64(1)).astype(bool)
+            if len(self._em_cache) > 4096:
+                self._em_cache.clear()
+            self._em_cache[mask] = r
+        return r
+
+    @staticmethod
+    def mask_of(boolarr):
+        return int(np.bitwise_or.reduce(np.where(boolarr, np.uint64(1) << LANES, np.uint64(0))))
+
+    def rs32(self, o):
+        k = o[0]
+        if k == "s":
+            return self.s[o[1]]
+        if k == "lit":
+            return o[1] & M32
+        if k == "exec_lo":
+            return self.exec & M32
+        if k == "exec_hi":
+            return self.exec >> 32
+        if k == "exec":
+            return self.exec & M32
+        if k == "scc":
+            return self.scc
+        if k == "m0":
+            return self.m0
+        raise EmuError("bad scalar source %r" % (o,))
+
+    def rs64(self, o):
+        k = o[0]
+        if k == "s":
+            if o[2] == 1:
+                raise EmuError("64-bit read of a single SGPR %r" % (o,))
+            return self.s[o[1]] | (self.s[o[1] + 1] << 32)
+        if k == "lit":
+            v = o[1]
+            # 32-bit inline constants / literals are sign-extended for integers in 64-bit operands
+            if v > M32:
+                return v & M64
+            return v  # positive literal (hex masks are written in full by the assembler output)
+        if k == "exec":
+            return self.exec
+        raise EmuError("bad 64-bit scalar source %r" % (o,))
+
+    def ws32(self, o, val):
+        k = o[0]
+        val &= M32
+        if k == "s":
+            self.s[o[1]] = val
+        elif k == "exec_lo":
+            self.exec = (self.exec & ~M32 & M64) | val
+        elif k == "exec_hi":
+            self.exec = (self.exec & M32) | (val << 32)
+        elif k == "m0":
+            self.m0 = val
+        elif k == "null":
+            pass
+        else:
+            raise EmuError("bad scalar destination %r" % (o,))
+
+    def ws64(self, o, val):
+        k = o[0]
+        val &= M64
+        if k == "s":
+            self.s[o[1]] = val & M32
+            self.s[o[1] + 1] = val >> 32
+        elif k == "exec":
+            self.exec = val
+        elif k == "null":
+            pass
+        else:
+            raise EmuError("bad 64-bit scalar destination %r" % (o,))
+
+    def rv32(self, o):
+        """vector source -> np.uint32[64]"""
+        k = o[0]
+        if k == "v":
+            return self.v[o[1]]
+        if k == "sext":
+            raise EmuError("sext() outside SDWA")
+        return np.full(64, self.rs32(o), dtype=np.uint32)
+
+    def rv64(self, o):
+        if o[0] == "v":
+            return self.v[o[1]].astype(np.uint64) | (self.v[o[1] + 1].astype(np.uint64) << np.uint64(32))
+        return np.full(64, self.rs64(o) if (o[0] != "lit") else (o[1] if o[1] <= M32 else o[1]), dtype=np.uint64)
+
+    def wv32(self, o, val, mask=None):
+        if o[0] != "v":
+            raise EmuError("bad vector destination %r" % (o,))
+        e = self.em(mask)
+        self.v[o[1]] = np.where(e, val.astype(np.uint32) if isinstance(val, np.ndarray) else np.uint32(val & M32),
+                                self.v[o[1]])
+
+    def wv64(self, o, val):
+        e = self.em()
+        val = val.astype(np.uint64)
+        self.v[o[1]] = np.where(e, (val & np.uint64(M32)).astype(np.uint32), self.v[o[1]])
+        self.v[o[1] + 1] = np.where(e, (val >> np.uint64(32)).astype(np.uint32), self.v[o[1] + 1])
+
+    def wmask(self, o, boolarr):
+        """result of a vector compare: only active lanes can set bits, inactive lanes read as 0"""
+        m = self.mask_of(boolarr & self.em())
+        self.ws64(o, m)
+
+
+def _i32(a):
+    return a.astype(np.int32)
+
+
+def _sdwa_sel(arr, sel, sext=False):
+    if sel is None or sel == "DWORD":
+        return arr
+    if sel.startswith("BYTE_"):
+        r = (arr >> np.uint32(8 * int(sel[5]))) & np.uint32(0xFF)
+        if sext:
+            r = r.astype(np.uint8).astype(np.int8).astype(np.int32).astype(np.uint32)
+        return r
+    if sel.startswith("WORD_"):
+        r = (arr >> np.uint32(16 * int(sel[5]))) & np.uint32(0xFFFF)
+        if sext:
+            r = r.astype(np.uint16).astype(np.int16).astype(np.int32).astype(np.uint32)
+        return r
+    raise EmuError("sdwa sel " + sel)
+
+
+def _sdwa_dst(old, new, sel, unused):
+    if sel is None or sel == "DWORD":
+        return new
+    if sel.startswith("BYTE_"):
+        sh, msk = 8 * int(sel[5]), 0xFF
+    else:
+        sh, msk = 16 * int(sel[5]), 0xFFFF
+    field = (new & np.uint32(msk)) << np.uint32(sh)
+    if unused == "UNUSED_PRESERVE":
+        return (old & np.uint32(~(msk << sh) & M32)) | field
+    if unused == "UNUSED_SEXT":
+        raise EmuError("UNUSED_SEXT not modelled")
+    return field  # UNUSED_PAD
+
+
+def _dpp_src(w, inst, arr, old):
+    """apply the DPP lane permutation of `inst` to arr; returns (values, valid lanes)"""
+    mods = inst.mods
+    lane = np.arange(64)
+    src = lane.copy()
+    valid = np.ones(64, dtype=bool)
+    row = lane & ~15
+    if "row_shr" in mods:
+        n = int(mods["row_shr"])
+        src = lane - n
+        valid = (lane & 15) >= n
+    elif "row_shl" in mods:
+        n = int(mods["row_shl"])
+        src = lane + n
+        valid = (lane & 15) + n < 16
+    elif "row_ror" in mods:
+        n = int(mods["row_ror"])
+        src = row | ((lane - n) & 15)
+    elif "wave_shr" in mods:
+        src = lane - 1
+        valid = lane >= 1
+    elif "wave_shl" in mods:
+        src = lane + 1
+        valid = lane < 63
+    elif "wave_ror" in mods:
+        src = (lane - 1) & 63
+    elif "wave_rol" in mods:
+        src = (lane + 1) & 63
+    elif "row_mirror" in mods:
+        src = row | (15 - (lane & 15))
+    elif "row_half_mirror" in mods:
+        src = (lane & ~7) | (7 - (lane & 7))
+    elif "quad_perm" in mods:
+        q = [int(x) for x in mods["quad_perm"].strip("[]").split(",")]
+        src = (lane & ~3) | np.array(q)[lane & 3]
+    elif "row_bcast" in mods:
+        n = int(mods["row_bcast"])
+        if n == 15:
+            src = (lane & ~15) - 1
+            valid = lane >= 16
+        else:
+            src = (lane & ~31) - 1
+            valid = lane >= 32
+    else:
+        raise EmuError("dpp control not modelled: " + inst.text)
+    srcc = np.clip(src, 0, 63)
+    vals = arr[srcc]
+    # a source lane that is disabled in EXEC is invalid as well
+    valid = valid & w.em()[srcc]
+    rm = int(mods.get("row_mask", "0xf"), 0)
+    bm = int(mods.get("bank_mask", "0xf"), 0)
+    wr = (((rm >> (lane >> 4)) & 1) == 1) & (((bm >> ((lane >> 2) & 3)) & 1) == 1)
+    bound = "bound_ctrl" in mods
+    if bound:
+        vals = np.where(valid, vals, np.uint32(0))
+        ok = wr
+    else:
+        ok = wr & valid
+    return vals, ok
+
+
+# ---- vector ALU tables ------------------------------------------------------------------------------------------
+def _shl(a, n):
+    return (a.astype(np.uint64) << (n & np.uint32(31)).astype(np.uint64)).astype(np.uint32)
+
+
+V2 = {  # name -> f(src0, src1) on uint32 arrays
+    "v_add_u32": lambda a, b: a + b,
+    "v_sub_u32": lambda a, b: a - b,
+    "v_subrev_u32": lambda a, b: b - a,
+    "v_and_b32": lambda a, b: a & b,
+    "v_or_b32": lambda a, b: a | b,
+    "v_xor_b32": lambda a, b: a ^ b,
+    "v_xnor_b32": lambda a, b: ~(a ^ b),
+    "v_lshlrev_b32": lambda a, b: _shl(b, a),
+    "v_lshrrev_b32": lambda a, b: b >> (a & np.uint32(31)),
+    "v_ashrrev_i32": lambda a, b: (_i32(b) >> (a & np.uint32(31)).astype(np.int32)).astype(np.uint32),
+    "v_min_u32": np.minimum,
+    "v_max_u32": np.maximum,
+    "v_min_i32": lambda a, b: np.minimum(_i32(a), _i32(b)).astype(np.uint32),
+    "v_max_i32": lambda a, b: np.maximum(_i32(a), _i32(b)).astype(np.uint32),
+    "v_mul_lo_u32": lambda a, b: (a.astype(np.uint64) * b.astype(np.uint64)).astype(np.uint32),
+    "v_mul_hi_u32": lambda a, b: ((a.astype(np.uint64) * b.astype(np.uint64)) >> np.uint64(32)).astype(np.uint32),
+    "v_mul_u32_u24": lambda a, b: ((a & np.uint32(0xFFFFFF)).astype(np.uint64) * (b & np.uint32(0xFFFFFF)).astype(np.uint64)).astype(np.uint32),
+    "v_lshlrev_b16": lambda a, b: (b << (a & np.uint32(15))) & np.uint32(0xFFFF),
+    "v_lshrrev_b16": lambda a, b: (b & np.uint32(0xFFFF)) >> (a & np.uint32(15)),
+    "v_add_u16": lambda a, b: (a + b) & np.uint32(0xFFFF),
+    "v_sub_u16": lambda a, b: (a - b) & np.uint32(0xFFFF),
+    "v_and_b16": lambda a, b: (a & b) & np.uint32(0xFFFF),
+    "v_or_b16": lambda a, b: (a | b) & np.uint32(0xFFFF),
+    "v_bcnt_u32_b32": lambda a, b: np.array([bin(int(x)).count("1") for x in a], dtype=np.uint32) + b,
+}
+
+
+def _ffbl(a):
+    out = np.full(64, M32, dtype=np.uint32)
+    nz = a != 0
+    low = a & (~a + np.uint32(1))
+    out[nz] = np.log2(low[nz].astype(np.float64)).astype(np.uint32)
+    return out
+
+
+def _ffbh(a):
+    out = np.full(64, M32, dtype=np.uint32)
+    nz = a != 0
+    bl = np.zeros(64, dtype=np.uint32)
+    x = a.astype(np.uint64)
+    bl[nz] = np.floor(np.log2(x[nz].astype(np.float64))).astype(np.uint32)
+    # float64 represents every uint32 exactly, so floor(log2) is exact
+    out[nz] = np.uint32(31) - bl[nz]
+    return out
+
+
+def _bfrev(a):
+    r = np.zeros(64, dtype=np.uint32)
+    x = a.copy()
+    for _ in range(32):
+        r = (r << np.uint32(1)) | (x & np.uint32(1))
+        x = x >> np.uint32(1)
+    return r
+
+
+V1 = {
+    "v_mov_b32": lambda a: a,
+    "v_not_b32": lambda a: ~a,
+    "v_ffbl_b32": _ffbl,
+    "v_ffbh_u32": _ffbh,
+    "v_bfrev_b32": _bfrev,
+    "v_mov_b16": lambda a: a & np.uint32(0xFFFF),
+}
+
+
+def _alignbyte(a, b, c):
+    sh = ((c & np.uint32(3)) * np.uint32(8)).astype(np.uint64)
+    return (((a.astype(np.uint64) << np.uint64(32)) | b.astype(np.uint64)) >> sh).astype(np.uint32)
+
+
+def _alignbit(a, b, c):
+    sh = (c & np.uint32(31)).astype(np.uint64)
+    return (((a.astype(np.uint64) << np.uint64(32)) | b.astype(np.uint64)) >> sh).astype(np.uint32)
+
+
+def _v_bfe_u32(a, b, c):
+    off = (b & np.uint32(31)).astype(np.uint64)
+    width = (c & np.uint32(31)).astype(np.uint64)
+    return ((a.astype(np.uint64) >> off) & ((np.uint64(1) << width) - np.uint64(1))).astype(np.uint32)
+
+
+def _perm(a, b, sel):
+    src = (a.astype(np.uint64) << np.uint64(32)) | b.astype(np.uint64)
+    out = np.zeros(64, dtype=np.uint32)
+    for i in range(4):
+        s = (sel >> np.uint32(8 * i)) & np.uint32(0xFF)
+        byte = np.zeros(64, dtype=np.uint32)
+        lo = s < 8
+        byte[lo] = ((src[lo] >> (s[lo].astype(np.uint64) * np.uint64(8))) & np.uint64(0xFF)).astype(np.uint32)
+        byte[s == 0x0C] = 0
+        byte[s >= 0x0D] = 0xFF
+        for k, bit in ((8, 15), (9, 31), (10, 47), (11, 63)):
+            m = s == k
+            byte[m] = np.where((src[m] >> np.uint64(bit)) & np.uint64(1), 0xFF, 0).astype(np.uint32)
+        out |= byte << np.uint32(8 * i)
+    return out
+
+
+V3 = {
+    "v_lshl_add_u32": lambda a, b, c: _shl(a, b) + c,
+    "v_add_lshl_u32": lambda a, b, c: _shl(a + b, c),
+    "v_lshl_or_b32": lambda a, b, c: _shl(a, b) | c,
+    "v_and_or_b32": lambda a, b, c: (a & b) | c,
+    "v_or3_b32": lambda a, b, c: a | b | c,
+    "v_add3_u32": lambda a, b, c: a + b + c,
+    "v_xad_u32": lambda a, b, c: (a ^ b) + c,
+    "v_bfi_b32": lambda a, b, c: (a & b) | (~a & c),
+    "v_alignbyte_b32": _alignbyte,
+    "v_alignbit_b32": _alignbit,
+    "v_bfe_u32": _v_bfe_u32,
+    "v_perm_b32": _perm,
+    "v_mad_u32_u24": lambda a, b, c: ((a & np.uint32(0xFFFFFF)).astype(np.uint64) * (b & np.uint32(0xFFFFFF)).astype(np.uint64)).astype(np.uint32) + c,
+    "v_med3_i32": lambda a, b, c: np.sort(np.stack([_i32(a), _i32(b), _i32(c)]), axis=0)[1].astype(np.uint32),
+    "v_med3_u32": lambda a, b, c: np.sort(np.stack([a, b, c]), axis=0)[1],
+    "v_min3_u32": lambda a, b, c: np.minimum(np.minimum(a, b), c),
+    "v_max3_u32": lambda a, b, c: np.maximum(np.maximum(a, b), c),
+    "v_min3_i32": lambda a, b, c: np.minimum(np.minimum(_i32(a), _i32(b)), _i32(c)).astype(np.uint32),
+    "v_max3_i32": lambda a, b, c: np.maximum(np.maximum(_i32(a), _i32(b)), _i32(c)).astype(np.uint32),
+    "v_mad_u32_u16": lambda a, b, c: (a & np.uint32(0xFFFF)) * (b & np.uint32(0xFFFF)) + c,
+}
+
+_CMP = {"eq": np.equal, "ne": np.not_equal, "lg": np.not_equal, "gt": np.greater, "ge": np.greater_equal,
+        "lt": np.less, "le": np.less_equal}
+_SCMP = {"eq": lambda a, b: a == b, "lg": lambda a, b: a != b, "gt": lambda a, b: a > b, "ge": lambda a, b: a >= b,
+         "lt": lambda a, b: a < b, "le": lambda a, b: a <= b}
+
+_S2_32 = {
+    "s_and_b32": lambda a, b: a & b, "s_or_b32": lambda a, b: a | b, "s_xor_b32": lambda a, b: a ^ b,
+    "s_andn2_b32": lambda a, b: a & ~b, "s_orn2_b32": lambda a, b: a | (~b & M32),
+    "s_nand_b32": lambda a, b: ~(a & b), "s_nor_b32": lambda a, b: ~(a | b), "s_xnor_b32": lambda a, b: ~(a ^ b),
+    "s_lshl_b32": lambda a, b: a << (b & 31), "s_lshr_b32": lambda a, b: a >> (b & 31),
+    "s_ashr_i32": lambda a, b: s32(a) >> (b & 31),
+}
+_S2_64 = {
+    "s_and_b64": lambda a, b: a & b, "s_or_b64": lambda a, b: a | b, "s_xor_b64": lambda a, b: a ^ b,
+    "s_andn2_b64": lambda a, b: a & ~b, "s_orn2_b64": lambda a, b: a | (~b & M64),
+    "s_nand_b64": lambda a, b: ~(a & b), "s_nor_b64": lambda a, b: ~(a | b), "s_xnor_b64": lambda a, b: ~(a ^ b),
+}
+
+
+def _lit64(o, w):
+    """64-bit scalar source where small negative inline constants are sign-extended"""
+    if o[0] == "lit":
+        v = o[1]
+        if v > M32:  # parsed from a negative number (already masked to 64 bits) or a long hex
+            return v & M64
+        return v
+    return w.rs64(o)
+
+
+class Program:
+    def __init__(self, text, entry=None):
+        self.insts, self.labels = parse_program(text, entry)
+        for i in self.insts:
+            self._bind(i)
+
+    def _bind(self, i):
+        op = i.op
+        base = op
+        for suf in ("_e32", "_e64", "_sdwa", "_dpp"):
+            if base.endswith(suf):
+                base = base[: -len(suf)]
+                break
+        fn = getattr(self, "x_" + base, None)
+        if fn is None:
+            fn = self._generic(i, base)
+        if fn is None:
+            i.fn = None  # raised when executed (unknown opcodes on paths that never run are harmless)
+        else:
+            i.fn = fn
+        if op.startswith("s_cbranch") or op == "s_branch":
+            i.target = i.ops[0][1]
+        c = op[0]
+        if op.startswith("ds_"):
+            i.kind = "lds"
+        elif op.startswith(("global_", "flat_", "buffer_", "scratch_")):
+            i.kind = "vmem"
+        elif op.startswith(("s_load", "s_buffer_load", "s_memtime", "s_memrealtime")):
+            i.kind = "smem"
+        elif c == "v":
+            i.kind = "valu"
+        else:
+            i.kind = "salu"
+
+    # ---- generic families ------------------------------------------------------------------------------------
+    def _generic(self, i, base):
+        if base in _S2_32:
+            f = _S2_32[base]
+
+            def run(w, i, f=f):
+                r = f(w.rs32(i.ops[1]), w.rs32(i.ops[2])) & M32
+                w.ws32(i.ops[0], r)
+                w.scc = 1 if r else 0
+            return run
+        if base in _S2_64:
+            f = _S2_64[base]
+
+            def run(w, i, f=f):
+                r = f(_lit64(i.ops[1], w), _lit64(i.ops[2], w)) & M64
+                w.ws64(i.ops[0], r)
+                w.scc = 1 if r else 0
+            return run
+        m = re.match(r"^s_cmp_(eq|lg|gt|ge|lt|le)_(i32|u32)$", base)
+        if m:
+            f, signed = _SCMP[m.group(1)], m.group(2) == "i32"
+
+            def run(w, i, f=f, signed=signed):
+                a, b = w.rs32(i.ops[0]), w.rs32(i.ops[1])
+                if signed:
+                    a, b = s32(a), s32(b)
+                w.scc = 1 if f(a, b) else 0
+            return run
+        m = re.match(r"^s_cmpk_(eq|lg|gt|ge|lt|le)_(i32|u32)$", base)
+        if m:
+            f, signed = _SCMP[m.group(1)], m.group(2) == "i32"
+
+            def run(w, i, f=f, signed=signed):
+                a, b = w.rs32(i.ops[0]), i.ops[1][1] & 0xFFFF
+                if signed:
+                    a = s32(a)
+                    b = b - 0x10000 if b & 0x8000 else b
+                w.scc = 1 if f(a, b) else 0
+            return run
+        m = re.match(r"^s_cmp_(eq|lg)_u64$", base)
+        if m:
+            f = _SCMP[m.group(1)]
+
+            def run(w, i, f=f):
+                w.scc = 1 if f(_lit64(i.ops[0], w), _lit64(i.ops[1], w)) else 0
+            return run
+        m = re.match(r"^v_cmp_(eq|ne|lg|gt|ge|lt|le)_(u32|i32|u16|i16|u64|i64)$", base)
+        if m:
+            f, ty = _CMP[m.group(1)], m.group(2)
+            e32 = i.op.endswith("_e32") or (len(i.ops) == 3 and i.ops[0] == ("s", VCC, 2) and not i.op.endswith("_e64"))
+
+            def run(w, i, f=f, ty=ty):
+                dst, a, b = i.ops[0], i.ops[1], i.ops[2]
+                if ty in ("u64", "i64"):
+                    x, y = w.rv64(a), w.rv64(b)
+                    if ty == "i64":
+                        x, y = x.astype(np.int64), y.astype(np.int64)
+                else:
+                    x, y = w.rv32(a), w.rv32(b)
+                    if "src0_sel" in i.mods or "src1_sel" in i.mods:
+                        x = _sdwa_sel(x, i.mods.get("src0_sel"))
+                        y = _sdwa_sel(y, i.mods.get("src1_sel"))
+                    if ty == "i32":
+                        x, y = _i32(x), _i32(y)
+                    elif ty == "u16":
+                        x, y = x & np.uint32(0xFFFF), y & np.uint32(0xFFFF)
+                    elif ty == "i16":
+                        x, y = x.astype(np.uint16).astype(np.int16), y.astype(np.uint16).astype(np.int16)
+                w.wmask(dst, f(x, y))
+            return run
+        if base in V2:
+            f = V2[base]
+
+            def run(w, i, f=f):
+                a, b = w.rv32(i.ops[1]), w.rv32(i.ops[2])
+                if i.op.endswith("_sdwa"):
+                    a = _sdwa_sel(a, i.mods.get("src0_sel"))
+                    b = _sdwa_sel(b, i.mods.get("src1_sel"))
+                    r = _sdwa_dst(w.v[i.ops[0][1]], f(a, b), i.mods.get("dst_sel"), i.mods.get("dst_unused"))
+                    w.wv32(i.ops[0], r)
+                elif i.op.endswith("_dpp"):
+                    a, ok = _dpp_src(w, i, a, None)
+                    r = f(a, b)
+                    w.wv32(i.ops[0], np.where(ok, r, w.v[i.ops[0][1]]))
+                else:
+                    w.wv32(i.ops[0], f(a, b))
+            return run
+        if base in V1:
+            f = V1[base]
+
+            def run(w, i, f=f):
+                a = w.rv32(i.ops[1])
+                if i.op.endswith("_sdwa"):
+                    a = _sdwa_sel(a, i.mods.get("src0_sel"))
+                    r = _sdwa_dst(w.v[i.ops[0][1]], f(a), i.mods.get("dst_sel"), i.mods.get("dst_unused"))
+                    w.wv32(i.ops[0], r)
+                elif i.op.endswith("_dpp"):
+                    a, ok = _dpp_src(w, i, a, None)
+                    w.wv32(i.ops[0], np.where(ok, f(a), w.v[i.ops[0][1]]))
+                else:
+                    w.wv32(i.ops[0], f(a))
+            return run
+        if base in V3:
+            f = V3[base]
+
+            def run(w, i, f=f):
+                w.wv32(i.ops[0], f(w.rv32(i.ops[1]), w.rv32(i.ops[2]), w.rv32(i.ops[3])))
+            return run
+        m = re.match(r"^(global|flat)_load_(ubyte|sbyte|ushort|sshort|dword|dwordx2|dwordx3|dwordx4|ubyte_d16|ubyte_d16_hi|short_d16|short_d16_hi)$", base)
+        if m:
+            return self._mk_gload(m.group(2))
+        m = re.match(r"^(global|flat)_store_(byte|short|dword|dwordx2|dwordx3|dwordx4)$", base)
+        if m:
+            return self._mk_gstore(m.group(2))
+        m = re.match(r"^ds_read_(u8|i8|u16|i16|b32|b64|b96|b128)$", base)
+        if m:
+            return self._mk_dsread(m.group(1))
+        m = re.match(r"^ds_write_(b8|b16|b32|b64|b96|b128)$", base)
+        if m:
+            return self._mk_dswrite(m.group(1))
+        m = re.match(r"^s_load_dword(x2|x4|x8|x16)?$", base)
+        if m:
+            n = {None: 1, "x2": 2, "x4": 4, "x8": 8, "x16": 16}[m.group(1)]
+
+            def run(w, i, n=n):
+                off = w.rs32(i.ops[2]) if i.ops[2][0] != "lit" else i.ops[2][1]
+                if "offset" in i.mods:
+                    off += int(i.mods["offset"], 0)
+                raw = w.mem.load_scalar(w.rs64(i.ops[1]) + off, 4 * n)
+                for k in range(n):
+                    w.s[i.ops[0][1] + k] = int.from_bytes(raw[4 * k:4 * k + 4], "little")
+            return run
+        return None
+
+    # ---- addresses
+    @staticmethod
+    def _gaddr(w, i, vaddr_op, saddr_op):
+        off = int(i.mods.get("offset", "0"), 0)
+        if off & 0x1000 and off < 0x2000:  # 13-bit signed, printed as positive by some tools (never by llvm)
+            pass
+        if saddr_op[0] == "off":
+            a = w.rv64(vaddr_op)
+        else:
+            a = np.uint64(w.rs64(saddr_op)) + w.v[vaddr_op[1]].astype(np.uint64)
+        return (a.astype(np.int64) + np.int64(s32(off) if off > 0x7FFFFFFF else off)).astype(np.uint64)
+
+    def _mk_gload(self, ty):
+        n = {"ubyte": 1, "sbyte": 1, "ushort": 2, "sshort": 2, "dword": 4, "dwordx2": 8, "dwordx3": 12, "dwordx4": 16,
+             "ubyte_d16": 1, "ubyte_d16_hi": 1, "short_d16": 2, "short_d16_hi": 2}[ty]
+
+        def run(w, i, n=n, ty=ty):
+            addrs = self._gaddr(w, i, i.ops[1], i.ops[2])
+            e = w.em()
+            raw = w.mem.load(addrs, e, n)
+            d = i.ops[0][1]
+            if n >= 4:
+                words = raw.view("<u4")
+                for k in range(n // 4):
+                    w.v[d + k] = np.where(e, words[:, k], w.v[d + k])
+                return
+            if n == 1:
+                val = raw[:, 0].astype(np.uint32)
+                if ty == "sbyte":
+                    val = raw[:, 0].astype(np.int8).astype(np.int32).astype(np.uint32)
+            else:
+                val = raw.view("<u2")[:, 0].astype(np.uint32)
+                if ty == "sshort":
+                    val = raw.view("<i2")[:, 0].astype(np.int32).astype(np.uint32)
+            if ty.endswith("d16"):
+                val = (w.v[d] & np.uint32(0xFFFF0000)) | val
+            elif ty.endswith("d16_hi"):
+                val = (w.v[d] & np.uint32(0xFFFF)) | (val << np.uint32(16))
+            w.v[d] = np.where(e, val, w.v[d])
+        return run
+
+    def _mk_gstore(self, ty):
+        n = {"byte": 1, "short": 2, "dword": 4, "dwordx2": 8, "dwordx3": 12, "dwordx4": 16}[ty]
+
+        def run(w, i, n=n):
+            addrs = self._gaddr(w, i, i.ops[0], i.ops[2])
+            e = w.em()
+            d = i.ops[1][1]
+            if n >= 4:
+                data = np.stack([w.v[d + k] for k in range(n // 4)], axis=1).astype("<u4").view(np.uint8).reshape(64, n)
+            else:
+                data = w.v[d].astype("<u4").view(np.uint8).reshape(64, 4)[:, :n]
+            w.mem.store(addrs, e, np.ascontiguousarray(data))
+        return run
+
+    def _mk_dsread(self, ty):
+        n = {"u8": 1, "i8": 1, "u16": 2, "i16": 2, "b32": 4, "b64": 8, "b96": 12, "b128": 16}[ty]
+
+        def run(w, i, n=n, ty=ty):
+            e = w.em()
+            addr = w.v[i.ops[1][1]].astype(np.int64) + int(i.mods.get("offset", "0"), 0)
+            a = np.where(e, addr, 0)
+            if e.any() and (a[e].min() < 0 or a[e].max() + n > w.lds_limit):
+                raise MemFault("LDS read out of bounds: %s" % i.text)
+            raw = w.lds[a[:, None] + np.arange(n)]
+            d = i.ops[0][1]
+            if n >= 4:
+                words = np.ascontiguousarray(raw).view("<u4")
+                for k in range(n // 4):
+                    w.v[d + k] = np.where(e, words[:, k], w.v[d + k])
+                return
+            if n == 1:
+                val = raw[:, 0].astype(np.uint32) if ty == "u8" else raw[:, 0].astype(np.int8).astype(np.int32).astype(np.uint32)
+            else:
+                c = np.ascontiguousarray(raw)
+                val = c.view("<u2")[:, 0].astype(np.uint32) if ty == "u16" else c.view("<i2")[:, 0].astype(np.int32).astype(np.uint32)
+            w.v[d] = np.where(e, val, w.v[d])
+        return run
+
+    def _mk_dswrite(self, ty):
+        n = {"b8": 1, "b16": 2, "b32": 4, "b64": 8, "b96": 12, "b128": 16}[ty]
+
+        def run(w, i, n=n):
+            e = w.em()
+            addr = w.v[i.ops[0][1]].astype(np.int64) + int(i.mods.get("offset", "0"), 0)
+            d = i.ops[1][1]
+            if n >= 4:
+                data = np.stack([w.v[d + k] for k in range(n // 4)], axis=1).astype("<u4").view(np.uint8).reshape(64, n)
+            else:
+                data = w.v[d].astype("<u4").view(np.uint8).reshape(64, 4)[:, :n]
+            lanes = np.flatnonzero(e)
+            if w.lds_order is not None:
+                lanes = lanes[w.lds_order(len(lanes))]
+            for lane in lanes:
+                a = int(addr[lane])
+                if a < 0 or a + n > w.lds_limit:
+                    raise MemFault("LDS write out of bounds (lane %d, addr %d): %s" % (lane, a, i.text))
+                w.lds[a:a + n] = data[lane]
+        return run
+
+    # ---- scalar singles ----------------------------------------------------------------------------------------
+    def x_s_mov_b32(self, w, i):
+        w.ws32(i.ops[0], w.rs32(i.ops[1]))
+
+    def x_s_movk_i32(self, w, i):
+        v = i.ops[1][1] & 0xFFFF
+        w.ws32(i.ops[0], v - 0x10000 if v & 0x8000 else v)
+
+    def x_s_mov_b64(self, w, i):
+        w.ws64(i.ops[0], _lit64(i.ops[1], w))
+
+    def x_s_cmov_b32(self, w, i):
+        if w.scc:
+            w.ws32(i.ops[0], w.rs32(i.ops[1]))
+
+    def x_s_cmov_b64(self, w, i):
+        if w.scc:
+            w.ws64(i.ops[0], _lit64(i.ops[1], w))
+
+    def x_s_not_b32(self, w, i):
+        r = ~w.rs32(i.ops[1]) & M32
+        w.ws32(i.ops[0], r)
+        w.scc = 1 if r else 0
+
+    def x_s_not_b64(self, w, i):
+        r = ~_lit64(i.ops[1], w) & M64
+        w.ws64(i.ops[0], r)
+        w.scc = 1 if r else 0
+
+    def x_s_add_i32(self, w, i):
+        a, b = s32(w.rs32(i.ops[1])), s32(w.rs32(i.ops[2]))
+        r = a + b
+        w.scc = 1 if (r > 0x7FFFFFFF or r < -0x80000000) else 0
+        w.ws32(i.ops[0], r)
+
+    def x_s_sub_i32(self, w, i):
+        a, b = s32(w.rs32(i.ops[1])), s32(w.rs32(i.ops[2]))
+        r = a - b
+        w.scc = 1 if (r > 0x7FFFFFFF or r < -0x80000000) else 0
+        w.ws32(i.ops[0], r)
+
+    def x_s_add_u32(self, w, i):
+        r = w.rs32(i.ops[1]) + w.rs32(i.ops[2])
+        w.scc = 1 if r > M32 else 0
+        w.ws32(i.ops[0], r)
+
+    def x_s_addc_u32(self, w, i):
+        r = w.rs32(i.ops[1]) + w.rs32(i.ops[2]) + w.scc
+        w.scc = 1 if r > M32 else 0
+        w.ws32(i.ops[0], r)
+
+    def x_s_sub_u32(self, w, i):
+        a, b = w.rs32(i.ops[1]), w.rs32(i.ops[2])
+        w.scc = 1 if b > a else 0
+        w.ws32(i.ops[0], a - b)
+
+    def x_s_subb_u32(self, w, i):
+        a, b = w.rs32(i.ops[1]), w.rs32(i.ops[2]) + w.scc
+        w.ws32(i.ops[0], a - b)
+        w.scc = 1 if b > a else 0
+
+    def x_s_addk_i32(self, w, i):
+        k = i.ops[1][1] & 0xFFFF
+        k = k - 0x10000 if k & 0x8000 else k
+        r = s32(w.rs32(i.ops[0])) + k
+        w.scc = 1 if (r > 0x7FFFFFFF or r < -0x80000000) else 0
+        w.ws32(i.ops[0], r)
+
+    def x_s_mulk_i32(self, w, i):
+        k = i.ops[1][1] & 0xFFFF
+        k = k - 0x10000 if k & 0x8000 else k
+        w.ws32(i.ops[0], s32(w.rs32(i.ops[0])) * k)
+
+    def x_s_mul_i32(self, w, i):
+        w.ws32(i.ops[0], s32(w.rs32(i.ops[1])) * s32(w.rs32(i.ops[2])))
+
+    def x_s_mul_hi_u32(self, w, i):
+        w.ws32(i.ops[0], (w.rs32(i.ops[1]) * w.rs32(i.ops[2])) >> 32)
+
+    def x_s_mul_hi_i32(self, w, i):
+        w.ws32(i.ops[0], (s32(w.rs32(i.ops[1])) * s32(w.rs32(i.ops[2]))) >> 32)
+
+    def x_s_min_i32(self, w, i):
+        a, b = s32(w.rs32(i.ops[1])), s32(w.rs32(i.ops[2]))
+        w.scc = 1 if a < b else 0
+        w.ws32(i.ops[0], min(a, b))
+
+    def x_s_max_i32(self, w, i):
+        a, b = s32(w.rs32(i.ops[1])), s32(w.rs32(i.ops[2]))
+        w.scc = 1 if a > b else 0
+        w.ws32(i.ops[0], max(a, b))
+
+    def x_s_min_u32(self, w, i):
+        a, b = w.rs32(i.ops[1]), w.rs32(i.ops[2])
+        w.scc = 1 if a < b else 0
+        w.ws32(i.ops[0], min(a, b))
+
+    def x_s_max_u32(self, w, i):
+        a, b = w.rs32(i.ops[1]), w.rs32(i.ops[2])
+        w.scc = 1 if a > b else 0
+        w.ws32(i.ops[0], max(a, b))
+
+    def x_s_cselect_b32(self, w, i):
+        w.ws32(i.ops[0], w.rs32(i.ops[1]) if w.scc else w.rs32(i.ops[2]))
+
+    def x_s_cselect_b64(self, w, i):
+        w.ws64(i.ops[0], _lit64(i.ops[1], w) if w.scc else _lit64(i.ops[2], w))
+
+    def x_s_lshl_b64(self, w, i):
+        r = (_lit64(i.ops[1], w) << (w.rs32(i.ops[2]) & 63)) & M64
+        w.ws64(i.ops[0], r)
+        w.scc = 1 if r else 0
+
+    def x_s_lshr_b64(self, w, i):
+        r = _lit64(i.ops[1], w) >> (w.rs32(i.ops[2]) & 63)
+        w.ws64(i.ops[0], r)
+        w.scc = 1 if r else 0
+
+    def x_s_ashr_i64(self, w, i):
+        r = s64(_lit64(i.ops[1], w)) >> (w.rs32(i.ops[2]) & 63)
+        w.ws64(i.ops[0], r)
+        w.scc = 1 if (r & M64) else 0
+
+    def x_s_bfe_u32(self, w, i):
+        r = _bfe_u32(w.rs32(i.ops[1]), w.rs32(i.ops[2]))
+        w.ws32(i.ops[0], r)
+        w.scc = 1 if r else 0
+
+    def x_s_bfe_i32(self, w, i):
+        spec = w.rs32(i.ops[2])
+        width = (spec >> 16) & 0x7F
+        r = _bfe_u32(w.rs32(i.ops[1]), spec)
+        if width and width < 32 and (r >> (width - 1)) & 1:
+            r -= 1 << width
+        w.ws32(i.ops[0], r)
+        w.scc = 1 if (r & M32) else 0
+
+    def x_s_bfe_u64(self, w, i):
+        spec = w.rs32(i.ops[2])
+        off, width = spec & 63, (spec >> 16) & 0x7F
+        r = (_lit64(i.ops[1], w) >> off) & ((1 << width) - 1) if width else 0
+        w.ws64(i.ops[0], r)
+        w.scc = 1 if r else 0
+
+    def x_s_ff1_i32_b32(self, w, i):
+        w.ws32(i.ops[0], _ff1(w.rs32(i.ops[1]), 32))
+
+    def x_s_ff1_i32_b64(self, w, i):
+        w.ws32(i.ops[0], _ff1(_lit64(i.ops[1], w), 64))
+
+    def x_s_flbit_i32_b32(self, w, i):
+        w.ws32(i.ops[0], _flbit(w.rs32(i.ops[1]), 32))
+
+    def x_s_flbit_i32_b64(self, w, i):
+        w.ws32(i.ops[0], _flbit(_lit64(i.ops[1], w), 64))
+
+    def x_s_bcnt1_i32_b32(self, w, i):
+        r = bin(w.rs32(i.ops[1])).count("1")
+        w.ws32(i.ops[0], r)
+        w.scc = 1 if r else 0
+
+    def x_s_bcnt1_i32_b64(self, w, i):
+        r = bin(_lit64(i.ops[1], w)).count("1")
+        w.ws32(i.ops[0], r)
+        w.scc = 1 if r else 0
+
+    def x_s_brev_b32(self, w, i):
+        w.ws32(i.ops[0], int("{:032b}".format(w.rs32(i.ops[1]))[::-1], 2))
+
+    def x_s_bitset1_b32(self, w, i):
+        w.ws32(i.ops[0], w.rs32(i.ops[0]) | (1 << (w.rs32(i.ops[1]) & 31)))
+
+    def x_s_bitset0_b32(self, w, i):
+        w.ws32(i.ops[0], w.rs32(i.ops[0]) & ~(1 << (w.rs32(i.ops[1]) & 31)))
+
+    def x_s_bitset1_b64(self, w, i):
+        w.ws64(i.ops[0], w.rs64(i.ops[0]) | (1 << (w.rs32(i.ops[1]) & 63)))
+
+    def x_s_bitset0_b64(self, w, i):
+        w.ws64(i.ops[0], w.rs64(i.ops[0]) & ~(1 << (w.rs32(i.ops[1]) & 63)))
+
+    def x_s_bitcmp0_b32(self, w, i):
+        w.scc = 1 if ((w.rs32(i.ops[0]) >> (w.rs32(i.ops[1]) & 31)) & 1) == 0 else 0
+
+    def x_s_bitcmp1_b32(self, w, i):
+        w.scc = (w.rs32(i.ops[0]) >> (w.rs32(i.ops[1]) & 31)) & 1
+
+    def x_s_bitcmp0_b64(self, w, i):
+        w.scc = 1 if ((_lit64(i.ops[0], w) >> (w.rs32(i.ops[1]) & 63)) & 1) == 0 else 0
+
+    def x_s_bitcmp1_b64(self, w, i):
+        w.scc = (_lit64(i.ops[0], w) >> (w.rs32(i.ops[1]) & 63)) & 1
+
+    def x_s_sext_i32_i16(self, w, i):
+        v = w.rs32(i.ops[1]) & 0xFFFF
+        w.ws32(i.ops[0], v - 0x10000 if v & 0x8000 else v)
+
+    def x_s_sext_i32_i8(self, w, i):
+        v = w.rs32(i.ops[1]) & 0xFF
+        w.ws32(i.ops[0], v - 0x100 if v & 0x80 else v)
+
+    def x_s_abs_i32(self, w, i):
+        r = abs(s32(w.rs32(i.ops[1])))
+        w.ws32(i.ops[0], r)
+        w.scc = 1 if (r & M32) else 0
+
+    def x_s_lshl1_add_u32(self, w, i):
+        self._lshl_add(w, i, 1)
+
+    def x_s_lshl2_add_u32(self, w, i):
+        self._lshl_add(w, i, 2)
+
+    def x_s_lshl3_add_u32(self, w, i):
+        self._lshl_add(w, i, 3)
+
+    def x_s_lshl4_add_u32(self, w, i):
+        self._lshl_add(w, i, 4)
+
+    def _lshl_add(self, w, i, n):
+        r = (w.rs32(i.ops[1]) << n) + w.rs32(i.ops[2])
+        w.scc = 1 if r > M32 else 0
+        w.ws32(i.ops[0], r)
+
+    def _saveexec(self, w, i, f):
+        old = w.exec
+        src = _lit64(i.ops[1], w)  # (the destination may be the source register)
+        w.ws64(i.ops[0], old)
+        w.exec = f(src, old) & M64
+        w.scc = 1 if w.exec else 0
+
+    def x_s_and_saveexec_b64(self, w, i):
+        self._saveexec(w, i, lambda s, e: s & e)
+
+    def x_s_or_saveexec_b64(self, w, i):
+        self._saveexec(w, i, lambda s, e: s | e)
+
+    def x_s_xor_saveexec_b64(self, w, i):
+        self._saveexec(w, i, lambda s, e: s ^ e)
+
+    def x_s_andn2_saveexec_b64(self, w, i):
+        self._saveexec(w, i, lambda s, e: s & ~e)
+
+    def x_s_andn1_saveexec_b64(self, w, i):
+        self._saveexec(w, i, lambda s, e: ~s & e)
+
+    def x_s_orn2_saveexec_b64(self, w, i):
+        self._saveexec(w, i, lambda s, e: s | ~e)
+
+    def x_s_nop(self, w, i):
+        pass
+
+    x_s_waitcnt = x_s_nop
+    x_s_barrier = x_s_nop
+    x_s_sleep = x_s_nop
+    x_s_setprio = x_s_nop
+    x_s_waitcnt_vscnt = x_s_nop
+    x_s_waitcnt_depctr = x_s_nop
+    x_s_inst_prefetch = x_s_nop
+    x_s_dcache_wb = x_s_nop
+    x_buffer_wbl2 = x_s_nop
+    x_buffer_inv = x_s_nop
+    x_s_setreg_imm32_b32 = x_s_nop
+    x_v_nop = x_s_nop
+
+    def x_s_memtime(self, w, i):
+        w.ws64(i.ops[0], w.clock)
+
+    x_s_memrealtime = x_s_memtime
+
+    # ---- vector singles ----------------------------------------------------------------------------------------
+    def x_v_mov_b64(self, w, i):
+        w.wv64(i.ops[0], w.rv64(i.ops[1]))
+
+    def x_v_cndmask_b32(self, w, i):
+        a, b = w.rv32(i.ops[1]), w.rv32(i.ops[2])
+        if i.op.endswith("_sdwa"):
+            a = _sdwa_sel(a, i.mods.get("src0_sel"))
+            b = _sdwa_sel(b, i.mods.get("src1_sel"))
+        sel = w.em(_lit64(i.ops[3], w))
+        r = np.where(sel, b, a)
+        if i.op.endswith("_sdwa"):
+            r = _sdwa_dst(w.v[i.ops[0][1]], r, i.mods.get("dst_sel"), i.mods.get("dst_unused"))
+        w.wv32(i.ops[0], r)
+
+    def x_v_readlane_b32(self, w, i):
+        lane = w.rs32(i.ops[2]) & 63
+        w.ws32(i.ops[0], int(w.v[i.ops[1][1]][lane]))
+
+    def x_v_readfirstlane_b32(self, w, i):
+        lane = _ff1(w.exec, 64) if w.exec else 0
+        w.ws32(i.ops[0], int(w.rv32(i.ops[1])[lane]))
+
+    def x_v_writelane_b32(self, w, i):
+        lane = w.rs32(i.ops[2]) & 63
+        w.v[i.ops[0][1]][lane] = w.rs32(i.ops[1])
+
+    def _carry_op(self, w, i, f):
+        # dst, carry_out, src0, src1 [, carry_in]
+        a, b = w.rv32(i.ops[2]).astype(np.int64), w.rv32(i.ops[3]).astype(np.int64)
+        cin = w.em(_lit64(i.ops[4], w)).astype(np.int64) if len(i.ops) > 4 else 0
+        r = f(a, b, cin)
+        w.wmask(i.ops[1], (r > M32) | (r < 0))
+        w.wv32(i.ops[0], (r & M32).astype(np.uint32))
+
+    def x_v_add_co_u32(self, w, i):
+        self._carry_op(w, i, lambda a, b, c: a + b)
+
+    def x_v_sub_co_u32(self, w, i):
+        self._carry_op(w, i, lambda a, b, c: a - b)
+
+    def x_v_subrev_co_u32(self, w, i):
+        self._carry_op(w, i, lambda a, b, c: b - a)
+
+    def x_v_addc_co_u32(self, w, i):
+        self._carry_op(w, i, lambda a, b, c: a + b + c)
+
+    def x_v_subb_co_u32(self, w, i):
+        self._carry_op(w, i, lambda a, b, c: a - b - c)
+
+    def x_v_subbrev_co_u32(self, w, i):
+        self._carry_op(w, i, lambda a, b, c: b - a - c)
+
+    def x_v_lshl_add_u64(self, w, i):
+        a, sh, c = w.rv64(i.ops[1]), w.rv32(i.ops[2]), w.rv64(i.ops[3])
+        w.wv64(i.ops[0], (a << (sh & np.uint32(7)).astype(np.uint64)) + c)
+
+    def x_v_lshlrev_b64(self, w, i):
+        sh, a = w.rv32(i.ops[1]), w.rv64(i.ops[2])
+        w.wv64(i.ops[0], a << (sh & np.uint32(63)).astype(np.uint64))
+
+    def x_v_lshrrev_b64(self, w, i):
+        sh, a = w.rv32(i.ops[1]), w.rv64(i.ops[2])
+        w.wv64(i.ops[0], a >> (sh & np.uint32(63)).astype(np.uint64))
+
+    def x_v_ashrrev_i64(self, w, i):
+        sh, a = w.rv32(i.ops[1]), w.rv64(i.ops[2])
+        w.wv64(i.ops[0], (a.astype(np.int64) >> (sh & np.uint32(63)).astype(np.int64)).astype(np.uint64))
+
+    def x_v_mad_u64_u32(self, w, i):
+        # vdst[2], sdst(carry), src0, src1, src2(64)
+        a, b, c = w.rv32(i.ops[2]).astype(np.uint64), w.rv32(i.ops[3]).astype(np.uint64), w.rv64(i.ops[4])
+        w.wv64(i.ops[0], a * b + c)
+
+    def x_v_mad_i64_i32(self, w, i):
+        a, b, c = _i32(w.rv32(i.ops[2])).astype(np.int64), _i32(w.rv32(i.ops[3])).astype(np.int64), w.rv64(i.ops[4]).astype(np.int64)
+        w.wv64(i.ops[0], (a * b + c).astype(np.uint64))
+
+    def x_v_mbcnt_lo_u32_b32(self, w, i):
+        m = w.rs32(i.ops[1]) if i.ops[1][0] != "v" else None
+        mask = np.array([(((m if m is not None else int(w.v[i.ops[1][1]][l])) & ((1 << min(l, 32)) - 1))) for l in range(64)], dtype=np.uint64)
+        cnt = np.array([bin(int(x)).count("1") for x in mask], dtype=np.uint32)
+        w.wv32(i.ops[0], cnt + w.rv32(i.ops[2]))
+
+    def x_v_mbcnt_hi_u32_b32(self, w, i):
+        m = w.rs32(i.ops[1]) if i.ops[1][0] != "v" else None
+        cnt = np.zeros(64, dtype=np.uint32)
+        for l in range(32, 64):
+            mm = m if m is not None else int(w.v[i.ops[1][1]][l])
+            cnt[l] = bin(mm & ((1 << (l - 32)) - 1)).count("1")
+        w.wv32(i.ops[0], cnt + w.rv32(i.ops[2]))
+
+    def x_ds_bpermute_b32(self, w, i):
+        addr = (w.v[i.ops[1][1]] >> np.uint32(2)) & np.uint32(63)
+        src = w.v[i.ops[2][1]]
+        e = w.em()
+        vals = np.where(e[addr], src[addr], np.uint32(0))
+        w.wv32(i.ops[0], vals)
+
+    def x_ds_permute_b32(self, w, i):
+        addr = (w.v[i.ops[1][1]] >> np.uint32(2)) & np.uint32(63)
+        src = w.v[i.ops[2][1]]
+        out = np.zeros(64, dtype=np.uint32)
+        for lane in np.flatnonzero(w.em()):
+            out[addr[lane]] = src[lane]
+        w.wv32(i.ops[0], out)
+
+    def x_ds_swizzle_b32(self, w, i):
+        raise EmuError("ds_swizzle not modelled")
+
+    def x_v_accvgpr_write_b32(self, w, i):
+        w.v[256 + i.ops[0][1]] = np.where(w.em(), w.rv32(i.ops[1]), w.v[256 + i.ops[0][1]])
+
+    def x_v_accvgpr_read_b32(self, w, i):
+        w.wv32(i.ops[0], w.v[256 + i.ops[1][1]])
+
+
+class Cost:
+    """crude per-wave cycle model (tools/probe/issue_probe.hip): used for A/B estimates only"""
+    ISSUE = 5
+    TAKEN = 25
+    NOT_TAKEN = 11
+    LDS = 128
+    VMEM = 700
+    SMEM = 200
+
+
+def run_wave(prog, w, entry=None, max_inst=50_000_000, profile=None):
+    """Runs until s_endpgm.  profile: optional dict label -> [instructions, taken branches] keyed by the most
+    recent label passed (a cheap path profiler)."""
+    insts, labels = prog.insts, prog.labels
+    pc = labels[entry] if entry else 0
+    n = 0
+    cur = "<entry>"
+    idx_label = {}
+    for name, k in labels.items():
+        idx_label.setdefault(k, name)
+    while True:
+        if profile is not None and pc in idx_label:
+            cur = idx_label[pc]
+        i = insts[pc]
+        op = i.op
+        n += 1
+        if n > max_inst:
+            raise EmuError("instruction limit reached at line %d: %s" % (i.line, i.text))
+        if profile is not None:
+            p = profile.setdefault(cur, [0, 0])
+            p[0] += 1
+        k = i.kind
+        if k == "salu":
+            w.n_salu += 1
+        elif k == "valu":
+            w.n_valu += 1
+        elif k == "lds":
+            w.n_lds += 1
+        elif k == "vmem":
+            w.n_vmem += 1
+        else:
+            w.n_smem += 1
+        w.clock += Cost.ISSUE
+        if i.target is not None:
+            if op == "s_branch":
+                take = True
+            elif op == "s_cbranch_scc0":
+                take = w.scc == 0
+            elif op == "s_cbranch_scc1":
+                take = w.scc == 1
+            elif op == "s_cbranch_vccz":
+                take = (w.s[VCC] | w.s[VCC + 1]) == 0
+            elif op == "s_cbranch_vccnz":
+                take = (w.s[VCC] | w.s[VCC + 1]) != 0
+            elif op == "s_cbranch_execz":
+                take = w.exec == 0
+            elif op == "s_cbranch_execnz":
+                take = w.exec != 0
+            else:
+                raise EmuError("branch " + op)
+            if take:
+                w.n_taken += 1
+                w.clock += Cost.TAKEN - Cost.ISSUE
+                if profile is not None:
+                    p[1] += 1
+                pc = labels[i.target]
+            else:
+                w.clock += Cost.NOT_TAKEN - Cost.ISSUE
+                pc += 1
+            continue
+        if op == "s_endpgm":
+            break
+        if i.fn is None:
+            raise EmuError("opcode not modelled (line %d): %s" % (i.line, i.text))
+        try:
+            i.fn(w, i)
+        except EmuError as e:
+            raise type(e)("%s   [line %d: %s]" % (e, i.line, i.text)) from None
+        pc += 1
+    w.n_inst += n
+    return n
+
+
+def new_wave(mem, lds_bytes, lds_order=None):
+    w = Wave(mem, max(lds_bytes, 4))
+    w.lds_limit = lds_bytes
+    w.lds_order = lds_order
+    return w
+
+
+def launch(prog, entry, mem, kernarg, grid_x, lds_bytes, user_sgprs=2, block_x=64, profile=None, lds_order=None,
+           on_wave=None):
+    """One 64-thread workgroup per block id (the kernels here use single-wave workgroups).  ABI as hipcc emits it
+    for these kernels: s[0:1] = kernarg segment, s2 = workgroup id x, v0 = thread id x."""
+    if block_x != 64:
+        raise EmuError("only single-wave workgroups are modelled")
+    kbase = mem.map(np.frombuffer(bytearray(kernarg), dtype=np.uint8), "kernarg", writable=False)
+    stats = []
+    for bx in (grid_x if not isinstance(grid_x, int) else range(grid_x)):
+        w = new_wave(mem, lds_bytes, lds_order)
+        w.s[0], w.s[1] = kbase & M32, kbase >> 32
+        w.s[user_sgprs] = bx
+        w.v[0] = np.arange(64, dtype=np.uint32)
+        run_wave(prog, w, entry, profile=profile)
+        stats.append(w)
+        if on_wave:
+            on_wave(bx, w)
+    return stats

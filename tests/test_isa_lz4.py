@@ -1,0 +1,72 @@
+"""The COMPILED LZ4 compress kernel (hipcc -S output, hand-written gfx950 blocks included) executed on the CPU by
+tests/isa/gfx950_emu.py and compared bit for bit with the oracle; plus the wait-state check of the asm blocks.
+Needs hipcc (cross-compiles without a GPU) but no device."""
+import os
+import shutil
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "isa"))
+import corpus  # noqa: E402
+
+pytestmark = pytest.mark.skipif(shutil.which(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")) is None,
+                                reason="hipcc not available")
+
+
+def _check(chunks, oracle, **kw):
+    import lz4_kernel as lk
+
+    res = lk.compress_chunks(chunks, **kw)
+    for c, (payload, hdr, w) in zip(chunks, res):
+        ref = oracle.lz4_compress_block(c)
+        if payload is None:
+            assert len(ref) >= len(c), "kernel stored RAW a chunk the reference compresses"
+        else:
+            assert np.array_equal(payload, ref), "compiled kernel differs from LZ4_compress_default (len %d)" % len(c)
+        assert hdr[:8] == b"LZ4Block"
+    return res
+
+
+@pytest.mark.parametrize("windows", [True, False])
+def test_compiled_kernel_matches_oracle(oracle, windows):
+    rng = np.random.default_rng(21)
+    chunks = [corpus.chunk_corpus(k, n, rng) for k, n in
+              [(7, 32768), (6, 9000), (3, 32768), (2, 4000), (5, 6000), (1, 3000), (0, 700), (4, 2500), (7, 13), (7, 12),
+               (7, 1), (7, 300)]]
+    # the last chunk ends the source allocation: any read past it faults in the interpreter
+    _check(chunks, oracle, windows=windows)
+
+
+def test_lds_race_winner_is_irrelevant(oracle):
+    """same-address LDS stores of one instruction: any lane may win (tests/model proves it; here on the real code)"""
+    rng = np.random.default_rng(22)
+    order = np.random.default_rng(5)
+    chunks = [corpus.chunk_corpus(k, 12000, rng) for k in (7, 2, 3)]
+    _check(chunks, oracle, lds_order=lambda n: order.permutation(n))
+
+
+def test_window_block_runs_most_windows(oracle):
+    """the hand-written window block must actually be the path taken (not a silent fallback to the C++ path)"""
+    import lz4_kernel as lk
+
+    rng = np.random.default_rng(23)
+    chunk = corpus.chunk_corpus(7, 32768, rng)
+    prof = {}
+    lk.compress_chunks([chunk], profile=prof)
+    in_block = sum(v[0] for k, v in prof.items() if k.startswith(".Lw_"))
+    total = sum(v[0] for v in prof.values())
+    assert in_block > 0.6 * total, (in_block, total)
+
+
+def test_asm_blocks_keep_their_wait_states():
+    import hazards
+    import lz4_kernel as lk
+
+    text = lk.compile_asm()
+    entry = lk.find_kernel(text, "lz4_compress_l2_kernelILb1E")
+    asm_viol, cc_viol, cc_nops, _ = hazards.check_kernel(text, entry)
+    assert not asm_viol, asm_viol
+    assert not cc_viol, ("rule set stricter than the compiler", cc_viol[:3])
