@@ -25,7 +25,6 @@
 // straight to the chunk's slot in HBM; compressed output never exceeds the chunk length (anything longer is
 // stored RAW by the frame rule compressedLength >= originalLength), so a slot is 32 B + 32 KiB.
 #include "s3s_internal.h"
-#include "lz4_run_loop.inc"
 #include "lz4_window_engine.inc"
 
 #ifdef S3S_LZ4_TIMING
@@ -299,7 +298,7 @@ __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t*
                            [Dp] "=&s"(Dp), [rs] "=&s"(rs), [pendq] "=&s"(pend_q), [p0l] "+v"(p0l), [p0h] "+v"(p0h),
                            [p1l] "+v"(p1l), [p1h] "+v"(p1h), [p2l] "+v"(p2l), [p2h] "+v"(p2h), [vp] "+v"(vp)
                          : [len] "s"(len), [inp] "s"(in.base), [outp] "s"(out)
-                         : "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86",
+                         : "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86",
                            "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99",
                            "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133",
                            "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145",
@@ -414,7 +413,6 @@ __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t*
           const int e0 = rs0 + 66 - t0;  // the first run may continue an older one (t0 <= 48 => e0 >= rs0 + 18)
           int elim = (had_match || e0 >= kWave) ? kWave : e0;
           if (!resumed) valid = e0 < kWave ? ((1ull << e0) - 1ull) : ~0ull;  // consecutive probes of the current run
-          bool skip_block = resumed;  // the block above has just refused this event
           const int lit_floor = vp_ok ? wbase - 64 : wbase;  // literals in registers start here
           // Cost model measured on gfx950 (tools/probe/issue_probe.hip): a plain SALU / VALU instruction costs a
           // wave ~5 cycles, a taken branch ~25, a not-taken one ~11, a VALU -> SGPR -> SALU crossing ~+20.  So the
@@ -425,35 +423,6 @@ __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t*
           {
             DBG_T(tl0);
             for (;;) {
-#ifndef S3S_NO_ASM_RUN_LOOP  // (-DS3S_NO_ASM_RUN_LOOP: the compiled loop alone, for A/B runs)
-              if ((ED & valid & (~0ull << rs)) == 0ull) { why = kNoEvent; break; }  // nothing to do: skip the block
-              if (!skip_block)
-              // Hand-scheduled gfx950 code for the COMMON event (candidate matches, no earlier same-candidate lane,
-              // extension of at most one cooperative round, short-form sequence): the same arithmetic as the C++
-              // body below in ~95 (no extension) / ~130 (with it) instructions instead of the ~135 / ~190 hipcc emits
-              // (it turns the multi-exit loop into a state machine with exit codes and 64-bit boolean masks).  Any
-              // other event leaves the block untouched (code 2) and is handled by the C++ body, once.
-              {
-                int code;
-                const int anchor_in = anchor;
-                asm volatile(S3S_RUN_LOOP_ASM
-                    : [valid] "+s"(valid), [rs] "+s"(rs), [anchor] "+s"(anchor), [K] "+s"(K), [pendq] "+s"(pend_q),
-                      [op] "+s"(op), [ED] "+s"(ED), [code] "=&s"(code)
-                    : [Dp] "s"(Dp), [h] "v"(h), [wbase] "s"(wbase), [litfloor] "s"(lit_floor), [len] "s"(len),
-                      [mlimit] "s"(matchlimit), [last4] "s"(last4), [inp] "s"(in.base), [outp] "s"(out), [info] "v"(info),
-                      [cp] "v"(cp), [v] "v"(v), [vp] "v"(vp), [lane] "v"(lane)
-                    : "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93",
-                      "s94", "s95", "s96", "s97", "s98", "s99", "v120", "v121", "v122", "v123", "v124", "v125", "v126",
-                      "v127", "v128", "v130", "v131", "vcc", "scc", "memory");
-                if (anchor != anchor_in) {
-                  rt = 0;
-                  elim = kWave;
-                }
-                if (code == 0) { why = kNoEvent; break; }
-                if (code == 1) { why = kLeft; break; }
-              }
-              skip_block = false;
-#endif
               const uint64_t live_m = valid & (~0ull << rs);
               const uint64_t cm = ED & live_m;
               if (cm == 0ull) { why = kNoEvent; break; }
@@ -765,7 +734,11 @@ __global__ __launch_bounds__(kWave) void lz4_compress_l2_kernel(
     const uint8_t* __restrict__ src, const Item* __restrict__ items, int32_t n_items,
     const uint32_t* __restrict__ item_check, uint8_t* __restrict__ slots,
     uint32_t* __restrict__ item_size) {
+#ifdef S3S_ABL_LDS_PAD  // occupancy experiment: fewer wavefronts per CU (timing only)
+  __shared__ __attribute__((aligned(16))) uint16_t table[8192 + S3S_ABL_LDS_PAD / 2];
+#else
   __shared__ __attribute__((aligned(16))) uint16_t table[8192];
+#endif
   const int it = blockIdx.x;
   if (it >= n_items) return;
   const Item item = items[it];
@@ -777,7 +750,7 @@ __global__ __launch_bounds__(kWave) void lz4_compress_l2_kernel(
   }
   {
     uint4* tz = reinterpret_cast<uint4*>(table);
-    for (int i = lane; i < (int)(sizeof(table) / 16); i += kWave) tz[i] = make_uint4(0, 0, 0, 0);
+    for (int i = lane; i < 16384 / 16; i += kWave) tz[i] = make_uint4(0, 0, 0, 0);
   }
   __syncthreads();
   uint8_t* slot = slots + (size_t)item.chunk * kSlotBytes;

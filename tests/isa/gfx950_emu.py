@@ -250,6 +250,11 @@ class Wave:
         self.clock = 0
         self.trace = None
         self.region_counts = None
+        # outstanding memory operations, oldest first: lists of pending destination VGPR numbers ([] for stores)
+        self.q_vm = []
+        self.q_lgkm = []
+        self.pending = {}  # VGPR -> text of the load that has not been waited for
+        self.n_wait_events = 0
 
     # ---- helpers
     def em(self, mask=None):
@@ -1268,6 +1273,49 @@ class Program:
         w.wv32(i.ops[0], w.v[256 + i.ops[1][1]])
 
 
+_WAIT_RE = re.compile(r"(vmcnt|lgkmcnt|expcnt)\((\d+)\)")
+
+
+def _regs_of(o):
+    return range(o[1], o[1] + o[2]) if o[0] == "v" else ()
+
+
+def scoreboard(w, i):
+    """Models the wait counters: a VGPR written by a load is unusable until an s_waitcnt covers the load (LDS
+    operations and vector loads return in order; with stores in flight only vmcnt(0) is safe on gfx9)."""
+    op = i.op
+    if op == "s_waitcnt":
+        for name, n in _WAIT_RE.findall(i.text):
+            n = int(n)
+            q = w.q_vm if name == "vmcnt" else w.q_lgkm if name == "lgkmcnt" else None
+            if q is None:
+                continue
+            if name == "vmcnt" and n > 0 and len(q) > n and any(not d for d in q) and any(d for d in q):
+                w.n_mixed_vmcnt = getattr(w, "n_mixed_vmcnt", 0) + 1
+            while len(q) > n:
+                for r in q.pop(0):
+                    w.pending.pop(r, None)
+        return
+    if w.pending and i.kind != "salu":
+        for o in i.ops:
+            for r in _regs_of(o):
+                if r in w.pending:
+                    raise EmuError("v%d is used before the wait for `%s`" % (r, w.pending[r]))
+    if i.kind == "lds":
+        dest = list(_regs_of(i.ops[0])) if op.startswith("ds_read") or "permute" in op else []
+        if "permute" not in op:
+            w.q_lgkm.append(dest)
+            for r in dest:
+                w.pending[r] = i.text
+    elif i.kind == "vmem":
+        dest = list(_regs_of(i.ops[0])) if "_load_" in op else []
+        w.q_vm.append(dest)
+        for r in dest:
+            w.pending[r] = i.text
+    elif i.kind == "smem" and op.startswith("s_load"):
+        w.q_lgkm.append([])
+
+
 class Cost:
     """crude per-wave cycle model (tools/probe/issue_probe.hip): used for A/B estimates only"""
     ISSUE = 5
@@ -1278,7 +1326,7 @@ class Cost:
     SMEM = 200
 
 
-def run_wave(prog, w, entry=None, max_inst=50_000_000, profile=None):
+def run_wave(prog, w, entry=None, max_inst=50_000_000, profile=None, hooks=None):
     """Runs until s_endpgm.  profile: optional dict label -> [instructions, taken branches] keyed by the most
     recent label passed (a cheap path profiler)."""
     insts, labels = prog.insts, prog.labels
@@ -1288,9 +1336,12 @@ def run_wave(prog, w, entry=None, max_inst=50_000_000, profile=None):
     idx_label = {}
     for name, k in labels.items():
         idx_label.setdefault(k, name)
+    hook_at = {labels[k]: f for k, f in (hooks or {}).items() if k in labels}
     while True:
         if profile is not None and pc in idx_label:
             cur = idx_label[pc]
+        if hook_at and pc in hook_at:
+            hook_at[pc](w)
         i = insts[pc]
         op = i.op
         n += 1
@@ -1343,6 +1394,7 @@ def run_wave(prog, w, entry=None, max_inst=50_000_000, profile=None):
         if i.fn is None:
             raise EmuError("opcode not modelled (line %d): %s" % (i.line, i.text))
         try:
+            scoreboard(w, i)
             i.fn(w, i)
         except EmuError as e:
             raise type(e)("%s   [line %d: %s]" % (e, i.line, i.text)) from None
@@ -1359,7 +1411,7 @@ def new_wave(mem, lds_bytes, lds_order=None):
 
 
 def launch(prog, entry, mem, kernarg, grid_x, lds_bytes, user_sgprs=2, block_x=64, profile=None, lds_order=None,
-           on_wave=None):
+           on_wave=None, hooks=None):
     """One 64-thread workgroup per block id (the kernels here use single-wave workgroups).  ABI as hipcc emits it
     for these kernels: s[0:1] = kernarg segment, s2 = workgroup id x, v0 = thread id x."""
     if block_x != 64:
@@ -1371,7 +1423,7 @@ def launch(prog, entry, mem, kernarg, grid_x, lds_bytes, user_sgprs=2, block_x=6
         w.s[0], w.s[1] = kbase & M32, kbase >> 32
         w.s[user_sgprs] = bx
         w.v[0] = np.arange(64, dtype=np.uint32)
-        run_wave(prog, w, entry, profile=profile)
+        run_wave(prog, w, entry, profile=profile, hooks=hooks)
         stats.append(w)
         if on_wave:
             on_wave(bx, w)

@@ -65,7 +65,7 @@ def program(windows=True, flags=()):
     return _PROGS[key]
 
 
-def compress_chunks(chunks, windows=True, flags=(), profile=None, lds_order=None, tail_guard=0):
+def compress_chunks(chunks, windows=True, flags=(), profile=None, lds_order=None, tail_guard=0, hooks=None):
     """chunks: list of uint8 arrays (<= 32768 bytes each).  The source buffer ends exactly at the last chunk's
     last byte (+ tail_guard), so any read past a chunk that ends the allocation faults."""
     prog, entry = program(windows, flags)
@@ -86,7 +86,7 @@ def compress_chunks(chunks, windows=True, flags=(), profile=None, lds_order=None
     a_slots = mem.map(slots, "slots")
     a_sizes = mem.map(sizes, "item_size")
     kernarg = struct.pack("<QQiiQQQ", a_src, a_items, n, 0, a_check, a_slots, a_sizes)
-    waves = emu.launch(prog, entry, mem, kernarg, n, 16384, profile=profile, lds_order=lds_order)
+    waves = emu.launch(prog, entry, mem, kernarg, n, 16384, profile=profile, lds_order=lds_order, hooks=hooks)
     out = []
     for k in range(n):
         sz = int(sizes[k])
