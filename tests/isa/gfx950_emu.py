@@ -1297,7 +1297,10 @@ def scoreboard(w, i):
                     w.pending.pop(r, None)
         return
     if w.pending and i.kind != "salu":
-        for o in i.ops:
+        is_load = (i.kind == "vmem" and "_load_" in op) or (i.kind == "lds" and op.startswith("ds_read"))
+        for k, o in enumerate(i.ops):
+            if k == 0 and is_load:
+                continue  # a later load may target a pending destination: loads return in order
             for r in _regs_of(o):
                 if r in w.pending:
                     raise EmuError("v%d is used before the wait for `%s`" % (r, w.pending[r]))
