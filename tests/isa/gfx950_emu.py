@@ -129,6 +129,10 @@ def parse_operand(tok):
         return ("lit", int(tok, 0) & M64, 1)
     except ValueError:
         pass
+    m = re.match(r"^([A-Za-z_.$][\w.$]*)@rel32@(lo|hi)(\+\d+)?$", tok)
+    if m:
+        # s_getpc_b64 + `sym@rel32@lo+4` / `sym@rel32@hi+12` is the address of sym itself; other addends shift it
+        return ("sym_" + m.group(2), (m.group(1), int(m.group(3) or "+0")), 1)
     m = re.match(r"^(sext)\((.*)\)$", tok)
     if m:
         inner = parse_operand(m.group(2))
@@ -147,7 +151,7 @@ class Inst:
 
 
 _MOD_RE = re.compile(r"\b(offset|dst_sel|dst_unused|src0_sel|src1_sel|row_shr|row_shl|row_ror|wave_shr|wave_shl|wave_ror|"
-                     r"wave_rol|row_mask|bank_mask|bound_ctrl|quad_perm|row_bcast|op_sel|op_sel_hi)\s*:\s*(\[[^\]]*\]|\S+)")
+                     r"wave_rol|row_mask|bank_mask|bound_ctrl|quad_perm|row_bcast|op_sel|op_sel_hi|bitop3)\s*:\s*(\[[^\]]*\]|\S+)")
 _FLAG_RE = re.compile(r"\b(glc|slc|sc0|sc1|nt|row_mirror|row_half_mirror|clamp|lds)\b")
 
 
@@ -287,6 +291,10 @@ class Wave:
             return self.scc
         if k == "m0":
             return self.m0
+        if k == "sym_lo":
+            return (self.symbols[o[1][0]] + o[1][1] - 4) & M32
+        if k == "sym_hi":  # (the carry of the low add comes through s_addc_u32)
+            return ((self.symbols[o[1][0]] + o[1][1] - 12) >> 32) & M32
         raise EmuError("bad scalar source %r" % (o,))
 
     def rs64(self, o):
@@ -1151,6 +1159,9 @@ class Program:
     x_s_setreg_imm32_b32 = x_s_nop
     x_v_nop = x_s_nop
 
+    def x_s_getpc_b64(self, w, i):
+        w.ws64(i.ops[0], 0)  # symbol@rel32 operands resolve to absolute addresses here
+
     def x_s_memtime(self, w, i):
         w.ws64(i.ops[0], w.clock)
 
@@ -1265,6 +1276,16 @@ class Program:
 
     def x_ds_swizzle_b32(self, w, i):
         raise EmuError("ds_swizzle not modelled")
+
+    def x_v_bitop3_b32(self, w, i):
+        # result bit = table[(a << 2) | (b << 1) | c]   (a, b, c = the bits of src0, src1, src2)
+        tt = int(i.mods["bitop3"], 0)
+        a, b, c = w.rv32(i.ops[1]), w.rv32(i.ops[2]), w.rv32(i.ops[3])
+        r = np.zeros(64, dtype=np.uint32)
+        for k in range(8):
+            if (tt >> k) & 1:
+                r |= (a if k & 4 else ~a) & (b if k & 2 else ~b) & (c if k & 1 else ~c)
+        w.wv32(i.ops[0], r)
 
     def x_v_accvgpr_write_b32(self, w, i):
         w.v[256 + i.ops[0][1]] = np.where(w.em(), w.rv32(i.ops[1]), w.v[256 + i.ops[0][1]])
@@ -1406,23 +1427,62 @@ def run_wave(prog, w, entry=None, max_inst=50_000_000, profile=None, hooks=None)
     return n
 
 
+def parse_objects(text):
+    """data objects of the assembly (`name:` followed by .long / .short / .byte / .quad / .zero) -> {name: bytes}"""
+    out, cur, buf = {}, None, None
+    fmt = {".long": 4, ".int": 4, ".short": 2, ".byte": 1, ".quad": 8}
+    for raw in text.splitlines():
+        line = raw.split(";")[0].strip()
+        if not line:
+            continue
+        if line.endswith(":") and not line.startswith(".L"):
+            if cur is not None and buf:
+                out[cur] = bytes(buf)
+            cur, buf = line[:-1], bytearray()
+            continue
+        if cur is None:
+            continue
+        parts = line.split(None, 1)
+        if parts[0] in fmt and len(parts) > 1:
+            try:
+                for v in parts[1].split(","):
+                    buf += (int(v.strip(), 0) & ((1 << (8 * fmt[parts[0]])) - 1)).to_bytes(fmt[parts[0]], "little")
+            except ValueError:
+                cur, buf = None, None
+        elif parts[0] == ".zero" and len(parts) > 1:
+            buf += bytes(int(parts[1].split(",")[0], 0))
+        elif parts[0] in (".size", ".p2align", ".type", ".globl", ".section"):
+            continue
+        else:
+            if buf:
+                out[cur] = bytes(buf)
+            cur, buf = None, None
+    if cur is not None and buf:
+        out[cur] = bytes(buf)
+    return out
+
+
 def new_wave(mem, lds_bytes, lds_order=None):
     w = Wave(mem, max(lds_bytes, 4))
+    w.symbols = {}
     w.lds_limit = lds_bytes
     w.lds_order = lds_order
     return w
 
 
 def launch(prog, entry, mem, kernarg, grid_x, lds_bytes, user_sgprs=2, block_x=64, profile=None, lds_order=None,
-           on_wave=None, hooks=None):
+           on_wave=None, hooks=None, objects=None):
     """One 64-thread workgroup per block id (the kernels here use single-wave workgroups).  ABI as hipcc emits it
     for these kernels: s[0:1] = kernarg segment, s2 = workgroup id x, v0 = thread id x."""
     if block_x != 64:
         raise EmuError("only single-wave workgroups are modelled")
     kbase = mem.map(np.frombuffer(bytearray(kernarg), dtype=np.uint8), "kernarg", writable=False)
+    symbols = {name: mem.map(np.frombuffer(bytearray(data), dtype=np.uint8), name, writable=False)
+               for name, data in (objects or {}).items()}
     stats = []
     for bx in (grid_x if not isinstance(grid_x, int) else range(grid_x)):
         w = new_wave(mem, lds_bytes, lds_order)
+        w.symbols = symbols
         w.s[0], w.s[1] = kbase & M32, kbase >> 32
         w.s[user_sgprs] = bx
         w.v[0] = np.arange(64, dtype=np.uint32)

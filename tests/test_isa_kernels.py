@@ -1,4 +1,4 @@
-"""The COMPILED LZ4 compress kernel (hipcc -S output, hand-written gfx950 blocks included) executed on the CPU by
+"""The COMPILED compress kernels (hipcc -S output, hand-written gfx950 blocks included) executed on the CPU by
 tests/isa/gfx950_emu.py and compared bit for bit with the oracle; plus the wait-state check of the asm blocks.
 Needs hipcc (cross-compiles without a GPU) but no device."""
 import os
@@ -70,3 +70,17 @@ def test_asm_blocks_keep_their_wait_states():
     asm_viol, cc_viol, cc_nops, _ = hazards.check_kernel(text, entry)
     assert not asm_viol, asm_viol
     assert not cc_viol, ("rule set stricter than the compiler", cc_viol[:3])
+
+
+@pytest.mark.parametrize("windows", [True, False])
+def test_compiled_snappy_kernel_matches_oracle(oracle, windows):
+    """same for the Snappy compressor (its probe schedule lives in a device global: exercises symbol addressing)"""
+    import snappy_kernel as sk
+
+    rng = np.random.default_rng(31)
+    chunks = [corpus.chunk_corpus(k, n, rng) for k, n in
+              [(6, 9000), (7, 12000), (2, 3000), (3, 5000), (5, 2000), (0, 600), (6, 520), (7, 15), (7, 14), (7, 1)]]
+    for c, (slot, sz, w) in zip(chunks, sk.compress_chunks(chunks, windows=windows)):
+        ref = bytes(oracle.snappy_compress_block(c))
+        assert sz - 4 == len(ref) and bytes(slot[32:32 + sz - 4]) == ref, "compiled Snappy kernel differs (len %d)" % len(c)
+        assert int.from_bytes(bytes(slot[28:32]), "big") == len(ref)
