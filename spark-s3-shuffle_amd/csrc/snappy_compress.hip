@@ -34,6 +34,7 @@
 // what the sequential code inserts (probes, and ip-1 after every copy); the highest kept lane of
 // every hash commits with one store at the end of the window.
 #include "s3s_internal.h"
+#include "snappy_window_engine.inc"
 
 namespace s3s {
 namespace {
@@ -218,18 +219,66 @@ __device__ int snappy_compress_wave(const uint8_t* in, lds_u16* table, int len, 
       if constexpr (kWin) {
         // position of probe u0 (closed form of sn_Q for u0 <= 60)
         const int q0 = u0 <= 33 ? u0 : (u0 <= 49 ? 2 * u0 - 33 : 3 * u0 - 82);
-        const int wbase = (rbase + q0) & ~63;
+        int wbase = (rbase + q0) & ~63;
         if (u0 <= 60 && wbase + 63 - rbase <= 98 && wbase <= fast_limit) {
-          // ================= window preparation (vector work, lane = position) ====================
+          // window state: set by the preparation below, or by the hand-written block when it hands over in mid-window
+          uint32_t v, h, cp, info;
+          uint64_t Dp, ED, K, runmask;
+          int rt, pend_q;
+          int cap_extra = 64;  // "at least" value of a record's length field
+          bool resumed = false;
+#ifndef S3S_NO_WINDOW_ENGINE
+          if ((uint32_t)reinterpret_cast<uintptr_t>(table) == 0u) {  // (the block addresses the table at LDS offset 0)
+            // Whole windows in one hand-written gfx950 block (snappy_window_engine.inc): it returns at a window boundary
+            // (code 0), when a copy reaches ip_limit (3), or at the first event it does not handle (2: the loop resumes).
+            int code, pk_e = -1000;
+            const int rbase_in = rbase, u0_in = u0;
+            uint32_t vcur, vnext;
+            rbase = __builtin_amdgcn_readfirstlane(rbase);  // (uniform already; hipcc cannot always prove it)
+            u0 = __builtin_amdgcn_readfirstlane(u0);
+            next_emit = __builtin_amdgcn_readfirstlane(next_emit);
+            op = __builtin_amdgcn_readfirstlane(op);
+            kp = __builtin_amdgcn_readfirstlane(kp);
+            asm volatile(S3S_SNAPPY_ENGINE_ASM
+                         : [code] "=&s"(code), [h] "=&v"(h), [cp] "=&v"(cp), [info] "=&v"(info), [vcur] "=&v"(vcur),
+                           [vnext] "=&v"(vnext), [rbase] "+s"(rbase), [u0] "+s"(u0), [ne] "+s"(next_emit), [op] "+s"(op),
+                           [pk] "+s"(pk_e), [kp] "+s"(kp), [K] "=&s"(K), [ED] "=&s"(ED), [Dp] "=&s"(Dp), [rm] "=&s"(runmask),
+                           [pendq] "=&s"(pend_q), [rt] "=&s"(rt), [vp] "+v"(vp)
+                         : [len] "s"(len), [inp] "s"(in), [outp] "s"(out), [shift] "s"(__builtin_amdgcn_readfirstlane(shift))
+                         : "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77",
+                           "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91",
+                           "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "v120", "v121", "v122", "v123", "v124",
+                           "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136",
+                           "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148",
+                           "v149", "v150", "v151", "v152", "v153", "vcc", "scc", "memory");
+            if (pk_e >= 0) {  // the block ran: its stream registers replace the cached dwords
+              vn = vnext;
+              kn = pk_e + 64;
+            }
+            if (code == 3) {
+              finished = true;
+              break;
+            }
+            if (code == 0 && (rbase != rbase_in || u0 != u0_in)) continue;  // re-dispatch at the next window
+            if (code == 2) {
+              resumed = true;
+              cap_extra = 12;
+              wbase = pk_e;
+              v = vcur;
+              if (kp != wbase - 64) vp = sn_rd32(in, wbase >= 64 ? wbase - 64 + lane : wbase + lane);
+            }
+          }
+#endif
           const int p = wbase + lane;
-          const uint32_t v = (kn == wbase) ? vn : sn_rd32(in, p);
+          if (!resumed) {
+          v = (kn == wbase) ? vn : sn_rd32(in, p);
           if (kp != wbase - 64) vp = sn_rd32(in, wbase >= 64 ? p - 64 : p);
           vn = sn_rd32(in, p + 64);
           kn = wbase + 64;
-          const uint32_t h = (v * 0x1e35a7bdu) >> shift;
+          h = (v * 0x1e35a7bdu) >> shift;
           const int rs0 = rbase + q0 - wbase;
           const bool live = lane >= rs0;
-          const uint32_t cp = T[h];
+          cp = T[h];
           // 68 bytes at the position and at its table candidate, one round trip
           const uint4 b0 = sn_ld16(in, (int)cp), b1 = sn_ld16(in, (int)cp + 16);
           const uint4 b2 = sn_ld16(in, (int)cp + 32), b3 = sn_ld16(in, (int)cp + 48);
@@ -251,7 +300,7 @@ __device__ int snappy_compress_wave(const uint8_t* in, lds_u16* table, int len, 
           // runs entering the window probe a fixed pattern of the distance to their base
           const int dd = p - rbase;
           const bool isprobe = live && (dd <= 33 || (dd <= 65 ? (dd & 1) != 0 : (dd >= 68 && (dd + 1) % 3 == 0)));
-          uint64_t runmask = __ballot(isprobe);
+          runmask = __ballot(isprobe);
           // equal bytes at p / cp: 0..68
           const int f0 = sn_first_diff16(make_uint4(a0.x ^ b0.x, a0.y ^ b0.y, a0.z ^ b0.z, a0.w ^ b0.w));
           const int f1 = sn_first_diff16(make_uint4(a1.x ^ b1.x, a1.y ^ b1.y, a1.z ^ b1.z, a1.w ^ b1.w));
@@ -267,15 +316,17 @@ __device__ int snappy_compress_wave(const uint8_t* in, lds_u16* table, int len, 
           const bool em = live && fl >= 4;
           // per-lane record: [15:0] table candidate, [22:16] equal bytes beyond the first four (64 =
           // at least), [29] candidate matches, [31] member of a duplicate-hash group
-          const uint32_t info = cp | ((uint32_t)(em ? fl - 4 : 0) << 16) | (em ? 0x20000000u : 0u) | (grp ? 0x80000000u : 0u);
+          info = cp | ((uint32_t)(em ? fl - 4 : 0) << 16) | (em ? 0x20000000u : 0u) | (grp ? 0x80000000u : 0u);
           asm volatile("" : "+v"(vn));  // landed: keep later uses from draining the in-order vmcnt queue
           const uint64_t Ecp = __ballot(em);
-          const uint64_t Dp = __ballot(grp);
-          uint64_t ED = Ecp | Dp;
+          Dp = __ballot(grp);
+          ED = Ecp | Dp;
           // ================= runs (scalar work) =====================================================
+          K = 0;  // lanes the sequential code inserts: probes, and ip-1 after every copy
+          rt = u0;
+          pend_q = -1;
+          }
           const uint64_t PM = 0xAAAAAAAA00000000ull | ((1ull << 34) - 1ull);  // d: 0..33, 35, 37, .., 63
-          uint64_t K = 0;  // lanes the sequential code inserts: probes, and ip-1 after every copy
-          int rt = u0, pend_q = -1;
           // ---- straight-line steps: up to six "plain" copies (the run's first event has its true candidate in the
           // table with an exact length, one literal tag + one copy element, literals in the registers of this or the
           // previous window, not the end of the fragment) without the generic loop's control flow: one branch
@@ -283,7 +334,7 @@ __device__ int snappy_compress_wave(const uint8_t* in, lds_u16* table, int len, 
           // from whatever state the steps left (lz4_compress.hip does the same).
           bool left_window = false;
 #pragma unroll
-          for (int step = 0; step < 6; step++) {
+          for (int step = 0; step < (resumed ? 0 : 6); step++) {
             const uint64_t cm = ED & runmask;
             if (cm == 0ull) break;
             const int m = __builtin_ctzll(cm);
@@ -345,7 +396,7 @@ __device__ int snappy_compress_wave(const uint8_t* in, lds_u16* table, int len, 
             const int ip0 = wbase + m;
             int cand = (int)(inf & 0xffffu);
             int extra = (int)((inf >> 16) & 0x7fu);
-            bool capped = extra >= 64;
+            bool capped = extra >= cap_extra;
             if (__builtin_expect((int)inf < 0, 0)) {
               // ---- another live lane has the same hash: the candidate may be inside the window ----
               bool is_match = (inf & 0x20000000u) != 0u;

@@ -208,17 +208,19 @@ def check_kernel(text, entry):
 if __name__ == "__main__":
     import lz4_kernel as lk
 
-    text = lk.compile_asm()
-    entry = lk.find_kernel(text, "lz4_compress_l2_kernelILb1E")
-    asm_viol, cc_viol, cc_nops, prog = check_kernel(text, entry)
-    print("violations inside asm blocks:", len(asm_viol))
-    for v in asm_viol:
-        print("  line %d: %s  ->  line %d: %s   (%s: %d < %d)" % v)
-    print("violations in compiler code (rule too strict?):", len(cc_viol))
-    for v in cc_viol[:20]:
-        print("  line %d: %s  ->  line %d: %s   (%s: %d < %d)" % v)
-    print("compiler s_nops no rule explains (rule missing?):", len(cc_nops))
-    for i in cc_nops[:40]:
-        k = prog.insts.index(i)
-        ctx = " | ".join(x.text for x in prog.insts[max(0, k - 2):k + 3])
-        print("  line %d: %s" % (i.line, ctx))
+    for src, needle in (("lz4_compress.hip", "lz4_compress_l2_kernelILb1E"), ("snappy_compress.hip", "snappy_compress_kernelILb1E")):
+        text = lk.compile_asm(src)
+        entry = lk.find_kernel(text, needle)
+        asm_viol, cc_viol, cc_nops, prog = check_kernel(text, entry)
+        print("==", src)
+        print("violations inside asm blocks:", len(asm_viol))
+        for v in asm_viol:
+            print("  line %d: %s  ->  line %d: %s   (%s: %d < %d)" % v)
+        print("violations in compiler code (rule too strict?):", len(cc_viol))
+        for v in cc_viol[:20]:
+            print("  line %d: %s  ->  line %d: %s   (%s: %d < %d)" % v)
+        print("compiler s_nops no rule explains (rule missing?):", len(cc_nops))
+        for i in cc_nops[:40]:
+            k = prog.insts.index(i)
+            ctx = " | ".join(x.text for x in prog.insts[max(0, k - 2):k + 3])
+            print("  line %d: %s" % (i.line, ctx))
