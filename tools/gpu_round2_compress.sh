@@ -1,6 +1,6 @@
 #!/bin/bash
-# Compress-side measurement set after the hand-written window block (round 2, r02g): bench lines of the LZ4 map side,
-# compress block-size points, rocprofv3 kernel trace + separate PMC passes of the headline command.
+# Map-side measurement set after the hand-written window blocks (round 2, r02g..r02i): bench lines of the LZ4 and Snappy map
+# side, compress block-size points, rocprofv3 kernel trace + separate PMC passes of the headline and the Snappy command.
 tag=${1:-r02g}
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -13,6 +13,7 @@ $B --no-cpu-baseline --workload tpcds-wide-100g-200p-lz4 > $O/bench_tpcds_lz4.js
 $B --no-cpu-baseline --workload terasort-100g-2000p-lz4-crc32 > $O/bench_2000p.json 2>> $O/bench.err
 $B --no-cpu-baseline --task-threads 1 > $O/bench_1thread.json 2>> $O/bench.err
 $B --no-cpu-baseline --lz4-variant 1 > $O/bench_lz4_variant1.json 2>> $O/bench.err
+$B --workload tpcds-wide-100g-200p-snappy --verify > $O/bench_snappy.json 2>> $O/bench.err
 : > $O/sweep_compress.jsonl
 for spec in "8 32 8" "32 16 4" "128 8 2" "512 2 2" "1024 2 2"; do set -- $spec
   timeout 300 python bench.py --no-cpu-baseline --workload skew-1part-lz4 --map-mib $1 --maps-per-gpu $2 --task-threads $3 --steps 5 --warmup 2 2>/dev/null >> $O/sweep_compress.jsonl
@@ -26,6 +27,15 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE -d $P/pmc_write -o p -- $CMD > $P/pmc_wri
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $P/pmc_sq1 -o p -- $CMD > $P/pmc_sq1.log 2>&1
 cd $R
 python tools/summarize_prof.py $P --md > $P/summary.md 2>&1
+P2=$O/prof_snappy_compress; mkdir -p $P2
+CMD2="python $R/bench.py --no-cpu-baseline --maps-per-gpu 4 --steps 3 --warmup 1 --workload tpcds-wide-100g-200p-snappy"
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d $P2/trace -o t -- $CMD2 > $P2/trace.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE -d $P2/pmc_fetch -o p -- $CMD2 > $P2/pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE -d $P2/pmc_write -o p -- $CMD2 > $P2/pmc_write.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $P2/pmc_sq1 -o p -- $CMD2 > $P2/pmc_sq1.log 2>&1
+cd $R
+python tools/summarize_prof.py $P2 --md > $P2/summary.md 2>&1
 for f in $O/bench*.json; do python - "$f" <<'PY'
 import json, sys
 try:
