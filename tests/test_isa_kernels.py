@@ -84,3 +84,26 @@ def test_compiled_snappy_kernel_matches_oracle(oracle, windows):
         ref = bytes(oracle.snappy_compress_block(c))
         assert sz - 4 == len(ref) and bytes(slot[32:32 + sz - 4]) == ref, "compiled Snappy kernel differs (len %d)" % len(c)
         assert int.from_bytes(bytes(slot[28:32]), "big") == len(ref)
+
+
+def test_snappy_window_block_runs_most_windows(oracle):
+    import snappy_kernel as sk
+
+    rng = np.random.default_rng(33)
+    chunk = corpus.chunk_corpus(7, 32768, rng)
+    prof = {}
+    (slot, sz, w), = sk.compress_chunks([chunk], profile=prof)
+    assert bytes(slot[32:32 + sz - 4]) == bytes(oracle.snappy_compress_block(chunk))
+    in_block = sum(v[0] for k, v in prof.items() if k.startswith(".Ls_"))
+    assert in_block > 0.6 * sum(v[0] for v in prof.values())
+
+
+def test_snappy_asm_block_keeps_its_wait_states():
+    import hazards
+    import lz4_kernel as lk
+
+    text = lk.compile_asm("snappy_compress.hip")
+    entry = lk.find_kernel(text, "snappy_compress_kernelILb1E")
+    asm_viol, cc_viol, _, _ = hazards.check_kernel(text, entry)
+    assert not asm_viol, asm_viol
+    assert not cc_viol, ("rule set stricter than the compiler", cc_viol[:3])
