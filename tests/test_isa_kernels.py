@@ -30,6 +30,18 @@ def _check(chunks, oracle, **kw):
     return res
 
 
+def test_compiled_window_paths_without_the_blocks(oracle):
+    """the compiled C++ window paths (what the blocks fall back to in mid-window) on their own"""
+    import lz4_kernel as lk
+    import snappy_kernel as sk
+
+    rng = np.random.default_rng(24)
+    chunks = [corpus.chunk_corpus(k, n, rng) for k, n in [(7, 9000), (6, 5000), (2, 2500), (3, 4000), (1, 1500)]]
+    _check(chunks, oracle, flags=("-DS3S_NO_WINDOW_ENGINE",))
+    for c, (slot, sz, w) in zip(chunks, sk.compress_chunks(chunks, flags=("-DS3S_NO_WINDOW_ENGINE",))):
+        assert bytes(slot[32:32 + sz - 4]) == bytes(oracle.snappy_compress_block(c))
+
+
 @pytest.mark.parametrize("windows", [True, False])
 def test_compiled_kernel_matches_oracle(oracle, windows):
     rng = np.random.default_rng(21)
