@@ -322,8 +322,15 @@ def main():
             comp_bytes[i] = total
         torch.cuda.synchronize()
 
-    def run_step(record: bool):
+    def run_steps(n_steps: int, record: bool):
+        """n_steps passes over all map tasks of this rank.  Every task thread runs its own tasks n_steps times back to
+        back (an executor core that keeps taking map tasks); the threads are joined once, at the end, so the
+        timed region holds exactly n_steps steps of work without a drain between them."""
         def worker(tid):
+            for _ in range(n_steps):
+                one_pass(tid)
+
+        def one_pass(tid):
             c = codecs[tid]
             acc = [0.0] * 5
             n = 0
@@ -389,15 +396,13 @@ def main():
             [t.start() for t in ths]
             [t.join() for t in ths]
 
-    for _ in range(args.warmup):
-        run_step(False)
+    run_steps(args.warmup, False)
 
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_step(True)
+    run_steps(args.steps, True)
     torch.cuda.synchronize()  # library calls already synchronise their own stream before returning
     if dist:
         dist.barrier()
