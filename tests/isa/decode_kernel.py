@@ -1,0 +1,58 @@
+"""Runs the compiled `batch_decode_kernel` (LZ4 / Snappy block decoder of the reduce side) on the CPU through
+tests/isa/gfx950_emu.py (TEST INFRASTRUCTURE).  The compressed payloads sit in a buffer that ends with the last
+payload's last byte and the destination has exactly the declared decoded size, so any access outside either is a
+fault of the interpreter's memory — a byte-exact version of the guard-byte tests of tests/test_gpu_hardening.py."""
+import os
+import struct
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import gfx950_emu as emu  # noqa: E402
+import lz4_kernel as lk  # noqa: E402
+
+_PROGS = {}
+
+
+def program(fmt):
+    if fmt not in _PROGS:
+        text = lk.compile_asm("lz4_decode_batch.hip")
+        entry = lk.find_kernel(text, "batch_decode_kernelILi%dE" % fmt)
+        lds = 0
+        for line in text.splitlines():  # the kernel's LDS size from its descriptor block
+            if ".amdhsa_group_segment_fixed_size" in line:
+                lds = max(lds, int(line.split()[-1]))
+        _PROGS[fmt] = (emu.Program(text, entry), entry, text, lds or 6144)
+    return _PROGS[fmt]
+
+
+def decode_blocks(blocks, fmt=0, methods=None, profile=None):
+    """blocks: list of (payload bytes, decoded length).  fmt 0 = LZ4 block payloads, 1 = raw Snappy blocks.
+    Returns (list of decoded bytes, status word, waves)."""
+    prog, entry, text, lds = program(fmt)
+    mem = emu.Memory()
+    comp = b"".join(p for p, _ in blocks)
+    frames = bytearray()
+    outs = []
+    co = oo = 0
+    for k, (p, olen) in enumerate(blocks):
+        method = (methods[k] if methods else (0x20 if fmt == 0 else 1))
+        frames += struct.pack("<qiiIi", co, len(p), olen, 0, method)
+        outs.append(oo)
+        co += len(p)
+        oo += olen
+    dst = np.zeros(max(oo, 1), dtype=np.uint8)
+    status = np.zeros(4, dtype=np.int32)
+    a_comp = mem.map(np.frombuffer(bytearray(comp) or bytearray(1), dtype=np.uint8), "comp", writable=False)
+    a_frames = mem.map(np.frombuffer(frames, dtype=np.uint8), "frames", writable=False)
+    a_fout = mem.map(np.array(outs + [oo], dtype=np.int64), "frame_out", writable=False)
+    a_dst = mem.map(dst, "dst")
+    a_status = mem.map(status, "status")
+    kernarg = struct.pack("<QQiiQQQ", a_comp, a_frames, len(blocks), 0, a_fout, a_dst, a_status)
+    objs = emu.parse_objects(text)
+    waves = emu.launch(prog, entry, mem, kernarg, len(blocks), lds, profile=profile,
+                       objects={k: v for k, v in objs.items() if k.startswith("_ZN3s3s")})
+    res = [bytes(dst[outs[k]:outs[k] + blocks[k][1]]) for k in range(len(blocks))]
+    return res, int(status[0]), waves

@@ -137,6 +137,10 @@ def parse_operand(tok):
     if m:
         inner = parse_operand(m.group(2))
         return ("sext", inner, 1)
+    if len(tok) > 2 and tok[0] == "|" and tok[-1] == "|":
+        return ("fabs", parse_operand(tok[1:-1]), 1)
+    if len(tok) > 1 and tok[0] == "-" and (tok[1] in "sv|" or tok[1:].startswith("vcc")):
+        return ("fneg", parse_operand(tok[1:]), 1)
     return ("label", tok, 0)
 
 
@@ -1276,6 +1280,56 @@ class Program:
 
     def x_ds_swizzle_b32(self, w, i):
         raise EmuError("ds_swizzle not modelled")
+
+    # ---- the few single-precision instructions of hipcc's integer-division sequences -------------------------
+    @staticmethod
+    def _f32(w, o):
+        if o[0] == "fneg":
+            return -Program._f32(w, o[1])
+        if o[0] == "fabs":
+            return np.abs(Program._f32(w, o[1]))
+        return w.rv32(o).view(np.float32)
+
+    def x_v_cvt_f32_u32(self, w, i):
+        w.wv32(i.ops[0], w.rv32(i.ops[1]).astype(np.float32).view(np.uint32))
+
+    def x_v_cvt_f32_i32(self, w, i):
+        w.wv32(i.ops[0], w.rv32(i.ops[1]).astype(np.int32).astype(np.float32).view(np.uint32))
+
+    def x_v_cvt_f32_ubyte0(self, w, i):
+        w.wv32(i.ops[0], (w.rv32(i.ops[1]) & np.uint32(0xFF)).astype(np.float32).view(np.uint32))
+
+    def x_v_cvt_u32_f32(self, w, i):
+        f = self._f32(w, i.ops[1]).astype(np.float64)
+        f = np.where(np.isnan(f), 0.0, np.clip(np.trunc(f), 0.0, 4294967295.0))
+        w.wv32(i.ops[0], f.astype(np.uint64).astype(np.uint32))
+
+    def x_v_rcp_iflag_f32(self, w, i):
+        with np.errstate(divide="ignore"):
+            w.wv32(i.ops[0], (np.float32(1.0) / self._f32(w, i.ops[1])).astype(np.float32).view(np.uint32))
+
+    x_v_rcp_f32 = x_v_rcp_iflag_f32
+
+    def x_v_mul_f32(self, w, i):
+        w.wv32(i.ops[0], (self._f32(w, i.ops[1]) * self._f32(w, i.ops[2])).astype(np.float32).view(np.uint32))
+
+    def x_v_trunc_f32(self, w, i):
+        w.wv32(i.ops[0], np.trunc(self._f32(w, i.ops[1])).astype(np.float32).view(np.uint32))
+
+    def x_v_fma_f32(self, w, i):
+        a, b, c = (self._f32(w, o).astype(np.float64) for o in i.ops[1:4])
+        w.wv32(i.ops[0], (a * b + c).astype(np.float32).view(np.uint32))  # (double product + add, rounded once)
+
+    x_v_mad_f32 = x_v_fma_f32
+
+    def x_v_cmp_ge_f32(self, w, i):
+        w.wmask(i.ops[0], self._f32(w, i.ops[1]) >= self._f32(w, i.ops[2]))
+
+    def x_global_atomic_swap(self, w, i):
+        # (no return value used here): global_atomic_swap vaddr, vdata, saddr
+        addrs = self._gaddr(w, i, i.ops[0], i.ops[2])
+        data = w.v[i.ops[1][1]].astype("<u4").view(np.uint8).reshape(64, 4)
+        w.mem.store(addrs, w.em(), np.ascontiguousarray(data))
 
     def x_v_bitop3_b32(self, w, i):
         # result bit = table[(a << 2) | (b << 1) | c]   (a, b, c = the bits of src0, src1, src2)

@@ -119,3 +119,62 @@ def test_snappy_asm_block_keeps_its_wait_states():
     asm_viol, cc_viol, _, _ = hazards.check_kernel(text, entry)
     assert not asm_viol, asm_viol
     assert not cc_viol, ("rule set stricter than the compiler", cc_viol[:3])
+
+
+# ---- the compiled block decoder (reduce side) under the interpreter: a byte-exact bounds check ---------------------
+def _preamble_len(blk: bytes) -> int:
+    n = sh = 0
+    for b in blk:
+        n |= (b & 0x7F) << sh
+        sh += 7
+        if not b & 0x80:
+            break
+    return n
+
+
+def test_compiled_decoder_valid_blocks(oracle):
+    import decode_kernel as dk
+    import framing
+
+    rng = np.random.default_rng(41)
+    chunks = [corpus.chunk_corpus(k, n, rng) for k, n in [(7, 20000), (6, 9000), (3, 5000), (1, 4000), (2, 3000), (7, 13)]]
+    blocks = [(bytes(oracle.lz4_compress_block(c)), len(c)) for c in chunks]
+    blocks.append((framing.lz4_hc(chunks[2], 9), len(chunks[2])))  # a foreign (non-greedy) compressor's block
+    res, st, _ = dk.decode_blocks(blocks, fmt=0)
+    assert st == 0 and res[:6] == [c.tobytes() for c in chunks] and res[6] == chunks[2].tobytes()
+    sblocks = [(bytes(oracle.snappy_compress_block(c)), len(c)) for c in chunks]
+    res, st, _ = dk.decode_blocks(sblocks, fmt=1)
+    assert st == 0 and res == [c.tobytes() for c in chunks]
+
+
+def test_compiled_decoder_rejects_malformed_blocks_without_leaving_its_buffers():
+    """the payload buffer ends with the block's last byte and the destination has exactly the declared size: any
+    access outside either faults in the interpreter (MemFault), whatever the bytes say"""
+    import decode_kernel as dk
+    import framing
+
+    z = b"abcdefgh"
+    good = framing.lz4_block([(z, 8, 40)], z)
+    orig = framing.lz4_decode_py(good)
+    bad = [framing.lz4_block([(z, 9, 4)], z), framing.lz4_block([(z, 0, 4)], z), framing.lz4_block([(z, 8, 4)], z)[:-3],
+           bytes([0xF0]) + b"\xff" * 40, framing.lz4_block([(z, 4, 19)], z)[:13] + b"\xff" * 9,
+           framing.lz4_block([(z * 4, 8, 30000)], z), framing.lz4_block([(z, 8, 40)], z * 3)]
+    for blk in bad:
+        res, st, _ = dk.decode_blocks([(good, len(orig)), (blk, len(orig))], fmt=0)
+        assert st == -3 and res[0] == orig
+    rng = np.random.default_rng(42)
+    d = corpus.chunk_corpus(2, 8192, rng)
+    payload = framing.lz4_hc(d, 9)
+    for _ in range(12):
+        p = bytearray(payload)
+        for _ in range(int(rng.integers(1, 6))):
+            p[int(rng.integers(0, len(p)))] = int(rng.integers(0, 256))
+        _, st, _ = dk.decode_blocks([(bytes(p), d.size)], fmt=0)
+        assert st in (0, -3)
+    sbad = [framing.snappy_block([("lit", z), ("copy", 9, 4, 2)]), framing.snappy_block([("lit", z), ("copy", 0, 4, 2)]),
+            framing.snappy_block([("lit", z), ("copy", 4, 8, 2)], ulen=12), framing.snappy_block([("lit", z)], ulen=9),
+            framing.snappy_block([("lit", z * 10)])[:-5], framing.snappy_block([("lit", z), ("copy", 4, 8, 4)])[:-2],
+            framing.snappy_block([("lit", z), ("copy", 4, 64, 2)] * 3, ulen=100)]
+    for blk in sbad:
+        _, st, _ = dk.decode_blocks([(blk, _preamble_len(blk))], fmt=1)
+        assert st == -3
