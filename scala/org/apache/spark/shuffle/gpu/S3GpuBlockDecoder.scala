@@ -9,7 +9,8 @@
 // Patch to S3ShuffleReader.read (the flatMap at :98-110):
 //
 //   .flatMap { case (blockId, stream) =>
-//     val in = if (dispatcher.gpuEnabled && stream.maxBytes >= dispatcher.gpuMinBytes)
+//     val in = if (dispatcher.gpuEnabled && S3SCodec.supports(dispatcher.compressionCodecShortName) &&
+//                  stream.maxBytes >= dispatcher.gpuMinBytes)
 //                S3GpuBlockDecoder.decode(blockId, stream)                 // <- this file
 //              else serializerManager.wrapStream(blockId, checked(stream))  // unchanged JVM path
 //     serializerInstance.deserializeStream(in).asKeyValueIterator

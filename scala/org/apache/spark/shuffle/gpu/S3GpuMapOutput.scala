@@ -14,7 +14,8 @@
 //
 // Patch to S3ShuffleMapOutputWriter (sketch of the three touched places, everything else unchanged):
 //
-//   private val gpu = if (dispatcher.gpuEnabled) new S3GpuMapOutput(shuffleId, mapId, numPartitions) else null
+//   private val gpu = if (dispatcher.gpuEnabled && S3SCodec.supports(dispatcher.compressionCodecShortName))
+//                       new S3GpuMapOutput(shuffleId, mapId, numPartitions) else null   // zstd / lzf: JVM codecs as before
 //   // S3ShuffleOutputStream.write(b, off, len):   if (gpu != null) gpu.append(reduceId, b, off, len) else bufferedStream.write(...)
 //   // commitAllPartitions(checksums):             if (gpu != null) return gpu.commit(createBlock = () => dispatcher.createBlock(shuffleBlock))
 //

@@ -85,6 +85,13 @@ object S3SCodec {
     case _ => throw new IOException(s"$what: ${lastError(handle)} (code $rc)")
   }
 
+  /** lz4 and snappy run on the GPU; zstd and lzf keep the reference's JVM stream stack (DESIGN.md §7.1): the patched
+    * call sites test this next to spark.shuffle.s3.gpu.enabled, so an unsupported codec is a fallback, not an error. */
+  def supports(sparkCodecShortName: String): Boolean = sparkCodecShortName.toLowerCase match {
+    case "lz4" | "snappy" => true
+    case _ => false
+  }
+
   def codecId(sparkCodecShortName: String): Int = sparkCodecShortName.toLowerCase match {
     case "lz4" => CODEC_LZ4
     case "snappy" => CODEC_SNAPPY
