@@ -1105,6 +1105,9 @@ class Program:
         w.ws32(i.ops[0], r)
         w.scc = 1 if (r & M32) else 0
 
+    def x_s_pack_ll_b32_b16(self, w, i):
+        w.ws32(i.ops[0], (w.rs32(i.ops[1]) & 0xFFFF) | ((w.rs32(i.ops[2]) & 0xFFFF) << 16))
+
     def x_s_lshl1_add_u32(self, w, i):
         self._lshl_add(w, i, 1)
 

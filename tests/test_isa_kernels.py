@@ -110,6 +110,23 @@ def test_snappy_window_block_runs_most_windows(oracle):
     assert in_block > 0.6 * sum(v[0] for v in prof.values())
 
 
+def test_compiled_kernels_on_the_bench_workloads(oracle):
+    """one block of each bench.py generator (TeraSort records, TPC-DS-like wide rows) through both compiled compressors"""
+    import lz4_kernel as lk
+    import snappy_kernel as sk
+    from s3shuffle import datagen
+
+    chunks = []
+    for gen, seed in ((datagen.terasort_map_output, 2), (datagen.tpcds_wide_map_output, 3)):
+        data, offs = gen(1 << 20, 4, seed=seed, map_id=1)
+        data = np.asarray(data, dtype=np.uint8)
+        p0 = int(offs[1])
+        chunks.append(data[p0:p0 + 32768].copy())
+    _check(chunks, oracle)
+    for c, (slot, sz, w) in zip(chunks, sk.compress_chunks(chunks)):
+        assert bytes(slot[32:32 + sz - 4]) == bytes(oracle.snappy_compress_block(c))
+
+
 def test_snappy_asm_block_keeps_its_wait_states():
     import hazards
     import lz4_kernel as lk
