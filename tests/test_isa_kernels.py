@@ -127,6 +127,30 @@ def test_compiled_kernels_on_the_bench_workloads(oracle):
         assert bytes(slot[32:32 + sz - 4]) == bytes(oracle.snappy_compress_block(c))
 
 
+def test_window_blocks_take_their_rare_paths(oracle):
+    """planted copies at window-critical distances / lengths drive the out-of-line cases of both blocks (ip-2 two windows
+    ahead or further, same-window re-entry, far dispatch, duplicate-hash groups): bit-exact there too"""
+    import re
+
+    import lz4_kernel as lk
+    import snappy_kernel as sk
+
+    sys.path.insert(0, os.path.join(HERE, "tools"))
+    import isa_fuzz as F
+
+    rng = np.random.default_rng(77)
+    prof_l, prof_s = {}, {}
+    for _ in range(2):
+        chunks = [F.GENS[int(rng.integers(0, len(F.GENS)))](rng, max(1, F.pick_len(rng))) for _ in range(6)]
+        _check(chunks, oracle, profile=prof_l)
+        for c, (slot, sz, w) in zip(chunks, sk.compress_chunks(chunks, profile=prof_s)):
+            assert bytes(slot[32:32 + sz - 4]) == bytes(oracle.snappy_compress_block(c))
+    hit_l = {re.sub(r"\d*_\d+$", "", k) for k in prof_l if k.startswith(".Lw_")}
+    hit_s = {re.sub(r"\d*_\d+$", "", k) for k in prof_s if k.startswith(".Ls_")}
+    assert {".Lw_pendb", ".Lw_pendc", ".Lw_dispf", ".Lw_dispx", ".Lw_dup", ".Lw_extb", ".Lw_cloop", ".Lw_noev"} <= hit_l, hit_l
+    assert {".Ls_dispf", ".Ls_dispx", ".Ls_dup", ".Ls_ext", ".Ls_cloop", ".Ls_noev", ".Ls_pendset"} <= hit_s, hit_s
+
+
 def test_snappy_asm_block_keeps_its_wait_states():
     import hazards
     import lz4_kernel as lk
