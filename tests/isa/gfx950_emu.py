@@ -262,6 +262,7 @@ class Wave:
         self.q_vm = []
         self.q_lgkm = []
         self.pending = {}  # VGPR -> text of the load that has not been waited for
+        self.t_vm, self.t_lgkm = [], []  # cycle model: return times of the outstanding operations (same order as q_vm / q_lgkm)
         self.n_wait_events = 0
 
     # ---- helpers
@@ -1370,9 +1371,12 @@ def scoreboard(w, i):
                 continue
             if name == "vmcnt" and n > 0 and len(q) > n and any(not d for d in q) and any(d for d in q):
                 w.n_mixed_vmcnt = getattr(w, "n_mixed_vmcnt", 0) + 1
+            tq = w.t_vm if name == "vmcnt" else w.t_lgkm
             while len(q) > n:
                 for r in q.pop(0):
                     w.pending.pop(r, None)
+                if tq:  # cycle model: the wave sleeps until the operation it waits for has returned
+                    w.clock = max(w.clock, tq.pop(0))
         return
     if w.pending and i.kind != "salu":
         is_load = (i.kind == "vmem" and "_load_" in op) or (i.kind == "lds" and op.startswith("ds_read"))
@@ -1386,15 +1390,18 @@ def scoreboard(w, i):
         dest = list(_regs_of(i.ops[0])) if op.startswith("ds_read") or "permute" in op else []
         if "permute" not in op:
             w.q_lgkm.append(dest)
+            w.t_lgkm.append(max(w.clock + Cost.LDS, w.t_lgkm[-1] if w.t_lgkm else 0))  # in-order return
             for r in dest:
                 w.pending[r] = i.text
     elif i.kind == "vmem":
         dest = list(_regs_of(i.ops[0])) if "_load_" in op else []
         w.q_vm.append(dest)
+        w.t_vm.append(max(w.clock + (Cost.VMEM if dest else Cost.VMEM_STORE), w.t_vm[-1] if w.t_vm else 0))
         for r in dest:
             w.pending[r] = i.text
     elif i.kind == "smem" and op.startswith("s_load"):
         w.q_lgkm.append([])
+        w.t_lgkm.append(max(w.clock + Cost.SMEM, w.t_lgkm[-1] if w.t_lgkm else 0))
 
 
 class Cost:
@@ -1404,6 +1411,7 @@ class Cost:
     NOT_TAKEN = 11
     LDS = 128
     VMEM = 700
+    VMEM_STORE = 300
     SMEM = 200
 
 
