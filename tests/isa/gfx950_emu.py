@@ -1422,12 +1422,20 @@ def run_wave(prog, w, entry=None, max_inst=50_000_000, profile=None, hooks=None)
     pc = labels[entry] if entry else 0
     n = 0
     cur = "<entry>"
+    t_label = w.clock
     idx_label = {}
     for name, k in labels.items():
         idx_label.setdefault(k, name)
     hook_at = {labels[k]: f for k, f in (hooks or {}).items() if k in labels}
     while True:
         if profile is not None and pc in idx_label:
+            if cur in profile:  # model cycles spent since the previous label
+                pr = profile[cur]
+                if len(pr) > 2:
+                    pr[2] += w.clock - t_label
+                else:
+                    pr.append(w.clock - t_label)
+            t_label = w.clock
             cur = idx_label[pc]
         if hook_at and pc in hook_at:
             hook_at[pc](w)
