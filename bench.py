@@ -76,6 +76,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU leg")
     ap.add_argument("--verify", action="store_true", help="check one map task against the oracle first")
+    ap.add_argument("--secondary", dest="secondary", action="store_true", default=None,
+                    help="after the headline, run short (3-step) passes of the other BASELINE.json configurations and attach "
+                         "them as `secondary` to the JSON line (default: on for the plain N=1 headline command)")
+    ap.add_argument("--no-secondary", dest="secondary", action="store_false")
     ap.add_argument("--dry-run", action="store_true",
                     help="no timing: every rank reports (rank, local rank, device, its map ids); rank 0 checks that "
                          "mapId % nGPU covers every map task exactly once and prints the table as one JSON line "
@@ -83,15 +87,25 @@ def parse_args():
     return ap.parse_args()
 
 
+_GEN_CACHE = {}  # (generator, partitions, map id, bytes) -> host arrays: the secondary passes reuse the headline's inputs
+
+
 def make_map_output(workload: str, map_id: int, n_bytes: int):
     from s3shuffle import datagen
 
     gen, nparts, _, _ = WORKLOADS[workload]
+    key = (gen, nparts, map_id, n_bytes)
+    if key in _GEN_CACHE:
+        return _GEN_CACHE[key]
     if gen == "terasort":
-        return datagen.terasort_map_output(n_bytes, nparts, seed=2, map_id=map_id)
-    if gen == "tpcds":
-        return datagen.tpcds_wide_map_output(n_bytes, nparts, seed=3, map_id=map_id)
-    return datagen.skew_block(n_bytes, "terasort", seed=5, map_id=map_id)
+        r = datagen.terasort_map_output(n_bytes, nparts, seed=2, map_id=map_id)
+    elif gen == "tpcds":
+        r = datagen.tpcds_wide_map_output(n_bytes, nparts, seed=3, map_id=map_id)
+    else:
+        r = datagen.skew_block(n_bytes, "terasort", seed=5, map_id=map_id)
+    if n_bytes <= (256 << 20):
+        _GEN_CACHE[key] = r
+    return r
 
 
 def usable_cores() -> int:
@@ -118,15 +132,9 @@ def cpu_baseline(workload: str, target_s: float, map_mib: int = 128):
 
     _, nparts, codec, algo = WORKLOADS[workload]
     cores = usable_cores()
-    sample_mib = map_mib  # the whole map task the GPU leg runs (not a slice)
+    sample_mib = min(map_mib, 256)  # the whole map task the GPU leg runs (not a slice); 1 GiB blocks: the first 256 MiB
     parts = nparts
-    from s3shuffle import datagen
-    if WORKLOADS[workload][0] == "terasort":
-        data, offs = datagen.terasort_map_output(sample_mib << 20, parts, seed=2, map_id=0)
-    elif WORKLOADS[workload][0] == "tpcds":
-        data, offs = datagen.tpcds_wide_map_output(sample_mib << 20, parts, seed=3, map_id=0)
-    else:
-        data, offs = datagen.skew_block(sample_mib << 20, "terasort", seed=5, map_id=0)
+    data, offs = make_map_output(workload, 0, sample_mib << 20)
     algo_id = {"adler32": oracle.CHECKSUM_ADLER32, "crc32": oracle.CHECKSUM_CRC32}[algo]
     codec_o = oracle.CODEC_LZ4 if codec == "lz4" else oracle.CODEC_SNAPPY
     have_liblz4 = bool(oracle.lib().s3o_mt_have_liblz4()) and codec == "lz4"
@@ -157,14 +165,9 @@ def cpu_baseline_decompress(workload: str, target_s: float, map_mib: int = 128):
 
     gen, nparts, codec, algo = WORKLOADS[workload]
     cores = usable_cores()
-    sample_mib = map_mib
+    sample_mib = min(map_mib, 256)
     parts = nparts
-    if gen == "terasort":
-        data, offs = datagen.terasort_map_output(sample_mib << 20, parts, seed=2, map_id=0)
-    elif gen == "tpcds":
-        data, offs = datagen.tpcds_wide_map_output(sample_mib << 20, parts, seed=3, map_id=0)
-    else:
-        data, offs = datagen.skew_block(sample_mib << 20, "terasort", seed=5, map_id=0)
+    data, offs = make_map_output(workload, 0, sample_mib << 20)
     algo_id = {"adler32": oracle.CHECKSUM_ADLER32, "crc32": oracle.CHECKSUM_CRC32}[algo]
     codec_o = oracle.CODEC_LZ4 if codec == "lz4" else oracle.CODEC_SNAPPY
     img, index, sums = oracle.compress_map_output(codec_o, algo_id, data, offs)
@@ -222,36 +225,12 @@ def dry_run(args, rank: int, local_rank: int, world: int, launched: bool):
             raise SystemExit(2)
 
 
-def main():
-    args = parse_args()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run --nproc-per-node N (one rank per GPU)")
-        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
-
+def run_workload(args, rank: int, local_rank: int, world: int, dist):
+    """One measured workload: W warmup + K timed steps of the hot path over this rank's map tasks.  Returns the
+    result dict on rank 0 (None elsewhere)."""
     import torch
     import s3shuffle
     from s3shuffle import sharding
-
-    # one rank per GPU; under torch.distributed.run the process group is ALWAYS created (also with one rank), so the
-    # single-GPU launch line exercises the same RCCL barrier / all_reduce code the N-GPU runs use
-    launched = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or "GROUP_RANK" in os.environ
-    if args.dry_run:
-        return dry_run(args, rank, local_rank, world, launched)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device: the codec library has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if launched:
-        import torch.distributed as dist_mod
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        dist = dist_mod
 
     gen, nparts, codec_name, algo_name = WORKLOADS[args.workload]
     codec_id = s3shuffle.CODEC_LZ4 if codec_name == "lz4" else s3shuffle.CODEC_SNAPPY
@@ -272,9 +251,8 @@ def main():
 
     dev = torch.device("cuda", local_rank)
     tasks = []
-    if args.task_threads <= 0:
-        args.task_threads = 1 if args.direction == "decompress" else 4
-    n_threads = max(1, min(args.task_threads, len(map_ids)))
+    task_threads = args.task_threads if args.task_threads > 0 else (1 if args.direction == "decompress" else 4)
+    n_threads = max(1, min(task_threads, len(map_ids)))
     codecs = [s3shuffle.Codec(local_rank) for _ in range(n_threads)]
     for c in codecs:
         c.set_option(s3shuffle.codec.OPT_PROFILE, 1)
@@ -421,6 +399,7 @@ def main():
     else:
         u_all, c_all = u_rank, c_rank
 
+    out = None
     if rank == 0:
         lz4_parse = None
         if codec_name == "lz4" and not decompress:
@@ -454,9 +433,10 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": args.workload,
-                "generator": "TeraGen-like 100-byte records, seed 2" if gen == "terasort" else "TeraGen-like skew block, seed 5",
+                "generator": {"terasort": "TeraGen-like 100-byte records, seed 2", "tpcds": "UnsafeRow-like wide rows, seed 3",
+                              "skew": "single-partition TeraGen-like block, seed 5"}[gen],
                 "direction": args.direction,
-                "codec": "lz4 (LZ4Block frames, 32 KiB blocks, bit-exact with lz4-java/liblz4 1.9.3)" if codec_name == "lz4"
+                "codec": "lz4 (LZ4Block frames, 32 KiB blocks; payload bit-exact with liblz4 1.9.3 LZ4_compress_default, framing restated from lz4-java 1.8.0)" if codec_name == "lz4"
                          else "snappy (SnappyOutputStream framing, 32 KiB blocks, byte-exact with snappy 1.1.8)",
                 "checksum": algo_name,
                 "partitions_per_map_task": nparts,
@@ -512,9 +492,100 @@ def main():
                         out["roofline"]["traffic_reference"] = dict(ref[key], note="PMC pass of an earlier profiled run of this workload (tracked under profiles/); not measured by this run")
                 except Exception:
                     pass
-        print(json.dumps(out), flush=True)
     for c in codecs:
         c.close()
+    tasks.clear()
+    torch.cuda.synchronize()
+    return out if rank == 0 else None
+
+
+SECONDARY = [
+    # (label, workload, direction, map MiB, map tasks): BASELINE.json configs[2..4] and the reduce side, 3 timed steps each
+    ("tpcds-wide-snappy:compress", "tpcds-wide-100g-200p-snappy", "compress", 128, 4),
+    ("tpcds-wide-lz4:compress", "tpcds-wide-100g-200p-lz4", "compress", 128, 4),
+    ("terasort-2000p-lz4-crc32:compress", "terasort-100g-2000p-lz4-crc32", "compress", 128, 4),
+    ("terasort-200p-lz4:decompress", "terasort-10g-200p-lz4", "decompress", 128, 4),
+    ("tpcds-wide-snappy:decompress", "tpcds-wide-100g-200p-snappy", "decompress", 128, 4),
+    ("skew-1gib-lz4:compress", "skew-1part-lz4", "compress", 1024, 1),
+    ("skew-1gib-lz4:decompress", "skew-1part-lz4", "decompress", 1024, 1),
+]
+
+
+def run_secondaries(args, rank: int, local_rank: int):
+    """Short driver-visible passes of the other configurations: same code path as the headline
+    (run_workload), 3 timed steps after 1 warmup, each with its own roofline and a bounded cpu_baseline."""
+    import copy
+
+    res = {}
+    t_all = time.perf_counter()
+    for label, workload, direction, mib, maps in SECONDARY:
+        a = copy.copy(args)
+        a.workload, a.direction, a.map_mib, a.maps_per_gpu = workload, direction, mib, maps
+        a.steps, a.warmup, a.task_threads, a.batch, a.verify = 3, 1, 0, -1, False
+        a.cpu_seconds = min(args.cpu_seconds, 2.5)
+        t0 = time.perf_counter()
+        try:
+            o = run_workload(a, rank, local_rank, 1, None)
+        except Exception as e:  # a secondary line must never take the headline down
+            res[label] = {"error": repr(e)}
+            continue
+        cb = o.get("cpu_baseline") or {}
+        res[label] = {
+            "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": o["steps"], "warmup": o["warmup"],
+            "metric": o["metric"],
+            "config": {k: o["config"][k] for k in ("workload", "direction", "codec", "checksum", "partitions_per_map_task",
+                                                    "map_task_bytes", "map_tasks_per_gpu", "compression_ratio",
+                                                    "task_threads_per_gpu", "map_tasks_per_library_call")},
+            "roofline": {k: o["roofline"][k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms",
+                                                        "algorithmic_bytes_per_launch", "whole_path_read_frac")},
+            "cpu_baseline": {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "single_thread_GBps", "wall_s")} if cb else None,
+            "speedup_vs_cpu_all_cores": o.get("speedup_vs_cpu_all_cores"),
+            "wall_s": round(time.perf_counter() - t0, 2),
+        }
+        _GEN_CACHE.pop(("skew", 1, 0, mib << 20), None)
+    res["wall_s_total"] = round(time.perf_counter() - t_all, 2)
+    return res
+
+
+def main():
+    args = parse_args()
+    if args.secondary is None:  # plain headline command only (the driver's); profiling / A-B commands stay short
+        args.secondary = (args.gpus == 1 and args.workload == "terasort-10g-200p-lz4" and args.direction == "compress"
+                          and not args.no_cpu_baseline and not args.dry_run and args.map_mib == 128)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with torch.distributed.run --nproc-per-node N (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+
+    import torch
+    import s3shuffle
+    from s3shuffle import sharding
+
+    # one rank per GPU; under torch.distributed.run the process group is ALWAYS created (also with one rank), so the
+    # single-GPU launch line exercises the same RCCL barrier / all_reduce code the N-GPU runs use
+    launched = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or "GROUP_RANK" in os.environ
+    if args.dry_run:
+        return dry_run(args, rank, local_rank, world, launched)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the codec library has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if launched:
+        import torch.distributed as dist_mod
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+
+    out = run_workload(args, rank, local_rank, world, dist)
+    if rank == 0 and world == 1 and args.secondary and not args.dry_run:
+        out["secondary"] = run_secondaries(args, rank, local_rank)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if dist:
         dist.destroy_process_group()
 

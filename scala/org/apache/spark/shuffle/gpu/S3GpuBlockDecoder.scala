@@ -1,20 +1,15 @@
 //
 // S3GpuBlockDecoder — what S3ShuffleReader.read (storage/S3ShuffleReader.scala:98-110) calls instead of
 //   new S3ChecksumValidationStream(blockId, stream, algo)  +  serializerManager.wrapStream(blockId, …)
-// when spark.shuffle.s3.gpu.enabled=true: the prefetched block range (one ShuffleBlockId or one
-// ShuffleBlockBatchId = several contiguous partitions of one map output, S3ShuffleBlockIterator.scala:37-42) is
-// verified per partition against the `.checksum` object and decoded in ONE library call; the deserializer then
-// reads plain bytes.
+// when spark.shuffle.s3.gpu.enabled=true (scala/patches/0001-gpu-codec.patch): the prefetched block range (one
+// ShuffleBlockId or one ShuffleBlockBatchId = several contiguous partitions of one map output,
+// S3ShuffleBlockIterator.scala:37-42) is verified per partition against the `.checksum` object and decoded in ONE
+// library call; the deserializer then reads plain bytes.
 //
-// Patch to S3ShuffleReader.read (the flatMap at :98-110):
-//
-//   .flatMap { case (blockId, stream) =>
-//     val in = if (dispatcher.gpuEnabled && S3SCodec.supports(dispatcher.compressionCodecShortName) &&
-//                  stream.maxBytes >= dispatcher.gpuMinBytes)
-//                S3GpuBlockDecoder.decode(blockId, stream)                 // <- this file
-//              else serializerManager.wrapStream(blockId, checked(stream))  // unchanged JVM path
-//     serializerInstance.deserializeStream(in).asKeyValueIterator
-//   }
+// A range that does not fit the GPU path — above 1 GiB compressed or decoded (one direct ByteBuffer has Int
+// positions), below spark.shuffle.s3.gpu.minBytes, or written with a codec the library does not have — takes the
+// reference's JVM stack (`jvmPath`): checksum validation stream + the codec's own input stream.  The objects a GPU
+// writer produced are ordinary LZ4Block / SnappyOutputStream streams, so either side may be the JVM.
 //
 // NOT COMPILED IN THIS IMAGE (no JDK / scalac).
 //
@@ -22,9 +17,10 @@ package org.apache.spark.shuffle.gpu
 
 import java.io.InputStream
 import java.nio.ByteBuffer
+import java.util.concurrent.atomic.AtomicBoolean
 
 import org.apache.spark.shuffle.helper.{S3ShuffleDispatcher, S3ShuffleHelper}
-import org.apache.spark.storage.{BlockId, S3ShuffleBlockStream, ShuffleBlockBatchId, ShuffleBlockId}
+import org.apache.spark.storage.{BlockId, ShuffleBlockBatchId, ShuffleBlockId}
 
 object S3GpuBlockDecoder {
   private def range(blockId: BlockId): (Int, Long, Int, Int) = blockId match {
@@ -33,30 +29,53 @@ object S3GpuBlockDecoder {
     case other => throw new IllegalArgumentException(s"unexpected block $other")
   }
 
-  def decode(blockId: BlockId, stream: S3ShuffleBlockStream): InputStream = {
+  /** Compressed length of the range from the cached `.index` (S3ShuffleHelper.scala:76-81). */
+  def compressedLength(blockId: BlockId): Long = {
+    val (shuffleId, mapId, r0, r1) = range(blockId)
+    val lengths = S3ShuffleHelper.getPartitionLengths(shuffleId, mapId)
+    lengths(r1) - lengths(r0)
+  }
+
+  /** True when `decode` should take this block (the reader keeps the JVM stack otherwise). */
+  def accepts(blockId: BlockId): Boolean = {
+    val d = S3ShuffleDispatcher.get
+    d.gpuEnabled && S3SCodec.supports(d.gpuCodec) && {
+      val n = compressedLength(blockId)
+      n >= d.gpuMinBytes && n <= S3GpuBuffers.MaxBuffer
+    }
+  }
+
+  /** `jvmPath(in)` = the reference's stream stack for the same block over `in` (used when the decoded size turns out
+    * to be above one buffer: the compressed bytes are already staged, nothing is fetched twice). */
+  def decode(blockId: BlockId, stream: InputStream, jvmPath: InputStream => InputStream): InputStream = {
     val dispatcher = S3ShuffleDispatcher.get
     val (shuffleId, mapId, r0, r1) = range(blockId)
     val ctx = S3SCodec.forThread(S3SCodec.deviceFor(mapId, S3SCodec.deviceCount()))
-    val codec = S3SCodec.codecId(dispatcher.compressionCodecShortName)
+    val codec = S3SCodec.codecId(dispatcher.gpuCodec)
     val algo = S3SCodec.checksumId(dispatcher.checksumEnabled, dispatcher.checksumAlgorithm)
-    // cumulative `.index` of the map output (cached by the helper, S3ShuffleHelper.scala:76-81), relative to the range
+    // cumulative `.index` of the map output, relative to the range
     val lengths = S3ShuffleHelper.getPartitionLengths(shuffleId, mapId)
     val rel = Array.tabulate(r1 - r0 + 1)(i => lengths(r0 + i) - lengths(r0))
     val refs = if (algo == S3SCodec.CHECKSUM_NONE) null else S3ShuffleHelper.getChecksums(shuffleId, mapId).slice(r0, r1)
-    val compLen = stream.maxBytes
+    val compLen = rel(r1 - r0)
     val comp = S3GpuBuffers.take(compLen)
+    var compOwned = true
     try {
       S3GpuStreams.readFully(stream, comp, compLen) // the prefetcher's buffer -> page-locked staging
       val outLen = new Array[Long](1)
       S3SCodec.check(ctx, S3SCodec.decompressedSize(ctx, codec, comp, compLen, outLen), blockId.name)
+      if (outLen(0) > S3GpuBuffers.MaxBuffer) { // decoded range above one buffer: the JVM codecs stream it
+        compOwned = false
+        return jvmPath(new S3GpuStreams.DirectBufferInputStream(comp, compLen))
+      }
       val out = S3GpuBuffers.take(outLen(0))
       val bad = Array(-1)
       val rc = S3SCodec.decompressRange(ctx, codec, algo, comp, compLen, rel, refs, r1 - r0, out, outLen(0), outLen, bad)
       if (rc != S3SCodec.OK) S3GpuBuffers.give(out)
       S3SCodec.check(ctx, rc, blockId.name, if (bad(0) >= 0) r0 + bad(0) else -1)
-      new S3GpuStreams.DirectBufferInputStream(out, outLen(0)) // gives `out` back to S3GpuBuffers on close()
+      new S3GpuStreams.DirectBufferInputStream(out, outLen(0)) // gives `out` back to S3GpuBuffers on the first close()
     } finally {
-      S3GpuBuffers.give(comp)
+      if (compOwned) S3GpuBuffers.give(comp)
       stream.close()
     }
   }
@@ -68,18 +87,24 @@ object S3GpuStreams {
     dst.clear()
     var left = n
     while (left > 0) {
-      val k = in.read(chunk, 0, math.min(left, chunk.length).toInt)
+      val k = in.read(chunk, 0, math.min(left, chunk.length.toLong).toInt)
       if (k < 0) throw new java.io.EOFException(s"block ended $left bytes early")
       dst.put(chunk, 0, k); left -= k
     }
   }
 
+  /** Reads a pooled page-locked buffer; close() is idempotent (Spark closes shuffle streams more than once) and
+    * returns the buffer to the pool exactly once. */
   final class DirectBufferInputStream(buf: ByteBuffer, n: Long) extends InputStream {
-    buf.position(0); buf.limit(n.toInt)
-    override def read(): Int = if (buf.hasRemaining) buf.get() & 0xff else -1
+    require(n <= buf.capacity() && n <= Int.MaxValue)
+    private val view = buf.duplicate()
+    view.position(0); view.limit(n.toInt)
+    private val closed = new AtomicBoolean(false)
+    private def live: Boolean = !closed.get()
+    override def read(): Int = if (live && view.hasRemaining) view.get() & 0xff else -1
     override def read(b: Array[Byte], off: Int, len: Int): Int =
-      if (!buf.hasRemaining) -1 else { val k = math.min(len, buf.remaining()); buf.get(b, off, k); k }
-    override def available(): Int = buf.remaining()
-    override def close(): Unit = S3GpuBuffers.give(buf)
+      if (!live || !view.hasRemaining) -1 else { val k = math.min(len, view.remaining()); view.get(b, off, k); k }
+    override def available(): Int = if (live) view.remaining() else 0
+    override def close(): Unit = if (closed.compareAndSet(false, true)) S3GpuBuffers.give(buf)
   }
 }

@@ -1,109 +1,223 @@
 //
 // S3GpuMapOutput — what S3ShuffleMapOutputWriter (shuffle/S3ShuffleMapOutputWriter.scala) and
 // S3SingleSpillShuffleMapOutputWriter (shuffle/S3SingleSpillShuffleMapOutputWriter.scala:24-64) call when
-// spark.shuffle.s3.gpu.enabled=true.  The writer keeps its SPI surface (getPartitionWriter / openStream /
+// spark.shuffle.s3.gpu.enabled=true (scala/patches/0001-gpu-codec.patch is the edit of those two files, of
+// S3ShuffleReader and of S3ShuffleDispatcher).  The writer keeps its SPI surface (getPartitionWriter / openStream /
 // commitAllPartitions / abort); two things change inside it:
 //
 //   1. S3ShuffleOutputStream.write (:168-202) appends the UNCOMPRESSED serialized bytes of the partition to
-//      `staging` (page-locked, from S3SCodec.hostAlloc) instead of the BufferedOutputStream, and close() records
-//      the partition boundary — Spark-level shuffle compression is off for these writers, so nothing upstream
-//      compressed or checksummed the bytes;
-//   2. commitAllPartitions (:91-118) calls `commit` below: ONE library call produces the exact `.data` byte image,
-//      the partition lengths and the per-partition checksums; the object, the `.index` and the `.checksum` are then
+//      `staging` (page-locked, from S3SCodec.hostAlloc) instead of the BufferedOutputStream — the executor runs with
+//      spark.shuffle.compress=false, so nothing upstream compressed the bytes;
+//   2. commitAllPartitions (:91-118) calls `commit` below: the library produces the exact `.data` byte image, the
+//      partition lengths and the per-partition checksums; the object, the `.index` and the `.checksum` are then
 //      written through the unchanged S3ShuffleHelper / dispatcher code, so the store layout is untouched.
 //
-// Patch to S3ShuffleMapOutputWriter (sketch of the three touched places, everything else unchanged):
-//
-//   private val gpu = if (dispatcher.gpuEnabled && S3SCodec.supports(dispatcher.compressionCodecShortName))
-//                       new S3GpuMapOutput(shuffleId, mapId, numPartitions) else null   // zstd / lzf: JVM codecs as before
-//   // S3ShuffleOutputStream.write(b, off, len):   if (gpu != null) gpu.append(reduceId, b, off, len) else bufferedStream.write(...)
-//   // commitAllPartitions(checksums):             if (gpu != null) return gpu.commit(createBlock = () => dispatcher.createBlock(shuffleBlock))
+// Sizes: a direct ByteBuffer holds at most 2^31-1 bytes, a map output does not have to.  Staging is therefore a
+// bounded buffer (spark.shuffle.s3.gpu.stagingBytes, at most 1 GiB) that is FLUSHED — compressed, checksummed and
+// appended to the data object — whenever it fills: at a partition boundary the flushed partitions are final; in the
+// middle of a partition the piece becomes one complete codec stream (all Spark codecs on this path support
+// concatenated streams, which is what their fast spill merge relies on), and the partition's checksum is kept
+// running on the JVM over the compressed pieces.  All positions are Long.
 //
 // NOT COMPILED IN THIS IMAGE (no JDK / scalac).
 //
 package org.apache.spark.shuffle.gpu
 
-import java.io.OutputStream
+import java.io.{File, FileInputStream, OutputStream}
 import java.nio.ByteBuffer
+import java.util.zip.{Adler32, CRC32, Checksum}
 
 import org.apache.spark.shuffle.api.metadata.MapOutputCommitMessage
 import org.apache.spark.shuffle.helper.{S3ShuffleDispatcher, S3ShuffleHelper}
 
-class S3GpuMapOutput(shuffleId: Int, mapId: Long, numPartitions: Int) {
+class S3GpuMapOutput(shuffleId: Int, mapId: Long, numPartitions: Int, createBlock: () => OutputStream) {
   private val dispatcher = S3ShuffleDispatcher.get
-  private val device = S3SCodec.deviceFor(mapId, S3SCodec.deviceCount())
-  private val ctx = S3SCodec.forThread(device)
-  private val codec = S3SCodec.codecId(dispatcher.compressionCodecShortName)
+  private val ctx = S3SCodec.forThread(S3SCodec.deviceFor(mapId, S3SCodec.deviceCount()))
+  private val codec = S3SCodec.codecId(dispatcher.gpuCodec)
   private val algo = S3SCodec.checksumId(dispatcher.checksumEnabled, dispatcher.checksumAlgorithm)
 
-  private var staging: ByteBuffer = S3GpuBuffers.take(S3GpuBuffers.lastMapOutputSize)
-  private val srcOffsets = new Array[Long](numPartitions + 1) // cumulative, srcOffsets(0) = 0
-  private var lastPartition = -1
+  private val stagingBytes: Long = math.min(dispatcher.gpuStagingBytes, S3GpuBuffers.MaxBuffer)
+  private var staging: ByteBuffer = S3GpuBuffers.take(math.min(S3GpuBuffers.lastMapOutputSize, stagingBytes))
 
-  /** Bytes of partition `reduceId` (ascending ids only — same precondition as getPartitionWriter, :67-73). */
-  def append(reduceId: Int, b: Array[Byte], off: Int, len: Int): Unit = {
-    if (reduceId < lastPartition)
+  // results, per partition of the map output
+  private val partitionLengths = new Array[Long](numPartitions) // compressed bytes
+  private val checksums = new Array[Long](numPartitions)
+  // the staged group: partitions groupFirst .. current, cumulative offsets inside `staging`
+  private var groupFirst = 0
+  private var current = -1
+  private val groupOffsets = new scala.collection.mutable.ArrayBuffer[Long]() += 0L
+  // a partition that was flushed in pieces keeps its checksum running here (compressed bytes, in order)
+  private var running: Checksum = null // non-null <=> partition groupFirst already has bytes in the object
+  private var stream: OutputStream = null // the data block, opened lazily like initStream() (:43-49)
+  private var uncompressedTotal = 0L
+
+  def bytesStaged: Long = uncompressedTotal
+
+  /** Opens partitions up to `reduceId`; the ones in between stay empty (0 bytes in the object). */
+  private def openPartition(reduceId: Int): Unit = {
+    if (reduceId < current)
       throw new RuntimeException("Precondition: Expect a monotonically increasing reducePartitionId.")
-    while (lastPartition < reduceId) { lastPartition += 1; srcOffsets(lastPartition + 1) = srcOffsets(lastPartition) }
-    if (staging.remaining() < len) staging = S3GpuBuffers.grow(staging, staging.position() + len)
-    staging.put(b, off, len)
-    srcOffsets(reduceId + 1) += len
-  }
-
-  /** commitAllPartitions: compress + checksum on the GPU, then the reference's own store writes. */
-  def commit(createBlock: () => OutputStream): MapOutputCommitMessage = {
-    while (lastPartition < numPartitions - 1) { lastPartition += 1; srcOffsets(lastPartition + 1) = srcOffsets(lastPartition) }
-    val cap = S3SCodec.maxCompressedSize(ctx, codec, srcOffsets, numPartitions)
-    val out = S3GpuBuffers.take(cap)
-    val index = new Array[Long](numPartitions + 1)
-    val sums = new Array[Long](math.max(numPartitions, 1))
-    val total = new Array[Long](1)
-    try {
-      val rc = S3SCodec.compressMapOutput(ctx, codec, algo, staging, srcOffsets, numPartitions, out, cap, index,
-        if (algo == S3SCodec.CHECKSUM_NONE) null else sums, total)
-      S3SCodec.check(ctx, rc, s"shuffle_${shuffleId}_${mapId}_0.data")
-      val partitionLengths = Array.tabulate(numPartitions)(p => index(p + 1) - index(p))
-      if (total(0) > 0) { // the data block is opened lazily, like initStream() (:43-49)
-        val stream = createBlock()
-        try S3GpuBuffers.writeTo(stream, out, total(0)) finally stream.close()
-      }
-      // emission rule and order of commitAllPartitions (:111-115): index, then checksum, iff bytes or alwaysCreateIndex
-      if (partitionLengths.sum > 0 || dispatcher.alwaysCreateIndex) {
-        S3ShuffleHelper.writePartitionLengths(shuffleId, mapId, partitionLengths)
-        if (dispatcher.checksumEnabled) S3ShuffleHelper.writeChecksum(shuffleId, mapId, sums.take(numPartitions))
-      }
-      S3GpuBuffers.lastMapOutputSize = staging.position()
-      MapOutputCommitMessage.of(partitionLengths)
-    } finally {
-      S3GpuBuffers.give(out)
-      S3GpuBuffers.give(staging)
+    while (current < reduceId) {
+      current += 1
+      groupOffsets += groupOffsets.last // (groupOffsets.length == current - groupFirst + 2)
     }
   }
 
-  def abort(): Unit = S3GpuBuffers.give(staging)
+  /** Bytes of partition `reduceId` (ascending ids only — same precondition as getPartitionWriter, :67-73). */
+  def append(reduceId: Int, b: Array[Byte], off: Int, len: Int): Unit = {
+    if (reduceId != current) openPartition(reduceId)
+    var o = off
+    var left = len
+    while (left > 0) {
+      if (!staging.hasRemaining) {
+        if (staging.capacity() < stagingBytes) staging = S3GpuBuffers.grow(staging, math.min(2L * staging.capacity(), stagingBytes))
+        else flush(endOfPartition = false)
+      }
+      val k = math.min(left, staging.remaining())
+      staging.put(b, o, k)
+      o += k; left -= k
+      groupOffsets(groupOffsets.length - 1) += k
+      uncompressedTotal += k
+    }
+  }
+
+  private val one = new Array[Byte](1)
+  def append(reduceId: Int, b: Int): Unit = { one(0) = b.toByte; append(reduceId, one, 0, 1) }
+
+  /** S3SingleSpillShuffleMapOutputWriter.transferMapSpillFile: the spill file holds the partitions back to back. */
+  def appendFile(spill: File, uncompressedLengths: Array[Long]): Unit = {
+    val in = new FileInputStream(spill)
+    val chunk = new Array[Byte](1 << 20)
+    try {
+      var p = 0
+      while (p < uncompressedLengths.length) {
+        var left = uncompressedLengths(p)
+        while (left > 0) {
+          val k = in.read(chunk, 0, math.min(left, chunk.length.toLong).toInt)
+          if (k < 0) throw new java.io.EOFException(s"${spill.getName} ended $left bytes early")
+          append(p, chunk, 0, k)
+          left -= k
+        }
+        p += 1
+      }
+    } finally in.close()
+  }
+
+  /** Compress + checksum what is staged and append it to the data block.  `endOfPartition = false`: the last staged
+    * partition continues after the flush (its piece is a complete stream; the checksum keeps running). */
+  private def flush(endOfPartition: Boolean): Unit = {
+    val n = groupOffsets.length - 1 // staged partitions groupFirst .. current (the last one possibly partial)
+    if (n <= 0) return
+    val offs = groupOffsets.toArray
+    val cap = S3SCodec.maxCompressedSize(ctx, codec, offs, n)
+    val out = S3GpuBuffers.take(cap)
+    val index = new Array[Long](n + 1)
+    val sums = new Array[Long](n)
+    val total = new Array[Long](1)
+    try {
+      val rc = S3SCodec.compressMapOutput(ctx, codec, algo, staging, offs, n, out, cap, index,
+        if (algo == S3SCodec.CHECKSUM_NONE) null else sums, total)
+      S3SCodec.check(ctx, rc, s"shuffle_${shuffleId}_${mapId}_0.data")
+      var i = 0
+      while (i < n) { // per partition: bytes, length, checksum (a split partition's checksum runs on the JVM)
+        val p = groupFirst + i
+        val len = index(i + 1) - index(i)
+        val continues = i == n - 1 && !endOfPartition // more bytes of p follow this flush
+        val piece = continues || (i == 0 && running != null) // p is written in more than one piece
+        if (piece && running == null && algo != S3SCodec.CHECKSUM_NONE)
+          running = if (algo == S3SCodec.CHECKSUM_CRC32) new CRC32() else new Adler32()
+        if (len > 0) {
+          if (stream == null) stream = createBlock()
+          S3GpuBuffers.writeTo(stream, out, index(i), len, if (piece) running else null)
+        }
+        partitionLengths(p) += len
+        if (!piece) checksums(p) = sums(i)
+        else if (!continues) {
+          if (running != null) checksums(p) = running.getValue
+          running = null
+        }
+        i += 1
+      }
+    } finally S3GpuBuffers.give(out)
+    // the next group starts with the partition that continues, or behind the last complete one
+    groupFirst = if (endOfPartition) current + 1 else current
+    groupOffsets.clear(); groupOffsets += 0L
+    if (!endOfPartition) groupOffsets += 0L
+    staging.clear()
+  }
+
+  /** commitAllPartitions: compress + checksum on the GPU, then the reference's own store writes. */
+  def commit(): MapOutputCommitMessage = {
+    try {
+      if (current < numPartitions - 1) openPartition(numPartitions - 1)
+      flush(endOfPartition = true)
+      if (stream != null) { stream.close(); stream = null }
+      // emission rule and order of commitAllPartitions (:111-115): index, then checksum, iff bytes or alwaysCreateIndex
+      if (partitionLengths.sum > 0 || dispatcher.alwaysCreateIndex) {
+        S3ShuffleHelper.writePartitionLengths(shuffleId, mapId, partitionLengths)
+        if (dispatcher.checksumEnabled) S3ShuffleHelper.writeChecksum(shuffleId, mapId, checksums)
+      }
+      S3GpuBuffers.lastMapOutputSize = math.max(uncompressedTotal, 1L << 20)
+      MapOutputCommitMessage.of(partitionLengths)
+    } finally release()
+  }
+
+  def abort(): Unit = {
+    try if (stream != null) stream.close() finally release()
+  }
+
+  private def release(): Unit = { S3GpuBuffers.give(staging); staging = null }
 }
 
-/** Process-wide cache of page-locked direct buffers (pinning pages costs ~100 ms per GiB: never per task). */
+/** Process-wide cache of page-locked direct buffers (pinning pages costs ~100 ms per GiB: never per task).  Bounded:
+  * what does not fit under spark.shuffle.s3.gpu.pinnedPoolBytes goes back to the driver (s3s_host_free). */
 object S3GpuBuffers {
+  val MaxBuffer: Long = 1L << 30 // one direct ByteBuffer: Int positions
   @volatile var lastMapOutputSize: Long = 8L << 20 // first guess = the reference's 8 MiB write buffer (S3ShuffleDispatcher.scala:55)
-  private val free = new java.util.concurrent.ConcurrentLinkedDeque[ByteBuffer]()
+  private val free = new java.util.ArrayDeque[ByteBuffer]()
+  private var pooledBytes = 0L
+  private def poolLimit: Long = S3ShuffleDispatcher.get.gpuPinnedPoolBytes
 
   def take(atLeast: Long): ByteBuffer = {
-    val it = free.iterator()
-    while (it.hasNext) { val b = it.next(); if (b.capacity() >= atLeast && free.remove(b)) { b.clear(); return b } }
+    if (atLeast > Int.MaxValue) throw new IllegalArgumentException(s"pinned buffer of $atLeast bytes: callers chunk above 2 GiB")
+    free.synchronized {
+      val it = free.iterator()
+      while (it.hasNext) {
+        val b = it.next()
+        if (b.capacity() >= atLeast) { it.remove(); pooledBytes -= b.capacity(); b.clear(); return b }
+      }
+    }
     val b = S3SCodec.hostAlloc(math.max(atLeast, 1L << 20))
     if (b == null) throw new OutOfMemoryError(s"s3s_host_alloc($atLeast)")
     b
   }
-  def give(b: ByteBuffer): Unit = if (b != null) free.offerFirst(b)
+
+  /** Idempotence is the caller's job (DirectBufferInputStream.close guards it); a buffer is pooled at most once. */
+  def give(b: ByteBuffer): Unit = if (b != null) {
+    val keep = free.synchronized {
+      val dup = { val it = free.iterator(); var f = false; while (it.hasNext) f |= (it.next() eq b); f }
+      if (dup) true
+      else if (pooledBytes + b.capacity() <= poolLimit) { free.addFirst(b); pooledBytes += b.capacity(); true }
+      else false
+    }
+    if (!keep) S3SCodec.hostFree(b)
+  }
+
   def grow(b: ByteBuffer, atLeast: Long): ByteBuffer = {
-    val n = take(math.max(atLeast, 2L * b.capacity()))
+    val n = take(atLeast)
     b.flip(); n.put(b); give(b); n
   }
-  def writeTo(s: OutputStream, b: ByteBuffer, n: Long): Unit = {
+
+  /** out[from, from+len) -> s in 1 MiB pieces; `sum` (optional) sees the same bytes in the same order. */
+  def writeTo(s: OutputStream, out: ByteBuffer, from: Long, len: Long, sum: Checksum): Unit = {
     val chunk = new Array[Byte](1 << 20)
-    b.position(0)
-    var left = n
-    while (left > 0) { val k = math.min(left, chunk.length).toInt; b.get(chunk, 0, k); s.write(chunk, 0, k); left -= k }
+    val view = out.duplicate()
+    view.limit((from + len).toInt); view.position(from.toInt) // (one buffer never exceeds MaxBuffer)
+    while (view.hasRemaining) {
+      val k = math.min(view.remaining(), chunk.length)
+      view.get(chunk, 0, k)
+      if (sum != null) sum.update(chunk, 0, k)
+      s.write(chunk, 0, k)
+    }
   }
 }

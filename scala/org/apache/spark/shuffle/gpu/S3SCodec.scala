@@ -69,8 +69,16 @@ object S3SCodec {
   }
 
   def forThread(device: Int): Long = contexts.get().getOrElseUpdate(device, {
+    val d = org.apache.spark.shuffle.helper.S3ShuffleDispatcher.get
+    load(d.gpuLibrary)
     val h = create(device, 0L)
     if (h == 0L) throw new IOException(s"s3s_create($device) failed: no HIP device (there is no CPU fallback)")
+    // the JVM codecs' chunk sizes (spark.io.compression.{lz4,snappy}.blockSize): the objects must look like theirs
+    if (setOption(h, OPT_LZ4_BLOCK_SIZE, d.gpuLz4BlockSize) != OK || setOption(h, OPT_SNAPPY_BLOCK_SIZE, d.gpuSnappyBlockSize) != OK) {
+      val why = lastError(h)
+      destroy(h)
+      throw new IllegalArgumentException(s"codec block size not supported by the GPU path: $why")
+    }
     h
   })
 

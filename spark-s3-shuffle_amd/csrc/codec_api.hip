@@ -714,12 +714,19 @@ int s3s_compress_map_output(s3s_ctx* ctx, int codec, int checksum_algo, const ui
   std::vector<int64_t> rebased((size_t)n + 1);
   for (int32_t p = 0; p <= n; p++) rebased[(size_t)p] = src_offsets[p] - first;
   int64_t total = 0;
-  ctx->up_host = total_u > 0 ? src + first : nullptr;
   if (codec == S3S_CODEC_NONE && total_u > 0)  // (no codec kernel to overlap with)
     HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_SRC].p, src + first, (size_t)total_u, hipMemcpyHostToDevice, ctx->stream));
-  rc = s3s_compress_map_output_device(ctx, codec, checksum_algo, dev<uint8_t>(ctx, B_SRC), rebased.data(), n,
-                                      dev<uint8_t>(ctx, B_DST), dcap, out_index, out_checksums, &total);
-  ctx->up_host = nullptr;
+  {
+    // up_host is set for the device call only and cleared on every way out of it: a stale pointer would make a
+    // later s3s_compress_map_output_device call on this context upload over the caller's d_src
+    struct UpHostScope {
+      s3s_ctx* c;
+      ~UpHostScope() { c->up_host = nullptr; }
+    } scope{ctx};
+    ctx->up_host = (total_u > 0 && codec != S3S_CODEC_NONE) ? src + first : nullptr;
+    rc = s3s_compress_map_output_device(ctx, codec, checksum_algo, dev<uint8_t>(ctx, B_SRC), rebased.data(), n,
+                                        dev<uint8_t>(ctx, B_DST), dcap, out_index, out_checksums, &total);
+  }
   if (out_total) *out_total = total;
   if (rc != S3S_OK) return rc;
   if (total > 0) HIP_TRY(ctx, hipMemcpy(dst, ctx->buf[B_DST].p, (size_t)total, hipMemcpyDeviceToHost));

@@ -302,7 +302,11 @@ __device__ int lz4_compress_wave(const Src in, lds_u16* table, int len, uint8_t*
                            "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99",
                            "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133",
                            "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145",
-                           "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "vcc", "scc", "memory");
+                           "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153",
+#if defined(S3S_ABL_DUP_PW) || defined(S3S_ABL_DUP_GATHER)
+                           "v154", "v155", "v156", "v157",
+#endif
+                           "vcc", "scc", "memory");
             pw0 = make_uint4((uint32_t)p0l, (uint32_t)(p0l >> 32), (uint32_t)p0h, (uint32_t)(p0h >> 32));
             pw1 = make_uint4((uint32_t)p1l, (uint32_t)(p1l >> 32), (uint32_t)p1h, (uint32_t)(p1h >> 32));
             pw2 = make_uint4((uint32_t)p2l, (uint32_t)(p2l >> 32), (uint32_t)p2h, (uint32_t)(p2h >> 32));
@@ -693,9 +697,14 @@ __device__ __forceinline__ uint32_t xxh32_wave(const uint8_t* g, int len, uint32
   uint32_t acc = lane == 0 ? seed + XXP1 + XXP2 : lane == 1 ? seed + XXP2 : lane == 2 ? seed : seed - XXP1;
   const int stripes = len >> 4, nblk = len >> 8;
   auto ld32u = [&](int byte_pos) -> uint32_t {
+#ifdef S3S_X_HASH_NT
+    typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+    return __builtin_nontemporal_load(reinterpret_cast<const u32_unaligned*>(g + byte_pos));
+#else
     uint32_t x;
     __builtin_memcpy(&x, g + byte_pos, 4);
     return x;
+#endif
   };
   uint32_t cur = nblk > 0 ? ld32u(4 * lane) : 0u;
   for (int bk = 0; bk < nblk; bk++) {
@@ -753,6 +762,18 @@ __global__ __launch_bounds__(kWave) void lz4_compress_l2_kernel(
     for (int i = lane; i < 16384 / 16; i += kWave) tz[i] = make_uint4(0, 0, 0, 0);
   }
   __syncthreads();
+#ifdef S3S_X_PREFETCH_BLOCK  // experiment: touch the whole block first (L2 / MALL warm right before the parse)
+  {
+    const uint8_t* g = src + item.src_off;
+    uint32_t acc = 0;
+    for (int i = lane * 16; i + 16 <= item.len; i += kWave * 16) {
+      uint4 x;
+      __builtin_memcpy(&x, g + i, 16);
+      acc ^= x.x ^ x.y ^ x.z ^ x.w;
+    }
+    if (acc == 0x12345678u && item.len < 0) table[0] = 1;  // (never taken: keeps the loads)
+  }
+#endif
   uint8_t* slot = slots + (size_t)item.chunk * kSlotBytes;
   const uint32_t check = item_check[it];
   const int clen = lz4_compress_wave<SrcGlobal, kWindows>(SrcGlobal{src + item.src_off}, (lds_u16*)table,

@@ -708,6 +708,10 @@ __global__ __launch_bounds__(kWave) void lz4_verify_frames_kernel(
     len = fr.orig_len;
     want = fr.check;
     g = dst + frame_out[f];
+    // a compressed frame above kMaxBlock was NOT decoded by batch_decode_kernel (status = S3S_E_UNSUPPORTED, the
+    // caller retries with the ring decoder, which checks the hash itself): hashing the stale destination here
+    // would replace that status with S3S_E_BAD_FRAME and suppress the retry
+    if (len > kMaxBlock && fr.method != 0x10) len = 0;
   }
   const uint32_t seed = kLz4BlockSeed;
   uint32_t acc = l == 0 ? seed + XP1 + XP2 : l == 1 ? seed + XP2 : l == 2 ? seed : seed - XP1;

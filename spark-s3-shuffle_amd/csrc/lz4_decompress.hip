@@ -370,7 +370,7 @@ __global__ __launch_bounds__(kWave) void lz4_decompress_valu_kernel(
     const uint32_t c_lo = (uint32_t)(reinterpret_cast<uint64_t>(c) & 3u);  // stream byte s sits at dword-space byte s + c_lo
     const uint8_t* c_al = c - c_lo;                                        // dword-aligned base of the stream
     const int last_dw = (int)((c_lo + (uint32_t)clen - 1u) >> 2);          // last dword index holding stream bytes
-    int wb = -1 << 20;   // dword index (relative to c_al) of window lane 0; VGPR-uniform
+    int wb = -(1 << 20);  // dword index (relative to c_al) of window lane 0; VGPR-uniform
     asm volatile("" : "+v"(wb));
     uint32_t win = 0;
 #ifdef S3S_LZ4_TIMING

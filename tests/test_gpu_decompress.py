@@ -158,9 +158,35 @@ def test_codec_none_passthrough(gpu_codec, oracle):
 def test_blocks_above_32k_from_a_foreign_writer(gpu_codec, oracle):
     """A JVM writer configured with spark.io.compression.lz4.blockSize=64k produces 64 KiB LZ4Block frames.  The
     batch decoder keeps stream offsets in 16 bits and reports such frames as unsupported; the library retries the
-    range with the ring decoder, so the caller gets the bytes either way (also through the batched entry point)."""
+    range with the ring decoder, so the caller gets the bytes either way (also through the batched entry point).
+    The destination is painted first: a decoder that skips the frames cannot pass on what an earlier call left there
+    (round-2 advisor finding: the frame-check kernel used to overwrite UNSUPPORTED with BAD_FRAME)."""
+    from hipdev import Dev
+
     rng = np.random.default_rng(41)
     data, offsets = corpus.ragged_map_output(rng, 6, 400_000)
     img, index, sums = oracle.compress_map_output(LZ4, ADLER, data, offsets, 65536)
-    out = gpu_codec.decompress_range(LZ4, ADLER, img, index, sums)
-    assert np.array_equal(out, data)
+    dev = Dev()
+    try:
+        d_comp = dev.upload(img)
+        paint = np.full(data.size + 64, 0xA5, np.uint8)
+        d_out = dev.upload(paint)
+        got = gpu_codec.decompress_range_device(LZ4, ADLER, d_comp, img.size, index, sums, d_out, data.size)
+        assert got == data.size
+        back = dev.download(d_out, data.size + 64)
+        assert np.array_equal(back[:data.size], data)
+        assert np.all(back[data.size:] == 0xA5)
+        # the batched entry point: two ranges, one with 64 KiB frames and one ordinary
+        small, soffs = corpus.ragged_map_output(rng, 4, 90_000)
+        simg, sindex, ssums = oracle.compress_map_output(LZ4, ADLER, small, soffs)
+        d_comp2 = dev.upload(simg)
+        d_out1 = dev.upload(paint)
+        d_out2 = dev.upload(np.full(small.size, 0x5A, np.uint8))
+        res = gpu_codec.decompress_ranges_batch_device(
+            LZ4, ADLER, [(d_comp, img.size, index, sums, d_out1, data.size),
+                         (d_comp2, simg.size, sindex, ssums, d_out2, small.size)])
+        assert [r[0] for r in res] == [0, 0] and [r[1] for r in res] == [data.size, small.size]
+        assert np.array_equal(dev.download(d_out1, data.size), data)
+        assert np.array_equal(dev.download(d_out2, small.size), small)
+    finally:
+        dev.free()

@@ -1,7 +1,7 @@
-"""Full-size property checks on the GPU (BASELINE.json sizes, where the oracle would take too long):
-size-independent properties instead of byte comparison — compress -> verify+decompress round trip,
-index consistency, checksum-of-output re-derived by the checksum kernel, idempotence (same bytes on a
-second run and on a second context) — plus an oracle spot check on a few whole partitions."""
+"""BASELINE.json sizes on the GPU: the WHOLE `.data` image, the index and the checksums of every full-size
+configuration are compared with the oracle (it needs 0.16 s per 128 MiB map task, 1.3 s for the 1 GiB block), and
+the size-independent properties ride along — compress -> verify+decompress round trip, index consistency,
+checksum-of-output re-derived by the checksum kernel, idempotence (same bytes on a second context)."""
 import numpy as np
 import pytest
 
@@ -11,13 +11,19 @@ LZ4, SNAPPY = 1, 2
 ADLER, CRC = 1, 2
 
 
-def _roundtrip(gpu_codec, oracle, codec, algo, data, offsets, spot_parts=()):
+def _roundtrip(gpu_codec, oracle, codec, algo, data, offsets):
     """Host-buffer entry points on purpose (no torch in the test process: the library brings its own
     HIP runtime binding and must be the only one initialised)."""
     import s3shuffle
 
     img, index, sums = gpu_codec.compress_map_output(codec, algo, data, offsets)
     total = img.size
+    # the oracle on the same input: every byte of the image, every index entry, every checksum
+    want_img, want_index, want_sums = oracle.compress_map_output(codec, algo, data, offsets)
+    assert np.array_equal(index, want_index), "index differs from the oracle"
+    assert np.array_equal(sums, want_sums), "checksums differ from the oracle"
+    assert img.size == want_img.size and np.array_equal(img, want_img), ".data image differs from the oracle"
+    del want_img
     assert index[0] == 0 and index[-1] == total and (np.diff(index) >= 0).all()
     empty = np.diff(np.asarray(offsets)) == 0
     assert (np.diff(index)[empty] == 0).all()                      # empty partition = 0 bytes
@@ -33,12 +39,6 @@ def _roundtrip(gpu_codec, oracle, codec, algo, data, offsets, spot_parts=()):
     out = gpu_codec.decompress_range(codec, algo, img, index, sums, dst_capacity=data.size)
     assert out.size == data.size and np.array_equal(out, data)
     del out
-    # oracle spot check on a few whole partitions (their streams are self-contained)
-    for p in spot_parts:
-        part = data[offsets[p]:offsets[p + 1]]
-        want = oracle.compress_stream(codec, part) if part.size else np.zeros(0, np.uint8)
-        assert np.array_equal(img[index[p]:index[p + 1]], want), p
-        assert sums[p] == oracle.checksum(algo, want)
     return total
 
 
@@ -46,7 +46,7 @@ def test_terasort_128mib_200_partitions_lz4(gpu_codec, oracle):
     from s3shuffle import datagen
 
     data, offs = datagen.terasort_map_output(128 << 20, 200, seed=2, map_id=1)
-    total = _roundtrip(gpu_codec, oracle, LZ4, ADLER, data, offs, spot_parts=(0, 99, 199))
+    total = _roundtrip(gpu_codec, oracle, LZ4, ADLER, data, offs)
     assert 3.5 < data.size / total < 5.5
 
 
@@ -54,7 +54,7 @@ def test_terasort_128mib_2000_partitions_lz4_crc32(gpu_codec, oracle):
     from s3shuffle import datagen
 
     data, offs = datagen.terasort_map_output(128 << 20, 2000, seed=4, map_id=5)
-    _roundtrip(gpu_codec, oracle, LZ4, CRC, data, offs, spot_parts=(0, 1000, 1999))
+    _roundtrip(gpu_codec, oracle, LZ4, CRC, data, offs)
 
 
 def test_skew_1gib_single_partition_lz4(gpu_codec, oracle):
@@ -80,4 +80,12 @@ def test_tpcds_wide_128mib_snappy(gpu_codec, oracle):
     from s3shuffle import datagen
 
     data, offs = datagen.tpcds_wide_map_output(128 << 20, 200, seed=3)
-    _roundtrip(gpu_codec, oracle, SNAPPY, ADLER, data, offs, spot_parts=(0, 100))
+    _roundtrip(gpu_codec, oracle, SNAPPY, ADLER, data, offs)
+
+
+def test_tpcds_wide_128mib_lz4(gpu_codec, oracle):
+    """configs[2] rows under Spark's default codec (match-dense: ~6.5 sequences per 64-byte window)."""
+    from s3shuffle import datagen
+
+    data, offs = datagen.tpcds_wide_map_output(128 << 20, 200, seed=3, map_id=2)
+    _roundtrip(gpu_codec, oracle, LZ4, CRC, data, offs)

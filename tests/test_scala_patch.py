@@ -1,0 +1,90 @@
+"""f1 as something checkable without a JDK: scala/patches/0001-gpu-codec.patch must apply to the
+reference's own writer / reader / dispatcher (`git apply --check` on a scratch copy of /root/reference — skipped on
+the GPU box, where the reference does not exist), and the names that cross between the patch and the shim sources
+under scala/ must exist on the other side (config keys, methods)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PATCH = os.path.join(ROOT, "scala", "patches", "0001-gpu-codec.patch")
+SHIM = os.path.join(ROOT, "scala", "org", "apache", "spark", "shuffle", "gpu")
+REF = "/root/reference"
+
+
+def _read(*parts):
+    return open(os.path.join(*parts), errors="ignore").read()
+
+
+@pytest.fixture(scope="module")
+def patched_tree(tmp_path_factory):
+    if not os.path.isdir(os.path.join(REF, "src", "main", "scala")):
+        pytest.skip("reference sources not present (GPU box)")
+    top = tmp_path_factory.mktemp("ref")
+    shutil.copytree(os.path.join(REF, "src"), os.path.join(top, "src"))
+    chk = subprocess.run(["git", "apply", "--check", "--verbose", PATCH], cwd=top, capture_output=True, text=True)
+    assert chk.returncode == 0, chk.stderr
+    subprocess.run(["git", "apply", PATCH], cwd=top, check=True)
+    # the shim sources go next to the plugin's own packages
+    dst = os.path.join(top, "src", "main", "scala", "org", "apache", "spark", "shuffle", "gpu")
+    shutil.copytree(SHIM, dst)
+    return str(top)
+
+
+def test_patch_touches_the_four_call_sites():
+    text = _read(PATCH)
+    files = re.findall(r"^\+\+\+ b/(\S+)", text, re.M)
+    assert sorted(os.path.basename(f) for f in files) == [
+        "S3ShuffleDispatcher.scala", "S3ShuffleMapOutputWriter.scala", "S3ShuffleReader.scala",
+        "S3SingleSpillShuffleMapOutputWriter.scala"]
+
+
+def test_patch_applies_to_the_reference(patched_tree):
+    w = _read(patched_tree, "src/main/scala/org/apache/spark/shuffle/S3ShuffleMapOutputWriter.scala")
+    assert "gpu.append(reduceId, b, off, len)" in w and "return gpu.commit()" in w
+    r = _read(patched_tree, "src/main/scala/org/apache/spark/storage/S3ShuffleReader.scala")
+    assert "S3GpuBlockDecoder.decode(blockId, stream, jvmStack)" in r
+
+
+def test_config_keys_used_by_the_shim_are_defined_by_the_patch(patched_tree):
+    disp = _read(patched_tree, "src/main/scala/org/apache/spark/shuffle/helper/S3ShuffleDispatcher.scala")
+    defined = set(re.findall(r"^\s*val (gpu\w+)\s*:", disp, re.M))
+    used = set()
+    for d, _, names in os.walk(os.path.join(patched_tree, "src", "main", "scala")):
+        for n in names:
+            if n.endswith(".scala") and n != "S3ShuffleDispatcher.scala":
+                used |= set(re.findall(r"\b(?:dispatcher|d|S3ShuffleDispatcher\.get)\.(gpu\w+)", _read(d, n)))
+    assert used and used <= defined, (used - defined)
+    # every key is documented where the maintainer looks for it
+    integ = _read(ROOT, "INTEGRATION.md")
+    for key in re.findall(r'"(spark\.shuffle\.s3\.gpu\.\w+)"', disp):
+        assert key in integ, key
+
+
+def test_methods_the_patch_calls_exist_in_the_shim():
+    patch = _read(PATCH)
+    out_cls = _read(SHIM, "S3GpuMapOutput.scala")
+    dec = _read(SHIM, "S3GpuBlockDecoder.scala")
+    codec = _read(SHIM, "S3SCodec.scala")
+    for m in set(re.findall(r"(?<![\w.])gpu\.(\w+)", patch)):
+        assert re.search(r"\bdef %s\b" % m, out_cls), m
+    for m in set(re.findall(r"S3GpuBlockDecoder\.(\w+)", patch)):
+        assert re.search(r"\bdef %s\b" % m, dec), m
+    for m in set(re.findall(r"S3SCodec\.(\w+)", patch)):
+        assert re.search(r"\b(def|val) %s\b" % m, codec), m
+    # constructor arity: (shuffleId, mapId, numPartitions, createBlock)
+    assert re.search(r"class S3GpuMapOutput\(shuffleId: Int, mapId: Long, numPartitions: Int, createBlock: \(\) => OutputStream\)", out_cls)
+    assert len(re.findall(r"new S3GpuMapOutput\(", patch)) == 2
+
+
+def test_shim_positions_are_long_and_close_is_idempotent():
+    """no Int arithmetic on staging positions, pooled buffers returned once."""
+    out_cls = _read(SHIM, "S3GpuMapOutput.scala")
+    assert "staging.position() + len" not in out_cls
+    assert "MaxBuffer" in out_cls and "flush(endOfPartition = false)" in out_cls
+    dec = _read(SHIM, "S3GpuBlockDecoder.scala")
+    assert "compareAndSet(false, true)" in dec
+    assert "hostFree" in out_cls  # the pool gives surplus buffers back
