@@ -80,6 +80,7 @@ def parse_args():
                     help="after the headline, run short (3-step) passes of the other BASELINE.json configurations and attach "
                          "them as `secondary` to the JSON line (default: on for the plain N=1 headline command)")
     ap.add_argument("--no-secondary", dest="secondary", action="store_false")
+    ap.add_argument("--host-path-only", action="store_true", help="run only the host-buffer leg (run_host_path) and print it")
     ap.add_argument("--dry-run", action="store_true",
                     help="no timing: every rank reports (rank, local rank, device, its map ids); rank 0 checks that "
                          "mapId % nGPU covers every map task exactly once and prints the table as one JSON line "
@@ -543,8 +544,87 @@ def run_secondaries(args, rank: int, local_rank: int):
             "wall_s": round(time.perf_counter() - t0, 2),
         }
         _GEN_CACHE.pop(("skew", 1, 0, mib << 20), None)
+    t0 = time.perf_counter()
+    try:
+        res["host_path"] = run_host_path(args, local_rank)
+        res["host_path"]["wall_s"] = round(time.perf_counter() - t0, 2)
+    except Exception as e:
+        res["host_path"] = {"error": repr(e)}
     res["wall_s_total"] = round(time.perf_counter() - t_all, 2)
     return res
+
+
+def run_host_path(args, local_rank: int):
+    """The path a Spark executor gets: host buffers in, host buffers out, through the batched
+    host entry points the JNI shim binds (s3s_compress_map_outputs_batch / s3s_decompress_ranges_batch) — PCIe
+    inclusive, NEVER the headline `value`.  Page-locked buffers (s3s_host_alloc), the headline's TeraSort map outputs,
+    1 / 2 / 4 task threads with one context each; every thread passes all its map tasks in one call."""
+    import s3shuffle
+
+    workload, maps, steps = "terasort-10g-200p-lz4", 8, 3
+    codec_id, algo_id = s3shuffle.CODEC_LZ4, s3shuffle.CHECKSUM_ADLER32
+    outs = [make_map_output(workload, m, args.map_mib << 20) for m in range(maps)]
+    probe = s3shuffle.Codec(local_rank)
+    src, dst, caps = [], [], []
+    for data, offs in outs:
+        b = s3shuffle.PinnedBuffer(data.size)
+        b.array[:] = data
+        src.append(b)
+        caps.append(probe.max_compressed_size(codec_id, offs))
+        dst.append(s3shuffle.PinnedBuffer(caps[-1]))
+    probe.close()
+    u_total = sum(int(d.size) for d, _ in outs)
+    totals, images = [0] * maps, [None] * maps
+
+    def timed(n_threads, fn):
+        codecs = [s3shuffle.Codec(local_rank) for _ in range(n_threads)]
+
+        def worker(tid, n):
+            mine = list(range(tid, maps, n_threads))
+            for _ in range(n):
+                fn(codecs[tid], mine)
+
+        def run(n):
+            ths = [threading.Thread(target=worker, args=(j, n)) for j in range(n_threads)]
+            [t.start() for t in ths]
+            [t.join() for t in ths]
+
+        run(1)
+        t0 = time.perf_counter()
+        run(steps)
+        dt = time.perf_counter() - t0
+        for c in codecs:
+            c.close()
+        return round(u_total * steps / dt / 1e9, 3)
+
+    def do_compress(c, mine):
+        res = c.compress_map_outputs_batch(codec_id, algo_id, [(src[i].ptr, outs[i][1], dst[i].ptr, caps[i]) for i in mine])
+        for i, r in zip(mine, res):
+            totals[i], images[i] = r[0], (r[1], r[2])
+
+    comp = {str(t): timed(t, do_compress) for t in (1, 2, 4)}
+    c_total = sum(totals)
+
+    def do_decompress(c, mine):  # decoded bytes land in the source buffers (same content)
+        res = c.decompress_ranges_batch(codec_id, algo_id, [(dst[i].ptr, totals[i], images[i][0], images[i][1], src[i].ptr,
+                                                             int(outs[i][0].size)) for i in mine])
+        assert all(r[0] == 0 and r[1] == outs[i][0].size for i, r in zip(mine, res))
+
+    for b in src:
+        b.array[:] = 0
+    dec = {str(t): timed(t, do_decompress) for t in (1, 2)}
+    ok = all(np.array_equal(src[i].array[:outs[i][0].size], outs[i][0]) for i in range(maps))
+    for b in src + dst:
+        b.free()
+    return {
+        "what": "host (page-locked) buffers in and out through s3s_compress_map_outputs_batch / s3s_decompress_ranges_batch: "
+                "the figure a Spark executor gets through the JNI shim; PCIe-inclusive, not the headline value",
+        "workload": workload, "map_tasks": maps, "map_task_bytes": int(outs[0][0].size), "steps": steps, "warmup": 1,
+        "unit": "GB/s of uncompressed bytes", "compress_by_task_threads": comp, "verify_decompress_by_task_threads": dec,
+        "pcie_bytes_per_step": {"compress": {"host_to_device": u_total, "device_to_host": c_total},
+                                "decompress": {"host_to_device": c_total, "device_to_host": u_total}},
+        "round_trip_bit_exact": bool(ok),
+    }
 
 
 def main():
@@ -581,6 +661,9 @@ def main():
         dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         dist = dist_mod
 
+    if args.host_path_only:
+        print(json.dumps({"host_path": run_host_path(args, local_rank)}), flush=True)
+        return
     out = run_workload(args, rank, local_rank, world, dist)
     if rank == 0 and world == 1 and args.secondary and not args.dry_run:
         out["secondary"] = run_secondaries(args, rank, local_rank)

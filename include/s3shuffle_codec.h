@@ -66,9 +66,10 @@
 extern "C" {
 #endif
 
-#define S3S_ABI_VERSION 4 /* 2: + segments entry points, page-locked staging, tuning options 6, 7;
+#define S3S_ABI_VERSION 5 /* 2: + segments entry points, page-locked staging, tuning options 6, 7;
                              3: + s3s_compress_map_outputs_batch_device;
-                             4: + s3s_decompress_ranges_batch_device; decode variants {3, 4}, LZ4 parses {1, 9, 10} */
+                             4: + s3s_decompress_ranges_batch_device; decode variants {3, 4}, LZ4 parses {1, 9, 10};
+                             5: + s3s_compress_map_outputs_batch / s3s_decompress_ranges_batch (host buffers) */
 
 /* spark.io.compression.codec (only when spark.shuffle.compress=true) */
 enum { S3S_CODEC_NONE = 0, S3S_CODEC_LZ4 = 1, S3S_CODEC_SNAPPY = 2 };
@@ -185,6 +186,17 @@ typedef struct s3s_map_task {
 int s3s_compress_map_outputs_batch_device(s3s_ctx* ctx, int codec, int checksum_algo,
                                           s3s_map_task* tasks, int32_t n_tasks);
 
+/* The same batch for HOST buffers — the form a Spark executor reaches through the JNI shim (the reference's
+ * call sites hold heap / direct buffers: shuffle/S3ShuffleMapOutputWriter.scala:91-118, 168-202).  In this
+ * variant `d_src` / `d_dst` of every task are HOST addresses (page-locked memory from s3s_host_alloc moves by
+ * plain DMA; pageable memory works through the runtime's bounce buffers).  The tasks run as a pipeline over
+ * groups of ~64 MiB: the upload of group g+1 and the download of group g-1 are in flight while group g is
+ * compressed, so one call is bound by the slower of PCIe host->device (uncompressed bytes) and the codec.
+ * Results per task are exactly those of s3s_compress_map_output.  A single task takes that entry point's
+ * own chunked upload overlap. */
+int s3s_compress_map_outputs_batch(s3s_ctx* ctx, int codec, int checksum_algo, s3s_map_task* tasks,
+                                   int32_t n_tasks);
+
 /* ---- checksum only ---------------------------------------------------------------------- */
 /* out[i] = checksum(data[offsets[i], offsets[i+1])) for i in [0, n). */
 int s3s_checksum_ranges(s3s_ctx* ctx, int checksum_algo, const uint8_t* data,
@@ -228,6 +240,13 @@ typedef struct s3s_fetch_range {
 } s3s_fetch_range;
 int s3s_decompress_ranges_batch_device(s3s_ctx* ctx, int codec, int checksum_algo,
                                        s3s_fetch_range* ranges, int32_t n_ranges);
+
+/* Host-buffer form (storage/S3ShuffleReader.scala:98-110 holds the prefetcher's heap buffers): `d_comp` /
+ * `d_dst` of every range are HOST addresses; upload of the next group, decode of this one and download of the
+ * previous one overlap (groups of ~128 MiB decoded), so one call is bound by the slower of PCIe
+ * device->host (decoded bytes) and the decoder.  Results per range are those of s3s_decompress_range. */
+int s3s_decompress_ranges_batch(s3s_ctx* ctx, int codec, int checksum_algo, s3s_fetch_range* ranges,
+                                int32_t n_ranges);
 
 /* Multi-spill map tasks.  When a map task spilled N times, Spark's merge hands every partition to the
  * partition writer as the concatenation of N independently written pieces, and on the JVM each piece is

@@ -141,3 +141,111 @@ JNIEXPORT jint JNICALL FN(decompressRange)(JNIEnv* e, jclass c, jlong h, jint co
   (*e)->ReleaseIntArrayElements(e, outBadPartition, ob, 0);
   return rc;
 }
+
+/* ---- batched forms over host buffers: what S3GpuCommitQueue / the prefetcher hand over in ONE call ------------------
+ * (s3s_compress_map_outputs_batch / s3s_decompress_ranges_batch pipeline upload, codec and download over the tasks).
+ * Object arrays carry one entry per task: direct ByteBuffers and long[] of the same shapes as in the single-task calls. */
+#include <stdlib.h>
+
+JNIEXPORT jint JNICALL FN(compressMapOutputsBatch)(JNIEnv* e, jclass c, jlong h, jint codec, jint algo, jobjectArray src,
+                                                   jobjectArray srcOffsets, jobjectArray dst, jlongArray dstCap,
+                                                   jobjectArray outIndex, jobjectArray outChecksums, jlongArray outTotal,
+                                                   jintArray outStatus) {
+  (void)c;
+  const jsize n = (*e)->GetArrayLength(e, src);
+  s3s_map_task* t = (s3s_map_task*)calloc((size_t)(n > 0 ? n : 1), sizeof *t);
+  jlongArray* arrs = (jlongArray*)calloc((size_t)(n > 0 ? n : 1) * 3, sizeof *arrs);
+  if (!t || !arrs) {
+    free(t);
+    free(arrs);
+    return S3S_E_NOMEM;
+  }
+  jlong *cap = pin(e, dstCap), *tot = pin(e, outTotal);
+  jint* st = (*e)->GetIntArrayElements(e, outStatus, NULL);
+  for (jsize i = 0; i < n; i++) {
+    jlongArray so = (jlongArray)(*e)->GetObjectArrayElement(e, srcOffsets, i);
+    jlongArray oi = (jlongArray)(*e)->GetObjectArrayElement(e, outIndex, i);
+    jlongArray oc = outChecksums ? (jlongArray)(*e)->GetObjectArrayElement(e, outChecksums, i) : NULL;
+    arrs[3 * i] = so;
+    arrs[3 * i + 1] = oi;
+    arrs[3 * i + 2] = oc;
+    jobject sb = (*e)->GetObjectArrayElement(e, src, i), db = (*e)->GetObjectArrayElement(e, dst, i);
+    t[i].d_src = addr(e, sb); /* host addresses in the host-buffer batch */
+    t[i].d_dst = addr(e, db);
+    (*e)->DeleteLocalRef(e, sb);
+    (*e)->DeleteLocalRef(e, db);
+    t[i].src_offsets = (const int64_t*)pin(e, so);
+    t[i].num_partitions = (int32_t)((*e)->GetArrayLength(e, so) - 1);
+    t[i].dst_capacity = cap[i];
+    t[i].out_index = (int64_t*)pin(e, oi);
+    t[i].out_checksums = (int64_t*)pin(e, oc);
+  }
+  const int rc = s3s_compress_map_outputs_batch(CTX(h), codec, algo, t, (int32_t)n);
+  for (jsize i = 0; i < n; i++) {
+    tot[i] = t[i].out_total;
+    st[i] = t[i].status;
+    unpin(e, arrs[3 * i], (jlong*)t[i].src_offsets, JNI_ABORT);
+    unpin(e, arrs[3 * i + 1], (jlong*)t[i].out_index, 0);
+    unpin(e, arrs[3 * i + 2], (jlong*)t[i].out_checksums, 0);
+    (*e)->DeleteLocalRef(e, arrs[3 * i]);
+    (*e)->DeleteLocalRef(e, arrs[3 * i + 1]);
+    if (arrs[3 * i + 2]) (*e)->DeleteLocalRef(e, arrs[3 * i + 2]);
+  }
+  unpin(e, dstCap, cap, JNI_ABORT);
+  unpin(e, outTotal, tot, 0);
+  (*e)->ReleaseIntArrayElements(e, outStatus, st, 0);
+  free(arrs);
+  free(t);
+  return rc;
+}
+
+JNIEXPORT jint JNICALL FN(decompressRangesBatch)(JNIEnv* e, jclass c, jlong h, jint codec, jint algo, jobjectArray comp,
+                                                 jlongArray compLen, jobjectArray partOffsets, jobjectArray refChecksums,
+                                                 jobjectArray dst, jlongArray dstCap, jlongArray outLen,
+                                                 jintArray outBadPartition, jintArray outStatus) {
+  (void)c;
+  const jsize n = (*e)->GetArrayLength(e, comp);
+  s3s_fetch_range* r = (s3s_fetch_range*)calloc((size_t)(n > 0 ? n : 1), sizeof *r);
+  jlongArray* arrs = (jlongArray*)calloc((size_t)(n > 0 ? n : 1) * 2, sizeof *arrs);
+  if (!r || !arrs) {
+    free(r);
+    free(arrs);
+    return S3S_E_NOMEM;
+  }
+  jlong *cl = pin(e, compLen), *cap = pin(e, dstCap), *ol = pin(e, outLen);
+  jint *bad = (*e)->GetIntArrayElements(e, outBadPartition, NULL), *st = (*e)->GetIntArrayElements(e, outStatus, NULL);
+  for (jsize i = 0; i < n; i++) {
+    jlongArray po = (jlongArray)(*e)->GetObjectArrayElement(e, partOffsets, i);
+    jlongArray rs = refChecksums ? (jlongArray)(*e)->GetObjectArrayElement(e, refChecksums, i) : NULL;
+    arrs[2 * i] = po;
+    arrs[2 * i + 1] = rs;
+    jobject cb = (*e)->GetObjectArrayElement(e, comp, i), db = (*e)->GetObjectArrayElement(e, dst, i);
+    r[i].d_comp = addr(e, cb);
+    r[i].d_dst = addr(e, db);
+    (*e)->DeleteLocalRef(e, cb);
+    (*e)->DeleteLocalRef(e, db);
+    r[i].comp_len = cl[i];
+    r[i].part_offsets = (const int64_t*)pin(e, po);
+    r[i].ref_checksums = (const int64_t*)pin(e, rs);
+    r[i].num_partitions = (int32_t)((*e)->GetArrayLength(e, po) - 1);
+    r[i].dst_capacity = cap[i];
+  }
+  const int rc = s3s_decompress_ranges_batch(CTX(h), codec, algo, r, (int32_t)n);
+  for (jsize i = 0; i < n; i++) {
+    ol[i] = r[i].out_len;
+    bad[i] = r[i].bad_partition;
+    st[i] = r[i].status;
+    unpin(e, arrs[2 * i], (jlong*)r[i].part_offsets, JNI_ABORT);
+    unpin(e, arrs[2 * i + 1], (jlong*)r[i].ref_checksums, JNI_ABORT);
+    (*e)->DeleteLocalRef(e, arrs[2 * i]);
+    if (arrs[2 * i + 1]) (*e)->DeleteLocalRef(e, arrs[2 * i + 1]);
+  }
+  unpin(e, compLen, cl, JNI_ABORT);
+  unpin(e, dstCap, cap, JNI_ABORT);
+  unpin(e, outLen, ol, 0);
+  (*e)->ReleaseIntArrayElements(e, outBadPartition, bad, 0);
+  (*e)->ReleaseIntArrayElements(e, outStatus, st, 0);
+  free(arrs);
+  free(r);
+  return rc;
+}

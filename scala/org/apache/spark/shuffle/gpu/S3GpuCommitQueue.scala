@@ -1,0 +1,86 @@
+//
+// S3GpuCommitQueue — map tasks of one executor that reach commitAllPartitions (shuffle/S3ShuffleMapOutputWriter.scala:
+// 91-118) at about the same time share ONE library call.  A task thread alone drives the batched host entry point with
+// a single task (chunked upload under the codec kernels: ~28 GB/s host to host); several tasks in one call run as a
+// pipeline — upload of the next task, codec of this one, download of the previous one — at ~45 GB/s, the PCIe rate
+// (s3s_compress_map_outputs_batch, jni/s3s_jni.c compressMapOutputsBatch).  One daemon thread and one native context per
+// device; requests are taken in arrival order, at most spark.shuffle.s3.gpu.commitBatch (default 8) per call, and a
+// lone request is never held back waiting for company.
+//
+// NOT COMPILED IN THIS IMAGE (no JDK / scalac).
+//
+package org.apache.spark.shuffle.gpu
+
+import java.nio.ByteBuffer
+import java.util.concurrent.{ConcurrentHashMap, CountDownLatch, LinkedBlockingQueue}
+
+import org.apache.spark.shuffle.helper.S3ShuffleDispatcher
+
+object S3GpuCommitQueue {
+  final class Request(val codec: Int, val algo: Int, val src: ByteBuffer, val srcOffsets: Array[Long], val dst: ByteBuffer,
+                      val dstCap: Long, val index: Array[Long], val sums: Array[Long]) {
+    @volatile var total = 0L
+    @volatile var rc = S3SCodec.OK
+    @volatile var error: String = ""
+    private[gpu] val done = new CountDownLatch(1)
+  }
+
+  private final class Worker(device: Int) extends Thread(s"s3-gpu-commit-$device") {
+    setDaemon(true)
+    val queue = new LinkedBlockingQueue[Request]()
+    private val maxBatch = math.max(S3ShuffleDispatcher.get.gpuCommitBatch, 1)
+
+    override def run(): Unit = {
+      val ctx = S3SCodec.forThread(device) // this thread's own context
+      val batch = new java.util.ArrayList[Request]()
+      while (true) {
+        batch.clear()
+        batch.add(queue.take())
+        queue.drainTo(batch, maxBatch - 1)
+        // one call per (codec, checksum) pair: in practice one pair per application
+        val first = batch.get(0)
+        val same = new scala.collection.mutable.ArrayBuffer[Request]()
+        val it = batch.iterator()
+        while (it.hasNext) { val r = it.next(); if (r.codec == first.codec && r.algo == first.algo) same += r else queue.put(r) }
+        val n = same.length
+        val totals = new Array[Long](n)
+        val status = new Array[Int](n)
+        try {
+          val rc = S3SCodec.compressMapOutputsBatch(ctx, first.codec, first.algo, same.map(_.src).toArray,
+            same.map(_.srcOffsets).toArray, same.map(_.dst).toArray, same.map(_.dstCap).toArray, same.map(_.index).toArray,
+            if (first.algo == S3SCodec.CHECKSUM_NONE) null else same.map(_.sums).toArray, totals, status)
+          val why = if (rc != S3SCodec.OK) S3SCodec.lastError(ctx) else ""
+          var i = 0
+          while (i < n) {
+            same(i).total = totals(i)
+            // a call-level failure (HIP error, bad argument) fails every request of the call; otherwise each has its own status
+            same(i).rc = if (rc != S3SCodec.OK && status(i) == S3SCodec.OK && rc != S3SCodec.E_CAPACITY) rc else status(i)
+            same(i).error = why
+            i += 1
+          }
+        } catch {
+          case t: Throwable => same.foreach { r => r.rc = S3SCodec.E_HIP; r.error = t.toString }
+        } finally same.foreach(_.done.countDown())
+      }
+    }
+  }
+
+  private val workers = new ConcurrentHashMap[Int, Worker]()
+
+  private def worker(device: Int): Worker = {
+    var w = workers.get(device)
+    if (w == null) {
+      val fresh = new Worker(device)
+      w = workers.putIfAbsent(device, fresh)
+      if (w == null) { fresh.start(); w = fresh }
+    }
+    w
+  }
+
+  /** Blocks the task thread until its request has been compressed (possibly together with other tasks' requests). */
+  def compress(device: Int, r: Request): Request = {
+    worker(device).queue.put(r)
+    r.done.await()
+    r
+  }
+}

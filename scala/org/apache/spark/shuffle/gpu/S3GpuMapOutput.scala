@@ -32,7 +32,8 @@ import org.apache.spark.shuffle.helper.{S3ShuffleDispatcher, S3ShuffleHelper}
 
 class S3GpuMapOutput(shuffleId: Int, mapId: Long, numPartitions: Int, createBlock: () => OutputStream) {
   private val dispatcher = S3ShuffleDispatcher.get
-  private val ctx = S3SCodec.forThread(S3SCodec.deviceFor(mapId, S3SCodec.deviceCount()))
+  private val device = S3SCodec.deviceFor(mapId, S3SCodec.deviceCount())
+  private val ctx = S3SCodec.forThread(device)
   private val codec = S3SCodec.codecId(dispatcher.gpuCodec)
   private val algo = S3SCodec.checksumId(dispatcher.checksumEnabled, dispatcher.checksumAlgorithm)
 
@@ -115,9 +116,16 @@ class S3GpuMapOutput(shuffleId: Int, mapId: Long, numPartitions: Int, createBloc
     val sums = new Array[Long](n)
     val total = new Array[Long](1)
     try {
-      val rc = S3SCodec.compressMapOutput(ctx, codec, algo, staging, offs, n, out, cap, index,
-        if (algo == S3SCodec.CHECKSUM_NONE) null else sums, total)
-      S3SCodec.check(ctx, rc, s"shuffle_${shuffleId}_${mapId}_0.data")
+      val what = s"shuffle_${shuffleId}_${mapId}_0.data"
+      if (dispatcher.gpuCommitBatch > 1) { // commits of concurrent tasks share one pipelined call (S3GpuCommitQueue)
+        val r = S3GpuCommitQueue.compress(device, new S3GpuCommitQueue.Request(codec, algo, staging, offs, out, cap, index, sums))
+        if (r.rc != S3SCodec.OK) S3SCodec.raise(r.rc, r.error, what)
+        total(0) = r.total
+      } else {
+        val rc = S3SCodec.compressMapOutput(ctx, codec, algo, staging, offs, n, out, cap, index,
+          if (algo == S3SCodec.CHECKSUM_NONE) null else sums, total)
+        S3SCodec.check(ctx, rc, what)
+      }
       var i = 0
       while (i < n) { // per partition: bytes, length, checksum (a split partition's checksum runs on the JVM)
         val p = groupFirst + i

@@ -24,9 +24,9 @@ object S3SCodec {
   // ---- constants of include/s3shuffle_codec.h ----------------------------------------------------------------
   val CODEC_NONE = 0; val CODEC_LZ4 = 1; val CODEC_SNAPPY = 2
   val CHECKSUM_NONE = 0; val CHECKSUM_ADLER32 = 1; val CHECKSUM_CRC32 = 2
-  val OK = 0; val E_INVALID = -1; val E_CAPACITY = -2; val E_BAD_FRAME = -3; val E_CHECKSUM = -4
+  val OK = 0; val E_INVALID = -1; val E_CAPACITY = -2; val E_BAD_FRAME = -3; val E_CHECKSUM = -4; val E_HIP = -5
   val OPT_LZ4_BLOCK_SIZE = 1; val OPT_SNAPPY_BLOCK_SIZE = 2
-  val ABI_VERSION = 4
+  val ABI_VERSION = 5
 
   // ---- native entry points (jni/s3s_jni.c, one line each) -------------------------------------------------------
   @native def abiVersion(): Int
@@ -51,6 +51,16 @@ object S3SCodec {
   @native def decompressRange(handle: Long, codec: Int, algo: Int, comp: ByteBuffer, compLen: Long,
                               partOffsets: Array[Long], refChecksums: Array[Long], nparts: Int, dst: ByteBuffer,
                               dstCap: Long, outLen: Array[Long], outBadPartition: Array[Int]): Int
+
+  // batched forms over host buffers (one entry per task / range; the library pipelines upload, codec and download)
+  @native def compressMapOutputsBatch(handle: Long, codec: Int, algo: Int, src: Array[ByteBuffer],
+                                      srcOffsets: Array[Array[Long]], dst: Array[ByteBuffer], dstCap: Array[Long],
+                                      outIndex: Array[Array[Long]], outChecksums: Array[Array[Long]],
+                                      outTotal: Array[Long], outStatus: Array[Int]): Int
+  @native def decompressRangesBatch(handle: Long, codec: Int, algo: Int, comp: Array[ByteBuffer], compLen: Array[Long],
+                                    partOffsets: Array[Array[Long]], refChecksums: Array[Array[Long]],
+                                    dst: Array[ByteBuffer], dstCap: Array[Long], outLen: Array[Long],
+                                    outBadPartition: Array[Int], outStatus: Array[Int]): Int
 
   // ---- loading + per-thread contexts -------------------------------------------------------------------------------
   @volatile private var loaded = false
@@ -85,12 +95,15 @@ object S3SCodec {
   /** mapId % nGpu — S3ShuffleDispatcher.getPath shards folder prefixes the same way. */
   def deviceFor(mapId: Long, devices: Int): Int = (mapId % math.max(devices, 1)).toInt
 
-  def check(handle: Long, rc: Int, what: => String, badPartition: Int = -1): Unit = rc match {
-    case OK => ()
-    case E_INVALID => throw new RuntimeException(s"Precondition: ${lastError(handle)}")
+  def check(handle: Long, rc: Int, what: => String, badPartition: Int = -1): Unit =
+    if (rc != OK) raise(rc, lastError(handle), what, badPartition)
+
+  /** The exception the reference raises for this condition today (message of the context that ran the call). */
+  def raise(rc: Int, message: String, what: String, badPartition: Int = -1): Nothing = rc match {
+    case E_INVALID => throw new RuntimeException(s"Precondition: $message")
     case E_CHECKSUM => throw new SparkException(s"Invalid checksum detected for $what (partition $badPartition)")
     case E_BAD_FRAME => throw new IOException("Stream is corrupted")
-    case _ => throw new IOException(s"$what: ${lastError(handle)} (code $rc)")
+    case _ => throw new IOException(s"$what: $message (code $rc)")
   }
 
   /** lz4 and snappy run on the GPU; zstd and lzf keep the reference's JVM stream stack (DESIGN.md §7.1): the patched

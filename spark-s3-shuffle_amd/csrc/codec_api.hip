@@ -77,6 +77,8 @@ void s3s_destroy(s3s_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
+  if (ctx->hb_in) hipStreamSynchronize(ctx->hb_in);
+  if (ctx->hb_out) hipStreamSynchronize(ctx->hb_out);
   for (auto& b : ctx->buf)
     if (b.p) hipFree(b.p);
   if (ctx->h_stage) hipHostFree(ctx->h_stage);
@@ -88,6 +90,12 @@ void s3s_destroy(s3s_ctx* ctx) {
   for (auto& ev : ctx->ev_up)
     if (ev) hipEventDestroy(ev);
   if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
+  for (int i = 0; i < 2; i++) {
+    if (ctx->hb_ev_in[i]) hipEventDestroy(ctx->hb_ev_in[i]);
+    if (ctx->hb_ev_out[i]) hipEventDestroy(ctx->hb_ev_out[i]);
+  }
+  if (ctx->hb_in) hipStreamDestroy(ctx->hb_in);
+  if (ctx->hb_out) hipStreamDestroy(ctx->hb_out);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }

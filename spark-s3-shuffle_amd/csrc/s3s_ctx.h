@@ -22,7 +22,9 @@ struct DevBuf {
 enum BufId {
   B_ITEMS, B_PART_FIRST, B_SLOTS, B_ITEM_SIZE, B_ITEM_OFF, B_INDEX, B_SUMS, B_SEG_START,
   B_PARTIAL, B_STATUS, B_TABLES, B_SRC, B_DST, B_OFFSETS, B_FRAMES, B_PART_NFRAMES,
-  B_FRAME_OUT, B_REF_SUMS, B_ITEM_CHECK, B_RANGES, B_TILE_RANGE, B_COUNT
+  B_FRAME_OUT, B_REF_SUMS, B_ITEM_CHECK, B_RANGES, B_TILE_RANGE,
+  B_HB_IN0, B_HB_IN1, B_HB_OUT0, B_HB_OUT1,  // host-buffer batch pipeline (host_batch.hip): double-buffered device staging
+  B_COUNT
 };
 
 }  // namespace s3s
@@ -56,6 +58,9 @@ struct s3s_ctx {
   hipStream_t copy_stream = nullptr;
   std::vector<hipEvent_t> ev_up;
   const uint8_t* up_host = nullptr;  // host source of d_src[0, total_u), or nullptr (source already on the device)
+  // host-buffer batch entry points (host_batch.hip): one DMA stream per PCIe direction next to the compute stream
+  hipStream_t hb_in = nullptr, hb_out = nullptr;
+  hipEvent_t hb_ev_in[2] = {nullptr, nullptr}, hb_ev_out[2] = {nullptr, nullptr};
   double stage_ms[S3S_STAGE_COUNT] = {};
 };
 

@@ -128,6 +128,8 @@ def load_library() -> ctypes.CDLL:
                                                           ctypes.c_int32]
     lib.s3s_decompress_ranges_batch_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(FetchRange),
                                                        ctypes.c_int32]
+    lib.s3s_compress_map_outputs_batch.argtypes = lib.s3s_compress_map_outputs_batch_device.argtypes
+    lib.s3s_decompress_ranges_batch.argtypes = lib.s3s_decompress_ranges_batch_device.argtypes
     lib.s3s_host_alloc.restype = vp
     lib.s3s_host_alloc.argtypes = [ctypes.c_int64]
     lib.s3s_host_free.argtypes = [vp]
@@ -267,7 +269,13 @@ class Codec:
         self._check(rc)
         return int(total.value), index, (sums[:n] if checksum != CHECKSUM_NONE else None)
 
-    def compress_map_outputs_batch_device(self, codec: int, checksum: int, tasks):
+    def compress_map_outputs_batch(self, codec: int, checksum: int, tasks):
+        """Batched HOST-buffer form (what the JNI shim binds): `tasks` = [(src_address, src_offsets, dst_address,
+        dst_capacity), ...] with host addresses (e.g. `PinnedBuffer.address`, or `ndarray.ctypes.data`) -> per task
+        (total bytes, index[N+1], checksums[N] or None).  Upload, codec and download of consecutive groups overlap."""
+        return self.compress_map_outputs_batch_device(codec, checksum, tasks, _host=True)
+
+    def compress_map_outputs_batch_device(self, codec: int, checksum: int, tasks, _host: bool = False):
         """Batched device form: `tasks` = [(d_src, src_offsets, d_dst, dst_capacity), ...] -> per task
         (total bytes, index[N+1], checksums[N] or None).  One codec launch and one stream sync for all."""
         arr = (MapTask * len(tasks))()
@@ -285,7 +293,8 @@ class Codec:
             arr[i].dst_capacity = int(cap)
             arr[i].out_index = _p64(index)
             arr[i].out_checksums = _p64(sums) if checksum != CHECKSUM_NONE else None
-        rc = self._lib.s3s_compress_map_outputs_batch_device(self._h, codec, checksum, arr, len(tasks))
+        fn = self._lib.s3s_compress_map_outputs_batch if _host else self._lib.s3s_compress_map_outputs_batch_device
+        rc = fn(self._h, codec, checksum, arr, len(tasks))
         self._check(rc)
         return [(int(arr[i].out_total), k[1], (k[2][:k[3]] if checksum != CHECKSUM_NONE else None))
                 for i, k in enumerate(keep)]
@@ -351,7 +360,13 @@ class Codec:
 
 
 
-    def decompress_ranges_batch_device(self, codec: int, checksum: int, ranges, raise_on_error: bool = True):
+    def decompress_ranges_batch(self, codec: int, checksum: int, ranges, raise_on_error: bool = True):
+        """Batched HOST-buffer form: `ranges` = [(comp_address, comp_len, part_offsets, ref_checksums, dst_address,
+        dst_capacity), ...] with host addresses -> per range (status, decoded bytes, bad partition)."""
+        return self.decompress_ranges_batch_device(codec, checksum, ranges, raise_on_error, _host=True)
+
+    def decompress_ranges_batch_device(self, codec: int, checksum: int, ranges, raise_on_error: bool = True,
+                                       _host: bool = False):
         """Batched device form: `ranges` = [(d_comp, comp_len, part_offsets, ref_checksums, d_dst, dst_capacity), ...]
         -> per range (status, decoded bytes, bad partition).  One decode launch for all, three stream syncs."""
         arr = (FetchRange * len(ranges))()
@@ -367,7 +382,8 @@ class Codec:
             arr[i].num_partitions = len(offs) - 1
             arr[i].d_dst = d_dst
             arr[i].dst_capacity = int(cap)
-        rc = self._lib.s3s_decompress_ranges_batch_device(self._h, codec, checksum, arr, len(ranges))
+        fn = self._lib.s3s_decompress_ranges_batch if _host else self._lib.s3s_decompress_ranges_batch_device
+        rc = fn(self._h, codec, checksum, arr, len(ranges))
         out = [(int(arr[i].status), int(arr[i].out_len), int(arr[i].bad_partition)) for i in range(len(ranges))]
         if raise_on_error:
             bad = next((i for i, o in enumerate(out) if o[0] != 0), -1)

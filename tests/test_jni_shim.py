@@ -19,7 +19,8 @@ def test_jni_translation_unit_type_checks_against_the_header(tmp_path):
     syms = subprocess.run(["nm", "--defined-only", str(obj)], check=True, capture_output=True, text=True).stdout
     exported = set(re.findall(r"Java_org_apache_spark_shuffle_gpu_S3SCodec_(\w+)", syms))
     assert {"create", "destroy", "compressMapOutput", "compressMapOutputSegments", "decompressRange",
-            "checksumRanges", "maxCompressedSize", "decompressedSize", "hostAlloc", "hostFree", "lastError"} <= exported
+            "checksumRanges", "maxCompressedSize", "decompressedSize", "hostAlloc", "hostFree", "lastError",
+            "compressMapOutputsBatch", "decompressRangesBatch"} <= exported
     # every C-ABI function the wrappers call exists in the header (the compile above checked the types)
     used = set(re.findall(r"\b(s3s_[a-z0-9_]+)\s*\(", open(JNI_C).read()))
     header = open(os.path.join(ROOT, "include", "s3shuffle_codec.h")).read()
