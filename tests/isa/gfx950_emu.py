@@ -1268,7 +1268,8 @@ class Program:
         w.wv32(i.ops[0], cnt + w.rv32(i.ops[2]))
 
     def x_ds_bpermute_b32(self, w, i):
-        addr = (w.v[i.ops[1][1]] >> np.uint32(2)) & np.uint32(63)
+        off = np.uint32(int(i.mods.get("offset", "0"), 0))  # (added to the byte address before the lane is taken)
+        addr = ((w.v[i.ops[1][1]] + off) >> np.uint32(2)) & np.uint32(63)
         src = w.v[i.ops[2][1]]
         e = w.em()
         vals = np.where(e[addr], src[addr], np.uint32(0))
