@@ -132,8 +132,10 @@ def test_compiled_kernels_on_the_bench_workloads(oracle):
         assert bytes(slot[32:32 + sz - 4]) == bytes(oracle.snappy_compress_block(c))
         counts.append(sum(v[0] for v in prof.values()))
     print("instructions per block: lz4 terasort %d, snappy terasort %d, lz4 wide rows %d, snappy wide rows %d" % tuple(counts))
-    # end of round 2 (r02k): 163.2k / 161.9k / 330.5k / 319.9k on these four blocks; a change that adds ~3 % shows up here
-    assert counts[0] < 168_000 and counts[1] < 167_000 and counts[2] < 340_000 and counts[3] < 330_000, counts
+    # end of round 2 (r02k): 163.2k / 161.9k / 330.5k / 319.9k on these four blocks; round 3 (stream bytes through one
+    # 80-byte load + ds_bpermute instead of a 64-lane x 16-byte load: + 13 instructions per LZ4 window, - 34 % of the
+    # kernel's L1 lookups): 169.3k / 161.9k / 336.6k / 319.9k; a change that adds ~3 % shows up here
+    assert counts[0] < 174_000 and counts[1] < 167_000 and counts[2] < 346_000 and counts[3] < 330_000, counts
 
 
 def test_window_blocks_take_their_rare_paths(oracle):
