@@ -48,7 +48,113 @@ WORKLOADS = {
     "tpcds-wide-100g-200p-lz4": ("tpcds", 200, "lz4", "adler32"),         # configs[2] rows under the default codec
     "terasort-100g-2000p-lz4-crc32": ("terasort", 2000, "lz4", "crc32"),  # configs[3]
     "skew-1part-lz4": ("skew", 1, "lz4", "adler32"),                  # configs[4] (use --direction decompress)
+    "terasort-10g-200p-zstd": ("terasort", 200, "zstd", "adler32"),   # reduce side only (--direction decompress)
 }
+
+
+# ---- Zstandard inputs (reduce side only): the map outputs a JVM writer produces with spark.io.compression.codec=zstd ----
+# libzstd is a third-party library of the image (the one zstd-jni wraps); it is used here to BUILD the benchmark's input
+# and as the CPU baseline, exactly like numpy builds the uncompressed inputs — the product never links it.
+class _ZBuf(__import__("ctypes").Structure):
+    _fields_ = [("p", __import__("ctypes").c_void_p), ("size", __import__("ctypes").c_size_t), ("pos", __import__("ctypes").c_size_t)]
+
+
+def _libzstd():
+    import ctypes
+
+    z = ctypes.CDLL("libzstd.so.1")
+    z.ZSTD_compressBound.restype = ctypes.c_size_t
+    z.ZSTD_compressBound.argtypes = [ctypes.c_size_t]
+    z.ZSTD_isError.restype = ctypes.c_uint
+    z.ZSTD_isError.argtypes = [ctypes.c_size_t]
+    z.ZSTD_createCCtx.restype = ctypes.c_void_p
+    z.ZSTD_freeCCtx.argtypes = [ctypes.c_void_p]
+    z.ZSTD_CCtx_setParameter.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    z.ZSTD_compressStream2.restype = ctypes.c_size_t
+    z.ZSTD_compressStream2.argtypes = [ctypes.c_void_p, ctypes.POINTER(_ZBuf), ctypes.POINTER(_ZBuf), ctypes.c_int]
+    z.ZSTD_decompress.restype = ctypes.c_size_t
+    z.ZSTD_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+    return z
+
+
+def zstd_map_output_image(data, offs, algo_name: str):
+    """(.data image, index, checksums) of one map task under ZStdCompressionCodec: one streaming frame (level 1, 32 KiB
+    writes, no content size) per non-empty partition; checksums over the compressed bytes (zlib's Adler32 / CRC32)."""
+    import ctypes
+    import zlib
+
+    z = _libzstd()
+    n = len(offs) - 1
+    cctx = z.ZSTD_createCCtx()
+    parts = []
+    try:
+        for p in range(n):
+            a, b = int(offs[p]), int(offs[p + 1])
+            if b == a:
+                parts.append(np.zeros(0, np.uint8))
+                continue
+            z.ZSTD_CCtx_setParameter(cctx, 100, 1)  # ZSTD_c_compressionLevel = spark.io.compression.zstd.level default
+            cap = int(z.ZSTD_compressBound(b - a)) + 1024
+            out = np.empty(cap, np.uint8)
+            ob = _ZBuf(out.ctypes.data, cap, 0)
+            pos = a
+            while pos < b:
+                k = min(32768, b - pos)
+                ib = _ZBuf(data.ctypes.data + pos, k, 0)
+                while ib.pos < ib.size:
+                    assert not z.ZSTD_isError(z.ZSTD_compressStream2(cctx, ctypes.byref(ob), ctypes.byref(ib), 0))
+                pos += k
+            ib = _ZBuf(data.ctypes.data, 0, 0)
+            while z.ZSTD_compressStream2(cctx, ctypes.byref(ob), ctypes.byref(ib), 2) != 0:
+                pass
+            parts.append(out[: ob.pos].copy())
+    finally:
+        z.ZSTD_freeCCtx(cctx)
+    index = np.zeros(n + 1, np.int64)
+    np.cumsum([q.size for q in parts], out=index[1:])
+    fn = zlib.adler32 if algo_name == "adler32" else zlib.crc32
+    sums = np.array([fn(q) & 0xFFFFFFFF for q in parts], np.int64)
+    return (np.concatenate(parts) if parts else np.zeros(0, np.uint8)), index, sums
+
+
+def cpu_baseline_zstd_decompress(workload: str, target_s: float, map_mib: int):
+    """libzstd's own decoder on the host cores, one partition frame per call, all usable cores (ctypes drops the GIL);
+    per-partition checksum validation with zlib in front — what the JVM reader does per task, without JVM / JNI overheads."""
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+
+    gen, nparts, codec, algo = WORKLOADS[workload]
+    cores = usable_cores()
+    data, offs = make_map_output(workload, 0, min(map_mib, 256) << 20)
+    img, index, sums = zstd_map_output_image(data, offs, algo)
+    z = _libzstd()
+    fn = zlib.adler32 if algo == "adler32" else zlib.crc32
+
+    def one_task(_):
+        out = np.empty(data.size, np.uint8)
+        for p in range(len(offs) - 1):
+            a, b = int(index[p]), int(index[p + 1])
+            if b == a:
+                continue
+            assert fn(img[a:b]) & 0xFFFFFFFF == sums[p]  # (buffer protocol: no copy, zlib drops the GIL)
+            z.ZSTD_decompress(out.ctypes.data + int(offs[p]), int(offs[p + 1] - offs[p]), img.ctypes.data + a, b - a)
+        return out
+
+    t0 = time.perf_counter()
+    one_task(0)
+    s1 = time.perf_counter() - t0
+    reps = max(1, min(50, int(target_s / max(s1, 1e-3))))
+    with ThreadPoolExecutor(cores) as ex:
+        t0 = time.perf_counter()
+        list(ex.map(one_task, range(cores * reps)))
+        s = time.perf_counter() - t0
+    return {
+        "value": round(data.size * cores * reps / s / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "reference",
+        "sample": f"{cores} threads x {reps} reps x one whole {min(map_mib, 256)} MiB map task ({nparts} partitions = {nparts} zstd frames), "
+                  f"zlib {algo} validation + libzstd 1.4.8 ZSTD_decompress per frame (the library zstd-jni wraps); JVM/JNI overheads "
+                  f"not included; os.cpu_count()={os.cpu_count()}, cgroup/affinity limit={cores}",
+        "single_thread_GBps": round(data.size / s1 / 1e9, 3), "wall_s": round(s, 2),
+    }
 
 
 def parse_args():
@@ -234,8 +340,10 @@ def run_workload(args, rank: int, local_rank: int, world: int, dist):
     from s3shuffle import sharding
 
     gen, nparts, codec_name, algo_name = WORKLOADS[args.workload]
-    codec_id = s3shuffle.CODEC_LZ4 if codec_name == "lz4" else s3shuffle.CODEC_SNAPPY
+    codec_id = {"lz4": s3shuffle.CODEC_LZ4, "snappy": s3shuffle.CODEC_SNAPPY, "zstd": s3shuffle.CODEC_ZSTD}[codec_name]
     algo_id = {"adler32": s3shuffle.CHECKSUM_ADLER32, "crc32": s3shuffle.CHECKSUM_CRC32}[algo_name]
+    if codec_name == "zstd" and args.direction != "decompress":
+        raise SystemExit("zstd is decode-only on the GPU path (compression stays on the JVM codec): use --direction decompress")
 
     # ---- this rank's shard: map tasks with mapId % nGPU == rank --------------------------------
     map_ids = sharding.map_ids_for_rank(rank, world, args.maps_per_gpu)
@@ -261,9 +369,19 @@ def run_workload(args, rank: int, local_rank: int, world: int, dist):
             c.set_option(s3shuffle.codec.OPT_LZ4_VARIANT, args.lz4_variant)
         if args.lz4_decode_variant >= 0:
             c.set_option(s3shuffle.codec.OPT_LZ4_DECODE_VARIANT, args.lz4_decode_variant)
-    for (data, offs) in outputs:
+    zstd_images = None
+    if codec_name == "zstd":  # the JVM-written objects: built on the host with libzstd (input generation, untimed)
+        zstd_images = [None] * len(outputs)
+
+        def _zimg(i):
+            zstd_images[i] = zstd_map_output_image(outputs[i][0], outputs[i][1], algo_name)
+
+        zt = [threading.Thread(target=_zimg, args=(i,)) for i in range(len(outputs))]
+        [t.start() for t in zt]
+        [t.join() for t in zt]
+    for ti, (data, offs) in enumerate(outputs):
         d_src = torch.from_numpy(data).to(dev)
-        cap = codecs[0].max_compressed_size(codec_id, offs)
+        cap = codecs[0].max_compressed_size(codec_id, offs) if zstd_images is None else int(zstd_images[ti][0].size) + 64
         d_dst = torch.empty(cap, dtype=torch.uint8, device=dev)
         tasks.append({"src": d_src, "dst": d_dst, "offs": offs, "cap": cap, "u": int(data.size)})
     torch.cuda.synchronize()
@@ -294,8 +412,13 @@ def run_workload(args, rank: int, local_rank: int, world: int, dist):
         # per-partition checksums and decodes the whole range [index[0], index[N]) — a
         # ShuffleBlockBatchId-style batch fetch of all partitions of the map output
         for i, t in enumerate(tasks):
-            total, index, sums = codecs[0].compress_map_output_device(codec_id, algo_id, t["src"].data_ptr(), t["offs"],
-                                                                      t["dst"].data_ptr(), t["cap"])
+            if zstd_images is not None:
+                img, index, sums = zstd_images[i]
+                total = int(img.size)
+                t["dst"][:total].copy_(torch.from_numpy(img))
+            else:
+                total, index, sums = codecs[0].compress_map_output_device(codec_id, algo_id, t["src"].data_ptr(), t["offs"],
+                                                                          t["dst"].data_ptr(), t["cap"])
             t["total"], t["index"], t["sums"] = total, index, sums
             t["out"] = torch.empty(t["u"], dtype=torch.uint8, device=dev)
             comp_bytes[i] = total
@@ -438,7 +561,8 @@ def run_workload(args, rank: int, local_rank: int, world: int, dist):
                               "skew": "single-partition TeraGen-like block, seed 5"}[gen],
                 "direction": args.direction,
                 "codec": "lz4 (LZ4Block frames, 32 KiB blocks; payload bit-exact with liblz4 1.9.3 LZ4_compress_default, framing restated from lz4-java 1.8.0)" if codec_name == "lz4"
-                         else "snappy (SnappyOutputStream framing, 32 KiB blocks, byte-exact with snappy 1.1.8)",
+                         else "snappy (SnappyOutputStream framing, 32 KiB blocks, byte-exact with snappy 1.1.8)" if codec_name == "snappy"
+                         else "zstd (decode only: libzstd 1.4.8 streaming frames, level 1, one per partition, as zstd-jni writes them)",
                 "checksum": algo_name,
                 "partitions_per_map_task": nparts,
                 "map_task_bytes": tasks[0]["u"],
@@ -454,8 +578,9 @@ def run_workload(args, rank: int, local_rank: int, world: int, dist):
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": ("%s batch decoder (one wavefront per frame, one sequence per lane)" if decompress
-                           else "%s_compress (one wavefront per 32 KiB block)") % codec_name,
+                "kernel": ("zstd decode pass (one wavefront per partition frame, serial entropy stages)" if codec_name == "zstd" else
+                           "%s batch decoder (one wavefront per frame, one sequence per lane)" % codec_name if decompress
+                           else "%s_compress (one wavefront per 32 KiB block)" % codec_name),
                 "achieved": round(achieved, 3),
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
@@ -471,7 +596,10 @@ def run_workload(args, rank: int, local_rank: int, world: int, dist):
             "stages_ms_per_library_call": {k: round(stage[k] / launches, 4) for k in ("hash", "codec", "assemble", "checksum", "total")},
         }
         if world == 1 and not args.no_cpu_baseline:
-            cb = (cpu_baseline_decompress if decompress else cpu_baseline)(args.workload, args.cpu_seconds, args.map_mib)
+            if codec_name == "zstd":
+                cb = cpu_baseline_zstd_decompress(args.workload, args.cpu_seconds, args.map_mib)
+            else:
+                cb = (cpu_baseline_decompress if decompress else cpu_baseline)(args.workload, args.cpu_seconds, args.map_mib)
             out["cpu_baseline"] = cb
             if cb:
                 out["speedup_vs_cpu_all_cores"] = round(value / cb["value"], 3)
@@ -509,6 +637,7 @@ SECONDARY = [
     ("tpcds-wide-snappy:decompress", "tpcds-wide-100g-200p-snappy", "decompress", 128, 4),
     ("skew-1gib-lz4:compress", "skew-1part-lz4", "compress", 1024, 1),
     ("skew-1gib-lz4:decompress", "skew-1part-lz4", "decompress", 1024, 1),
+    ("terasort-200p-zstd:decompress", "terasort-10g-200p-zstd", "decompress", 128, 4),
 ]
 
 

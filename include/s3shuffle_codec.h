@@ -69,10 +69,14 @@ extern "C" {
 #define S3S_ABI_VERSION 5 /* 2: + segments entry points, page-locked staging, tuning options 6, 7;
                              3: + s3s_compress_map_outputs_batch_device;
                              4: + s3s_decompress_ranges_batch_device; decode variants {3, 4}, LZ4 parses {1, 9, 10};
-                             5: + s3s_compress_map_outputs_batch / s3s_decompress_ranges_batch (host buffers) */
+                             5: + s3s_compress_map_outputs_batch / s3s_decompress_ranges_batch (host buffers),
+                                S3S_CODEC_ZSTD on the reduce side */
 
 /* spark.io.compression.codec (only when spark.shuffle.compress=true) */
-enum { S3S_CODEC_NONE = 0, S3S_CODEC_LZ4 = 1, S3S_CODEC_SNAPPY = 2 };
+enum { S3S_CODEC_NONE = 0, S3S_CODEC_LZ4 = 1, S3S_CODEC_SNAPPY = 2,
+       S3S_CODEC_ZSTD = 3 /* reduce side only (s3s_decompress_range*, s3s_decompressed_size): Zstandard frames as
+                             ZStdCompressionCodec / zstd-jni write them, one per non-empty partition; the compress
+                             entry points answer S3S_E_UNSUPPORTED (the codec stays on the JVM) */ };
 /* spark.shuffle.checksum.algorithm (NONE when spark.shuffle.checksum.enabled=false) */
 enum { S3S_CHECKSUM_NONE = 0, S3S_CHECKSUM_ADLER32 = 1, S3S_CHECKSUM_CRC32 = 2 };
 

@@ -86,6 +86,24 @@ int s3s_decompressed_size(s3s_ctx* ctx, int codec, const uint8_t* comp, int64_t 
     case S3S_CODEC_SNAPPY:
       rc = snappy_decoded_size_host(comp, comp_len, out_len);
       break;
+    case S3S_CODEC_ZSTD: {
+      // a Spark writer's frames carry no content size: the size pass of the device decoder walks them (pass 1 of
+      // zstd_decompress.hip); the whole buffer is one "partition" of concatenated frames
+      *out_len = 0;
+      if (comp_len == 0) return S3S_OK;
+      HIP_TRY(ctx, hipSetDevice(ctx->device));
+      if ((rc = ensure(ctx, B_SRC, (size_t)comp_len + 64))) return rc;
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_SRC].p, comp, (size_t)comp_len, hipMemcpyHostToDevice, ctx->stream));
+      const int64_t offs[2] = {0, comp_len};
+      s3s_fetch_range k{};
+      k.d_comp = dev<uint8_t>(ctx, B_SRC);
+      k.comp_len = comp_len;
+      k.part_offsets = offs;
+      k.num_partitions = 1;
+      rc = zstd_decompress_ranges(ctx, S3S_CHECKSUM_NONE, &k, 1, true);
+      *out_len = k.out_len;
+      return rc;
+    }
     default:
       return fail(ctx, S3S_E_INVALID, "unknown codec %d", codec);
   }
@@ -103,7 +121,7 @@ int s3s_decompress_range_device(s3s_ctx* ctx, int codec, int checksum_algo, cons
   if (out_len) *out_len = 0;
   if (nparts < 0 || !part_offsets || comp_len < 0 || dst_capacity < 0)
     return fail(ctx, S3S_E_INVALID, "null/invalid argument");
-  if (codec != S3S_CODEC_NONE && codec != S3S_CODEC_LZ4 && codec != S3S_CODEC_SNAPPY)
+  if (codec != S3S_CODEC_NONE && codec != S3S_CODEC_LZ4 && codec != S3S_CODEC_SNAPPY && codec != S3S_CODEC_ZSTD)
     return fail(ctx, S3S_E_INVALID, "unknown codec %d", codec);
   if (checksum_algo != S3S_CHECKSUM_NONE && checksum_algo != S3S_CHECKSUM_ADLER32 &&
       checksum_algo != S3S_CHECKSUM_CRC32)
@@ -117,6 +135,20 @@ int s3s_decompress_range_device(s3s_ctx* ctx, int codec, int checksum_algo, cons
   if ((comp_len > 0 && !d_comp) || (dst_capacity > 0 && !d_dst)) return fail(ctx, S3S_E_INVALID, "null data pointer");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   for (auto& v : ctx->stage_ms) v = 0;
+  if (codec == S3S_CODEC_ZSTD) {  // one wavefront per partition, two passes (zstd_decompress.hip)
+    s3s_fetch_range k{};
+    k.d_comp = d_comp;
+    k.comp_len = comp_len;
+    k.part_offsets = part_offsets;
+    k.ref_checksums = ref_checksums;
+    k.num_partitions = nparts;
+    k.d_dst = d_dst;
+    k.dst_capacity = dst_capacity;
+    const int zrc = zstd_decompress_ranges(ctx, checksum_algo, &k, 1, false);
+    if (out_len) *out_len = k.out_len;
+    if (out_bad_partition) *out_bad_partition = k.bad_partition;
+    return zrc;
+  }
 
   const int32_t n = nparts;
   const int32_t n_tiles = codec == S3S_CODEC_LZ4 ? lz4_tile_count(comp_len) : 0;
@@ -326,7 +358,9 @@ int s3s_decompress_range(s3s_ctx* ctx, int codec, int checksum_algo, const uint8
   int64_t need = dst_capacity;
   {
     int64_t decoded = 0;
-    if (codec != S3S_CODEC_NONE && s3s_decompressed_size(ctx, codec, comp, comp_len, &decoded) == S3S_OK && decoded < need)
+    if (codec == S3S_CODEC_ZSTD)
+      ;  // (its size pass runs on the device inside the call below; the caller sized dst with s3s_decompressed_size)
+    else if (codec != S3S_CODEC_NONE && s3s_decompressed_size(ctx, codec, comp, comp_len, &decoded) == S3S_OK && decoded < need)
       need = decoded;
     else if (codec == S3S_CODEC_NONE && comp_len < need)
       need = comp_len;
@@ -375,7 +409,7 @@ extern "C" int s3s_decompress_ranges_batch_device(s3s_ctx* ctx, int codec, int c
   if (!ctx) return S3S_E_INVALID;
   ctx->err[0] = 0;
   if (n_ranges < 0 || (n_ranges > 0 && !R)) return fail(ctx, S3S_E_INVALID, "null range array or negative count");
-  if (codec != S3S_CODEC_NONE && codec != S3S_CODEC_LZ4 && codec != S3S_CODEC_SNAPPY)
+  if (codec != S3S_CODEC_NONE && codec != S3S_CODEC_LZ4 && codec != S3S_CODEC_SNAPPY && codec != S3S_CODEC_ZSTD)
     return fail(ctx, S3S_E_INVALID, "unknown codec %d", codec);
   if (checksum_algo != S3S_CHECKSUM_NONE && checksum_algo != S3S_CHECKSUM_ADLER32 && checksum_algo != S3S_CHECKSUM_CRC32)
     return fail(ctx, S3S_E_INVALID, "Unsupported shuffle checksum algorithm: %d", checksum_algo);
@@ -418,6 +452,8 @@ extern "C" int s3s_decompress_ranges_batch_device(s3s_ctx* ctx, int codec, int c
   }
   if (n_segs > 0x7fffff00ll || n_parts > 0x7fffff00ll) return fail(ctx, S3S_E_UNSUPPORTED, "batch too large for one call");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (codec == S3S_CODEC_ZSTD)  // the partitions of every range in one launch per pass: frames in flight are the throughput
+    return zstd_decompress_ranges(ctx, checksum_algo, R, n_ranges, false);
   for (auto& v : ctx->stage_ms) v = 0;
   const bool do_sum = checksum_algo != S3S_CHECKSUM_NONE;
   const size_t np1 = (size_t)n_parts + (size_t)n_ranges;  // sum of (n_r + 1)

@@ -176,4 +176,7 @@ inline int run_checksum(s3s_ctx* ctx, int algo, const uint8_t* d_data, const int
   return S3S_OK;
 }
 
+// Zstandard reduce side (zstd_decompress.hip): verify + decode (or only size) the frames of n_ranges device ranges
+int zstd_decompress_ranges(s3s_ctx* ctx, int checksum_algo, s3s_fetch_range* R, int32_t n_ranges, bool size_only);
+
 }  // namespace s3s

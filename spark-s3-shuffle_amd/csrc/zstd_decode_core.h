@@ -1,0 +1,748 @@
+// zstd_decode_core.h — Zstandard frame decoder (RFC 8878), written once for the device and for the host.
+//
+// Reduce side of SURVEY §8 f4: with spark.io.compression.codec=zstd the reference's reader hands every fetched block
+// range to zstd-jni's ZstdInputStream through serializerManager.wrapStream (storage/S3ShuffleReader.scala:98-110,
+// codec matrix at :55-75); one frame per non-empty partition (several when a partition was written in spill pieces:
+// frames concatenate).  This file is the decoder behind S3S_CODEC_ZSTD in s3s_decompress_range*: COMPRESSION stays on
+// the JVM (libzstd's output is not reproducible by a data-parallel program), so the parity bar here is
+// "decodes every stream libzstd 1.4.8 — the library in this image, and the format zstd-jni writes — produces".
+//
+// Shape: one wavefront per partition.  The entropy stages are serial by construction (one FSE bit stream for a
+// block's sequences, four Huffman streams for its literals), so the wave runs the control flow uniformly — every lane
+// computes the same header / table / sequence values — and spreads only what has width: the four Huffman streams go
+// to lanes 0..3, literal runs and matches are copied 64 bytes per step, table fills are strided over the lanes.
+// Throughput therefore comes from the number of partitions in flight (a batched call holds thousands), not from a
+// single frame; a 1 GiB single-partition block is one wavefront's serial work and belongs on the host.
+//
+// Compiled by hipcc (S3S_ZSTD_DEVICE: zstd_decompress.hip) and by g++ (tests/model/zstd_decode_model.cpp: the same
+// code with one "lane", checked against libzstd on the CPU before it ever reaches a GPU).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#ifdef S3S_ZSTD_DEVICE
+#define ZS_HD __device__ __forceinline__
+#define ZS_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
+#else
+#define ZS_HD static inline
+#define ZS_FENCE() ((void)0)
+#endif
+
+#ifdef ZS_TRACE  // host debugging only: which check refused the stream
+#include <stdio.h>
+#define ZS_FAIL() (fprintf(stderr, "zstd_decode_core.h:%d\n", __LINE__), ZS_BAD)
+#else
+#define ZS_FAIL() ZS_BAD
+#endif
+
+namespace s3s_zstd {
+
+enum { ZS_OK = 0, ZS_BAD = -3, ZS_CAPACITY = -2, ZS_UNSUPPORTED = -6 };
+constexpr int kMaxBlock = 1 << 17;
+constexpr int kHufLogMax = 11;
+constexpr int kLLLogMax = 9, kMLLogMax = 9, kOFLogMax = 8;
+
+// per-wavefront tables (LDS on the device: 4 KiB + 5 KiB + scratch)
+struct Work {
+  uint16_t huf[1 << kHufLogMax];   // (symbol << 8) | nbBits
+  uint32_t ll[1 << kLLLogMax];     // baseline | nbBits << 16 | symbol << 24
+  uint32_t ml[1 << kMLLogMax];
+  uint32_t of[1 << kOFLogMax];
+  int16_t norm[256];               // normalized counts (FSE header), also Huffman weight scratch
+  uint16_t next[256];              // symbolNext / rank starts
+  uint8_t weights[256];
+  uint32_t wtab[64];               // FSE table of the Huffman weights (tableLog <= 6)
+  int32_t huf_log, ll_log, ml_log, of_log;
+  int32_t have_huf, have_ll, have_ml, have_of;  // "repeat" modes need a previous table
+};
+
+struct Lanes {  // who am I in the wavefront (host: lane 0 of 1)
+  int lane, n;
+};
+
+ZS_HD uint32_t rd_le(const uint8_t* p, int nbytes) {
+  uint32_t v = 0;
+  for (int i = 0; i < nbytes; i++) v |= (uint32_t)p[i] << (8 * i);
+  return v;
+}
+ZS_HD int highbit(uint32_t v) { return 31 - __builtin_clz(v); }
+
+// ---- backward bit stream (the convention of FSE / Huffman streams in zstd) ----------------------------------------------
+// The stream is bytes [0, size); its last byte carries a final 1 bit as end mark.  Bits are consumed from the top.
+// `pos` = number of unread bits below the cursor; a read of n bits takes bits [pos - n, pos).  Reading below bit 0 gives
+// zeros and makes pos negative: the callers check pos at the points where the format demands it.
+struct BitR {
+  const uint8_t* p;
+  int64_t size;
+  int64_t pos;
+  uint64_t cache;      // bits [cbase, cbase + 64)
+  int64_t cbase;
+};
+ZS_HD uint64_t load_bits64(const uint8_t* p, int64_t size, int64_t byte0) {  // bytes [byte0, byte0+8) with zeros outside [0,size)
+  uint64_t v = 0;
+  if (byte0 >= 0 && byte0 + 8 <= size) {
+    memcpy(&v, p + byte0, 8);
+    return v;
+  }
+  for (int i = 0; i < 8; i++) {
+    const int64_t b = byte0 + i;
+    if (b >= 0 && b < size) v |= (uint64_t)p[b] << (8 * i);
+  }
+  return v;
+}
+ZS_HD bool bitr_init(BitR& r, const uint8_t* p, int64_t size) {
+  r.p = p;
+  r.size = size;
+  r.cbase = 1;  // (no cache)
+  r.cache = 0;
+  r.pos = 0;
+  if (size <= 0) return false;
+  const uint32_t last = p[size - 1];
+  if (last == 0) return false;  // no end mark
+  r.pos = (size - 1) * 8 + highbit(last);
+  r.cbase = -1000;
+  return true;
+}
+ZS_HD uint32_t bitr_peek(BitR& r, int n) {  // n <= 32
+  if (n == 0) return 0;
+  const int64_t lo = r.pos - n;
+  if (!(lo >= r.cbase && r.pos <= r.cbase + 64)) {
+    // window whose top byte holds bit pos-1
+    const int64_t top = (r.pos - 1) >> 3;
+    const int64_t b0 = top - 7;
+    r.cbase = b0 * 8;
+    r.cache = load_bits64(r.p, r.size, b0);
+  }
+  if (lo >= r.cbase) return (uint32_t)((r.cache >> (lo - r.cbase)) & ((n == 32) ? 0xFFFFFFFFull : ((1ull << n) - 1)));
+  // (only when pos < n: below the start of the stream) bits under 0 read as zero
+  uint32_t v = 0;
+  for (int i = 0; i < n; i++) {
+    const int64_t b = lo + i;
+    if (b >= 0 && b < r.size * 8) v |= (uint32_t)((r.p[b >> 3] >> (b & 7)) & 1) << i;
+  }
+  return v;
+}
+ZS_HD uint32_t bitr_read(BitR& r, int n) {
+  const uint32_t v = bitr_peek(r, n);
+  r.pos -= n;
+  return v;
+}
+
+// ---- forward bit reader for FSE table descriptions ---------------------------------------------------------------------------
+// Normalized counts (FSE_readNCount): returns bytes consumed (> 0) or a negative error.  *max_sym out, *table_log out.
+ZS_HD int read_ncount(int16_t* norm, int max_sym_allowed, int max_log, const uint8_t* p, int64_t size, int* out_max_sym,
+                      int* out_log) {
+  if (size < 1) return ZS_FAIL();
+  uint64_t bits = 0;
+  int nb = 0;      // valid bits in `bits`
+  int64_t ip = 0;  // next byte to load
+  auto fill = [&]() {
+    while (nb <= 56 && ip < size) {
+      bits |= (uint64_t)p[ip++] << nb;
+      nb += 8;
+    }
+  };
+  int64_t used_bits = 0;
+  auto take = [&](int n) -> uint32_t {
+    fill();
+    const uint32_t v = (uint32_t)(bits & ((1ull << n) - 1));
+    bits >>= n;
+    nb -= n;
+    used_bits += n;
+    return v;
+  };
+  const int table_log = (int)take(4) + 5;
+  if (table_log > max_log) return ZS_FAIL();
+  int remaining = (1 << table_log) + 1;
+  int threshold = 1 << table_log;
+  int nbits = table_log + 1;
+  int sym = 0;
+  bool prev0 = false;
+  while (remaining > 1 && sym <= max_sym_allowed) {
+    if (prev0) {
+      // repeat flags: 2 bits each, value 3 = three more zero symbols and another flag follows
+      int n0 = sym;
+      for (;;) {
+        const uint32_t f = take(2);
+        n0 += (int)f;
+        if (f != 3) break;
+        if (n0 > max_sym_allowed + 1) return ZS_FAIL();
+      }
+      if (n0 > max_sym_allowed + 1) return ZS_FAIL();
+      while (sym < n0) norm[sym++] = 0;
+      prev0 = false;
+      if (sym > max_sym_allowed) break;
+    }
+    fill();
+    const int max = (2 * threshold - 1) - remaining;
+    int count;
+    const uint32_t low = (uint32_t)(bits & (uint64_t)(threshold - 1));
+    if ((int)low < max) {
+      count = (int)low;
+      bits >>= (nbits - 1);
+      nb -= nbits - 1;
+      used_bits += nbits - 1;
+    } else {
+      count = (int)(bits & (uint64_t)(2 * threshold - 1));
+      if (count >= threshold) count -= max;
+      bits >>= nbits;
+      nb -= nbits;
+      used_bits += nbits;
+    }
+    count--;  // -1 means "less than one" probability
+    remaining -= count < 0 ? -count : count;
+    norm[sym++] = (int16_t)count;
+    prev0 = count == 0;
+    while (remaining < threshold) {
+      nbits--;
+      threshold >>= 1;
+    }
+    if (nb < 0) return ZS_FAIL();
+  }
+  if (remaining != 1) return ZS_FAIL();
+  if (sym > max_sym_allowed + 1) return ZS_FAIL();
+  *out_max_sym = sym - 1;
+  *out_log = table_log;
+  const int64_t bytes = (used_bits + 7) >> 3;
+  if (bytes > size) return ZS_FAIL();
+  return (int)bytes;
+}
+
+// FSE decoding table from normalized counts (FSE_buildDTable).  entry = baseline | nbBits << 16 | symbol << 24
+ZS_HD int build_fse(uint32_t* tab, const int16_t* norm, int max_sym, int table_log, uint16_t* next) {
+  const int size = 1 << table_log;
+  int high = size - 1;
+  for (int s = 0; s <= max_sym; s++) {
+    if (norm[s] == -1) {
+      tab[high--] = (uint32_t)s << 24;
+      next[s] = 1;
+    } else {
+      next[s] = (uint16_t)norm[s];
+    }
+  }
+  const int mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+  int pos = 0;
+  for (int s = 0; s <= max_sym; s++) {
+    for (int i = 0; i < norm[s]; i++) {
+      tab[pos] = (uint32_t)s << 24;
+      pos = (pos + step) & mask;
+      while (pos > high) pos = (pos + step) & mask;
+    }
+  }
+  if (pos != 0) return ZS_FAIL();
+  for (int u = 0; u < size; u++) {
+    const int s = (int)(tab[u] >> 24);
+    const uint32_t ns = next[s]++;
+    const int nbb = table_log - highbit(ns);
+    const uint32_t base = (ns << nbb) - (uint32_t)size;
+    tab[u] = (base & 0xFFFFu) | ((uint32_t)nbb << 16) | ((uint32_t)s << 24);
+  }
+  return ZS_OK;
+}
+ZS_HD void build_rle(uint32_t* tab, int sym) { tab[0] = (uint32_t)sym << 24; }  // tableLog 0: one state, 0 bits
+
+// predefined distributions (RFC 8878 §3.1.1.3.2.2)
+ZS_HD int default_norm(int which, int16_t* norm, int* log) {  // 0 = LL, 1 = OF, 2 = ML; returns max symbol
+  static const int8_t LL[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+  static const int8_t OF[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+  static const int8_t ML[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+  if (which == 0) {
+    for (int i = 0; i < 36; i++) norm[i] = LL[i];
+    *log = 6;
+    return 35;
+  }
+  if (which == 1) {
+    for (int i = 0; i < 29; i++) norm[i] = OF[i];
+    *log = 5;
+    return 28;
+  }
+  for (int i = 0; i < 53; i++) norm[i] = ML[i];
+  *log = 6;
+  return 52;
+}
+
+ZS_HD uint32_t ll_base(int c) {
+  static const uint32_t B[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 28, 32, 40,
+                                 48, 64, 0x80, 0x100, 0x200, 0x400, 0x800, 0x1000, 0x2000, 0x4000, 0x8000, 0x10000};
+  return B[c];
+}
+ZS_HD int ll_bits(int c) {
+  static const uint8_t B[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+  return B[c];
+}
+ZS_HD uint32_t ml_base(int c) {
+  static const uint32_t B[53] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29,
+                                 30, 31, 32, 33, 34, 35, 37, 39, 41, 43, 47, 51, 59, 67, 83, 99, 0x83, 0x103, 0x203, 0x403, 0x803,
+                                 0x1003, 0x2003, 0x4003, 0x8003, 0x10003};
+  return B[c];
+}
+ZS_HD int ml_bits(int c) {
+  static const uint8_t B[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+  return B[c];
+}
+
+// ---- Huffman ----------------------------------------------------------------------------------------------------------------
+// Tree description -> decoding table.  Returns bytes consumed or a negative error.
+ZS_HD int read_huf_table(Work& w, const uint8_t* p, int64_t size) {
+  if (size < 1) return ZS_FAIL();
+  const int hb = p[0];
+  int nsym = 0;  // weights given explicitly
+  int used;
+  if (hb >= 128) {  // direct: 4-bit weights
+    nsym = hb - 127;
+    used = 1 + (nsym + 1) / 2;
+    if (used > size) return ZS_FAIL();
+    for (int i = 0; i < nsym; i++) w.weights[i] = (i & 1) ? (p[1 + i / 2] & 15) : (p[1 + i / 2] >> 4);
+  } else {  // FSE-compressed weights: two interleaved states over one backward stream
+    used = 1 + hb;
+    if (hb == 0 || used > size) return ZS_FAIL();
+    int max_sym, log;
+    const int hdr = read_ncount(w.norm, 255, 6, p + 1, hb, &max_sym, &log);
+    if (hdr < 0) return hdr;
+    if (max_sym > 12) return ZS_FAIL();  // weights are 0..12 (HUF_TABLELOG_ABSOLUTEMAX)
+    if (build_fse(w.wtab, w.norm, max_sym, log, w.next) != ZS_OK) return ZS_FAIL();
+    BitR r;
+    if (!bitr_init(r, p + 1 + hdr, hb - hdr)) return ZS_FAIL();
+    uint32_t s1 = bitr_read(r, log), s2 = bitr_read(r, log);
+    if (r.pos < 0) return ZS_FAIL();
+    // FSE_decompress_usingDTable: alternate the two states; when the stream runs dry the other state still holds a symbol
+    for (;;) {
+      if (nsym > 253) return ZS_FAIL();
+      uint32_t e = w.wtab[s1];
+      w.weights[nsym++] = (uint8_t)(e >> 24);
+      int nb = (int)((e >> 16) & 0xff);
+      if (r.pos < nb) {  // cannot update s1: s2's symbol is the last one
+        w.weights[nsym++] = (uint8_t)(w.wtab[s2] >> 24);
+        break;
+      }
+      s1 = (e & 0xFFFFu) + bitr_read(r, nb);
+      if (nsym > 253) return ZS_FAIL();
+      e = w.wtab[s2];
+      w.weights[nsym++] = (uint8_t)(e >> 24);
+      nb = (int)((e >> 16) & 0xff);
+      if (r.pos < nb) {
+        w.weights[nsym++] = (uint8_t)(w.wtab[s1] >> 24);
+        break;
+      }
+      s2 = (e & 0xFFFFu) + bitr_read(r, nb);
+    }
+  }
+  if (nsym < 1 || nsym > 255) return ZS_FAIL();
+  // the last weight follows from the sum being a power of two
+  uint32_t total = 0;
+  for (int i = 0; i < nsym; i++) {
+    if (w.weights[i] > 12) return ZS_FAIL();
+    if (w.weights[i]) total += 1u << (w.weights[i] - 1);
+  }
+  if (total == 0) return ZS_FAIL();
+  const int log = highbit(total) + 1;
+  if (log > kHufLogMax) return ZS_FAIL();
+  const uint32_t rest = (1u << log) - total;
+  if (rest == 0 || (rest & (rest - 1))) return ZS_FAIL();  // must be a power of two
+  w.weights[nsym] = (uint8_t)(highbit(rest) + 1);
+  nsym++;
+  // table: symbols of weight W occupy 2^(W-1) consecutive cells each, smaller weights first, symbols in order
+  uint32_t rank_start[14];
+  for (int i = 0; i < 14; i++) rank_start[i] = 0;
+  for (int i = 0; i < nsym; i++) rank_start[w.weights[i]]++;  // counts
+  if (rank_start[1] < 2 || (rank_start[1] & 1)) return ZS_FAIL();  // (at least two symbols of the longest length, in pairs)
+  uint32_t at = 0;
+  for (int wt = 1; wt <= log; wt++) {
+    const uint32_t cnt = rank_start[wt];
+    rank_start[wt] = at;
+    at += cnt << (wt - 1);
+  }
+  if (at != (1u << log)) return ZS_FAIL();
+  for (int s = 0; s < nsym; s++) {
+    const int wt = w.weights[s];
+    if (!wt) continue;
+    const uint32_t len = 1u << (wt - 1), nb = (uint32_t)(log + 1 - wt);
+    const uint32_t st = rank_start[wt];
+    for (uint32_t u = 0; u < len; u++) w.huf[st + u] = (uint16_t)((s << 8) | nb);
+    rank_start[wt] += len;
+  }
+  w.huf_log = log;
+  w.have_huf = 1;
+  return used;
+}
+
+// one Huffman stream: n symbols into dst
+ZS_HD int huf_decode_stream(const Work& w, const uint8_t* p, int64_t size, uint8_t* dst, int64_t n) {
+  BitR r;
+  if (!bitr_init(r, p, size)) return ZS_FAIL();
+  const int log = w.huf_log;
+  for (int64_t i = 0; i < n; i++) {
+    const uint32_t v = bitr_peek(r, log);  // (bits below the start of the stream read as zero, like libzstd's container)
+    const uint16_t e = w.huf[v];
+    r.pos -= e & 0xff;
+    if (r.pos < 0) return ZS_FAIL();
+    dst[i] = (uint8_t)(e >> 8);
+  }
+  return r.pos == 0 ? ZS_OK : ZS_BAD;  // the stream must be consumed exactly
+}
+
+// ---- cooperative copies ---------------------------------------------------------------------------------------------------------
+ZS_HD void copy_plain(uint8_t* dst, const uint8_t* src, int64_t n, Lanes L) {  // disjoint ranges
+  for (int64_t i = L.lane; i < n; i += L.n) dst[i] = src[i];
+}
+ZS_HD void fill_byte(uint8_t* dst, uint8_t v, int64_t n, Lanes L) {
+  for (int64_t i = L.lane; i < n; i += L.n) dst[i] = v;
+}
+// match copy: out[i] = out[i - offset], i in [0, n); with offset < n the source repeats with period `offset`, and every
+// byte of the period was written BEFORE this copy started, so no lane depends on another lane's store
+ZS_HD void copy_match(uint8_t* out, int64_t offset, int64_t n, Lanes L) {
+  const uint8_t* pat = out - offset;
+  if (offset >= n) {
+    for (int64_t i = L.lane; i < n; i += L.n) out[i] = pat[i];
+  } else {
+    for (int64_t i = L.lane; i < n; i += L.n) out[i] = pat[i % offset];
+  }
+}
+
+// ---- one frame ------------------------------------------------------------------------------------------------------------------
+struct FrameOut {
+  int64_t consumed;  // bytes of src this frame occupied
+  int64_t produced;  // decoded bytes
+  int64_t lit_need;  // largest regenerated (Huffman-coded) literals section of any block: what lit_buf must hold
+};
+
+// Decodes (execute = true) or only sizes (execute = false) the frame at src[0, size).  dst = where this frame's output
+// starts (history never reaches in front of it), cap = bytes available there.  lit_buf: kMaxBlock + 32 bytes of scratch.
+ZS_HD int decode_frame(Work& w, const uint8_t* src, int64_t size, uint8_t* dst, int64_t cap, bool execute, uint8_t* lit_buf,
+                       Lanes L, FrameOut* out) {
+  if (size < 4) return ZS_FAIL();
+  const uint32_t magic = rd_le(src, 4);
+  if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {  // skippable frame
+    if (size < 8) return ZS_FAIL();
+    const int64_t n = rd_le(src + 4, 4);
+    if (8 + n > size) return ZS_FAIL();
+    out->consumed = 8 + n;
+    out->produced = 0;
+    out->lit_need = 0;
+    return ZS_OK;
+  }
+  if (magic != 0xFD2FB528u) return ZS_FAIL();
+  if (size < 6) return ZS_FAIL();
+  const uint32_t fhd = src[4];
+  const int fcs_flag = (int)(fhd >> 6), single = (int)((fhd >> 5) & 1), has_check = (int)((fhd >> 2) & 1), did_flag = (int)(fhd & 3);
+  if (fhd & 0x08) return ZS_FAIL();  // reserved bit
+  int64_t ip = 5;
+  int64_t window = 0;
+  if (!single) {
+    const uint32_t wd = src[ip++];
+    const int exp = (int)(wd >> 3), man = (int)(wd & 7);
+    const int64_t base = 1ll << (10 + exp);
+    window = base + (base >> 3) * man;
+  }
+  static const int did_bytes[4] = {0, 1, 2, 4};
+  if (ip + did_bytes[did_flag] > size) return ZS_FAIL();
+  if (did_flag && rd_le(src + ip, did_bytes[did_flag]) != 0) return ZS_UNSUPPORTED;  // dictionaries are not used by Spark
+  ip += did_bytes[did_flag];
+  const int fcs_bytes = fcs_flag == 0 ? (single ? 1 : 0) : (fcs_flag == 1 ? 2 : (fcs_flag == 2 ? 4 : 8));
+  if (ip + fcs_bytes > size) return ZS_FAIL();
+  int64_t fcs = -1;
+  if (fcs_bytes) {
+    uint64_t v = 0;
+    for (int i = 0; i < fcs_bytes; i++) v |= (uint64_t)src[ip + i] << (8 * i);
+    if (fcs_bytes == 2) v += 256;
+    fcs = (int64_t)v;
+    ip += fcs_bytes;
+  }
+  if (single) window = fcs;
+  const int64_t block_max = window < kMaxBlock ? (window > 0 ? window : 1) : kMaxBlock;
+  (void)block_max;
+
+  uint32_t rep[3] = {1, 4, 8};
+  int64_t lit_need = 0;
+  w.have_huf = w.have_ll = w.have_ml = w.have_of = 0;
+  int64_t op = 0;          // bytes produced in this frame
+  int64_t visible = 0;     // bytes of this frame's output every lane may read (fence issued behind them)
+  for (;;) {
+    if (ip + 3 > size) return ZS_FAIL();
+    const uint32_t bh = rd_le(src + ip, 3);
+    ip += 3;
+    const int last = (int)(bh & 1), type = (int)((bh >> 1) & 3);
+    const int64_t bsize = bh >> 3;
+    if (type == 3) return ZS_FAIL();
+    if (type == 0) {  // raw
+      if (bsize > kMaxBlock || ip + bsize > size) return ZS_FAIL();
+      if (execute) {
+        if (op + bsize > cap) return ZS_CAPACITY;
+        copy_plain(dst + op, src + ip, bsize, L);
+      }
+      ip += bsize;
+      op += bsize;
+    } else if (type == 1) {  // RLE: bsize copies of one byte
+      if (bsize > kMaxBlock || ip + 1 > size) return ZS_FAIL();
+      if (execute) {
+        if (op + bsize > cap) return ZS_CAPACITY;
+        fill_byte(dst + op, src[ip], bsize, L);
+      }
+      ip += 1;
+      op += bsize;
+    } else {
+      if (bsize > kMaxBlock || bsize < 2 || ip + bsize > size) return ZS_FAIL();
+      const uint8_t* b = src + ip;
+      const uint8_t* const bend = b + bsize;
+      // ---- literals section ----
+      const int ltype = b[0] & 3, sf = (b[0] >> 2) & 3;
+      int64_t regen = 0, lcomp = 0;
+      int lh, streams = 1;
+      const uint8_t* lit = nullptr;   // where the regenerated literals are (raw: inside src)
+      int lit_rle = -1;
+      if (ltype < 2) {  // raw / RLE
+        if (sf == 0 || sf == 2) { lh = 1; regen = b[0] >> 3; }
+        else if (sf == 1) { lh = 2; if (bsize < 2) return ZS_FAIL(); regen = (b[0] >> 4) + ((int64_t)b[1] << 4); }
+        else { lh = 3; if (bsize < 3) return ZS_FAIL(); regen = (b[0] >> 4) + ((int64_t)b[1] << 4) + ((int64_t)b[2] << 12); }
+        if (regen > kMaxBlock) return ZS_FAIL();
+        if (ltype == 0) {
+          if (lh + regen > bsize) return ZS_FAIL();
+          lit = b + lh;
+          b += lh + regen;
+        } else {
+          if (lh + 1 > bsize) return ZS_FAIL();
+          lit_rle = b[lh];
+          b += lh + 1;
+        }
+      } else {  // Huffman-compressed (2) / treeless (3)
+        if (sf == 0 || sf == 1) {
+          lh = 3; if (bsize < 3) return ZS_FAIL();
+          const uint32_t v = rd_le(b, 3);
+          regen = (v >> 4) & 0x3FF; lcomp = v >> 14;
+          streams = sf == 0 ? 1 : 4;
+        } else if (sf == 2) {
+          lh = 4; if (bsize < 4) return ZS_FAIL();
+          const uint32_t v = rd_le(b, 4);
+          regen = (v >> 4) & 0x3FFF; lcomp = v >> 18;
+          streams = 4;
+        } else {
+          lh = 5; if (bsize < 5) return ZS_FAIL();
+          const uint64_t v = (uint64_t)rd_le(b, 4) | ((uint64_t)b[4] << 32);
+          regen = (int64_t)((v >> 4) & 0x3FFFF); lcomp = (int64_t)(v >> 22);
+          streams = 4;
+        }
+        if (regen > kMaxBlock || lh + lcomp > bsize) return ZS_FAIL();
+        lit_need = regen > lit_need ? regen : lit_need;
+        const uint8_t* hp = b + lh;
+        int64_t hleft = lcomp;
+        if (ltype == 2) {
+          const int used = read_huf_table(w, hp, hleft);
+          if (used < 0) return used;
+          hp += used;
+          hleft -= used;
+        } else if (!w.have_huf) {
+          return ZS_FAIL();
+        }
+        if (execute) {
+          int rc = ZS_OK;
+          if (streams == 1) {
+            if (L.lane == 0) rc = huf_decode_stream(w, hp, hleft, lit_buf, regen);
+          } else {
+            if (hleft < 6) return ZS_FAIL();
+            const int64_t s1 = rd_le(hp, 2), s2 = rd_le(hp + 2, 2), s3 = rd_le(hp + 4, 2);
+            const int64_t s4 = hleft - 6 - s1 - s2 - s3;
+            if (s4 < 0) return ZS_FAIL();
+            const int64_t q = (regen + 3) / 4;
+            const int64_t n4 = regen - 3 * q;
+            if (n4 < 0) return ZS_FAIL();
+            const uint8_t* sp = hp + 6;
+            // stream k -> lane k (device); the host walks them one after the other
+            for (int k = 0; k < 4; k++) {
+              const int64_t sz = k == 0 ? s1 : k == 1 ? s2 : k == 2 ? s3 : s4;
+              const int64_t off = k == 0 ? 0 : k == 1 ? s1 : k == 2 ? s1 + s2 : s1 + s2 + s3;
+              if (L.lane == k % L.n) {
+                const int r1 = huf_decode_stream(w, sp + off, sz, lit_buf + k * q, k == 3 ? n4 : q);
+                if (r1 != ZS_OK) rc = r1;
+              }
+            }
+          }
+#ifdef S3S_ZSTD_DEVICE
+          {  // the first failing lane's code, to every lane
+            const unsigned long long bad = __ballot(rc != ZS_OK);
+            if (bad) rc = __shfl(rc, __builtin_ctzll(bad));
+          }
+#endif
+          if (rc != ZS_OK) return rc;
+          ZS_FENCE();  // the literals were written by lanes 0..3: everybody reads them below
+        }
+        lit = lit_buf;
+        b += lh + lcomp;
+      }
+      // ---- sequences section ----
+      if (b >= bend) return ZS_FAIL();
+      int64_t nseq = b[0];
+      if (nseq == 0) {
+        b += 1;
+      } else if (nseq < 128) {
+        b += 1;
+      } else if (nseq < 255) {
+        if (b + 2 > bend) return ZS_FAIL();
+        nseq = ((nseq - 128) << 8) + b[1];
+        b += 2;
+      } else {
+        if (b + 3 > bend) return ZS_FAIL();
+        nseq = (int64_t)b[1] + ((int64_t)b[2] << 8) + 0x7F00;
+        b += 3;
+      }
+      int64_t lit_pos = 0;
+      int64_t bop = op;  // output position at the start of the block
+      if (nseq > 0) {
+        if (b >= bend) return ZS_FAIL();
+        const int modes = b[0];
+        b += 1;
+        if (modes & 3) return ZS_FAIL();
+        for (int t = 0; t < 3; t++) {  // LL, OF, ML
+          const int mode = (modes >> (6 - 2 * t)) & 3;
+          uint32_t* tab = t == 0 ? w.ll : t == 1 ? w.of : w.ml;
+          int32_t& tlog = t == 0 ? w.ll_log : t == 1 ? w.of_log : w.ml_log;
+          int32_t& have = t == 0 ? w.have_ll : t == 1 ? w.have_of : w.have_ml;
+          const int max_sym = t == 0 ? 35 : t == 1 ? 31 : 52, max_log = t == 0 ? kLLLogMax : t == 1 ? kOFLogMax : kMLLogMax;
+          if (mode == 0) {
+            int log;
+            const int ms = default_norm(t, w.norm, &log);
+            if (build_fse(tab, w.norm, ms, log, w.next) != ZS_OK) return ZS_FAIL();
+            tlog = log;
+            have = 1;
+          } else if (mode == 1) {
+            if (b >= bend) return ZS_FAIL();
+            if (b[0] > max_sym) return ZS_FAIL();
+            build_rle(tab, b[0]);
+            tlog = 0;
+            have = 1;
+            b += 1;
+          } else if (mode == 2) {
+            int ms, log;
+            const int used = read_ncount(w.norm, max_sym, max_log, b, bend - b, &ms, &log);
+            if (used < 0) return used;
+            if (build_fse(tab, w.norm, ms, log, w.next) != ZS_OK) return ZS_FAIL();
+            tlog = log;
+            have = 1;
+            b += used;
+          } else if (!have) {
+            return ZS_FAIL();
+          }
+        }
+        BitR r;
+        if (!bitr_init(r, b, bend - b)) return ZS_FAIL();
+        uint32_t sl = bitr_read(r, w.ll_log), so = bitr_read(r, w.of_log), sm = bitr_read(r, w.ml_log);
+        if (r.pos < 0) return ZS_FAIL();
+        for (int64_t i = 0; i < nseq; i++) {
+          const uint32_t el = w.ll[sl], eo = w.of[so], em = w.ml[sm];
+          const int cl = (int)(el >> 24), co = (int)(eo >> 24), cm = (int)(em >> 24);
+          if (co > 31) return ZS_FAIL();
+          // extra bits: offset, match length, literal length
+          uint32_t ov;
+          if (co > 24) {  // more than 32 bits cannot be peeked at once: two reads
+            const uint32_t hi = bitr_read(r, co - 16);
+            ov = (hi << 16) | bitr_read(r, 16);
+          } else {
+            ov = bitr_read(r, co);
+          }
+          const uint64_t oval = (1ull << co) + ov;
+          const int64_t mlen = (int64_t)ml_base(cm) + bitr_read(r, ml_bits(cm));
+          const int64_t llen = (int64_t)ll_base(cl) + bitr_read(r, ll_bits(cl));
+          if (i + 1 < nseq) {  // state updates: LL, ML, OF
+            sl = (el & 0xFFFFu) + bitr_read(r, (int)((el >> 16) & 0xff));
+            sm = (em & 0xFFFFu) + bitr_read(r, (int)((em >> 16) & 0xff));
+            so = (eo & 0xFFFFu) + bitr_read(r, (int)((eo >> 16) & 0xff));
+          }
+          // Strict (RFC 8878 §3.1.1.3.2.1.2: the stream ends exactly at its first bit): libzstd >= 1.4.5 lets a damaged
+          // stream read below its start — what it returns there depends on its 64-bit container's state — and only demands
+          // that no bits are left over; such streams are refused here ("Stream is corrupted") instead of decoded to
+          // whatever the container held.  Valid streams never get here, and damaged ones were stopped by the partition's
+          // Adler32 / CRC32 before the decoder saw them.
+          if (r.pos < 0) return ZS_FAIL();
+          // offset with the repeat history
+          uint64_t offset;
+          if (oval > 3) {
+            offset = oval - 3;
+            rep[2] = rep[1];
+            rep[1] = rep[0];
+            rep[0] = (uint32_t)offset;
+          } else {
+            uint32_t idx = (uint32_t)oval - 1 + (llen == 0 ? 1u : 0u);  // 0..3
+            if (idx == 0) {
+              offset = rep[0];
+            } else {
+              const uint32_t v = idx == 3 ? rep[0] - 1 : rep[idx];
+              if (v == 0) return ZS_FAIL();
+              if (idx != 1) rep[2] = rep[1];
+              rep[1] = rep[0];
+              rep[0] = v;
+              offset = v;
+            }
+          }
+          if (lit_pos + llen > regen) return ZS_FAIL();
+          if ((int64_t)offset > op + llen || offset == 0) return ZS_FAIL();  // (no dictionary: history starts with the frame)
+          if (execute) {
+            if (op + llen + mlen > cap) return ZS_CAPACITY;
+            if (llen) {
+              if (lit_rle >= 0) fill_byte(dst + op, (uint8_t)lit_rle, llen, L);
+              else copy_plain(dst + op, lit + lit_pos, llen, L);
+            }
+            // the match may read what other lanes wrote since the last fence
+            const int64_t mstart = op + llen - (int64_t)offset;
+            const int64_t mend = (int64_t)offset >= mlen ? mstart + mlen : op + llen;
+            if (mend > visible) {
+              ZS_FENCE();
+              visible = op + llen;
+            }
+            copy_match(dst + op + llen, (int64_t)offset, mlen, L);
+          }
+          lit_pos += llen;
+          op += llen + mlen;
+          if (op - bop > kMaxBlock) return ZS_FAIL();
+        }
+        if (r.pos != 0) return ZS_FAIL();  // the sequence stream must be consumed exactly
+      } else if (b != bend) {
+        return ZS_FAIL();
+      }
+      // literals behind the last sequence
+      const int64_t rest = regen - lit_pos;
+      if (execute) {
+        if (op + rest > cap) return ZS_CAPACITY;
+        if (rest) {
+          if (lit_rle >= 0) fill_byte(dst + op, (uint8_t)lit_rle, rest, L);
+          else copy_plain(dst + op, lit + lit_pos, rest, L);
+        }
+      }
+      op += rest;
+      if (op - bop > kMaxBlock) return ZS_FAIL();
+      ip += bsize;
+      if (execute) ZS_FENCE();  // lit_buf is rewritten by the next block; its readers must be done
+      visible = execute ? op : 0;
+    }
+    if (last) break;
+  }
+  if (has_check) {
+    if (ip + 4 > size) return ZS_FAIL();
+    ip += 4;  // XXH64 of the content (low 32 bits): not re-verified here — the partition's Adler32 / CRC32 over the
+              // compressed bytes has been checked by the caller before decoding (S3ChecksumValidationStream's role)
+  }
+  if (fcs >= 0 && fcs != op) return ZS_FAIL();
+  out->consumed = ip;
+  out->produced = op;
+  out->lit_need = lit_need;
+  return ZS_OK;
+}
+
+// All frames of one partition (concatenated streams of a multi-spill map task).  *total = decoded bytes.
+ZS_HD int decode_partition(Work& w, const uint8_t* src, int64_t size, uint8_t* dst, int64_t cap, bool execute, uint8_t* lit_buf,
+                           Lanes L, int64_t* total, int64_t* lit_need = nullptr) {
+  int64_t ip = 0, op = 0, need = 0;
+  while (ip < size) {
+    FrameOut fo;
+    const int rc = decode_frame(w, src + ip, size - ip, execute ? dst + op : dst, execute ? cap - op : 0, execute, lit_buf, L, &fo);
+    if (rc != ZS_OK) return rc;
+    ip += fo.consumed;
+    op += fo.produced;
+    need = fo.lit_need > need ? fo.lit_need : need;
+  }
+  *total = op;
+  if (lit_need) *lit_need = need;
+  return ZS_OK;
+}
+
+}  // namespace s3s_zstd

@@ -1,0 +1,228 @@
+// zstd_decompress.hip — reduce side for spark.io.compression.codec=zstd: verify + decode the Zstandard
+// frames of fetched block ranges.  The decoder itself is zstd_decode_core.h (shared with its host model); this file
+// is the kernel around it and the orchestration behind s3s_decompress_range* / s3s_decompressed_size for
+// S3S_CODEC_ZSTD.  One wavefront per partition, two passes over the compressed bytes:
+//   pass 1  sizes: headers, table descriptions and the sequence streams are decoded, nothing is written — a Spark
+//           writer's frames carry no content size (streaming API), and the partitions must land back to back in dst;
+//   pass 2  decode into dst + the partition's offset, Huffman literals through a per-partition scratch buffer sized
+//           by pass 1 (the largest regenerated literals section of its blocks).
+// Compression with this codec stays on the JVM: s3s_compress_* answer S3S_E_UNSUPPORTED.
+#define S3S_ZSTD_DEVICE 1
+#include "s3s_ctx.h"
+#include "zstd_decode_core.h"
+
+namespace s3s {
+namespace {
+
+struct ZPart {       // one partition of one range
+  const uint8_t* src;
+  int64_t size;
+  uint8_t* dst;      // pass 2: where its decoded bytes go
+  int64_t cap;       // pass 2: bytes available there
+  int64_t lit_off;   // pass 2: offset of its literals scratch
+};
+struct ZRes {
+  int64_t total;     // decoded bytes
+  int64_t lit_need;  // scratch the partition needs in pass 2
+  int32_t rc;        // ZS_OK / ZS_BAD / ZS_CAPACITY / ZS_UNSUPPORTED (= the S3S_E_* values)
+  int32_t pad;
+};
+
+__global__ __launch_bounds__(kWave) void zstd_partitions_kernel(const ZPart* __restrict__ parts, int32_t n, int execute,
+                                                               uint8_t* __restrict__ lit_base, ZRes* __restrict__ res) {
+  __shared__ s3s_zstd::Work w;
+  const int p = blockIdx.x;
+  if (p >= n) return;
+  const ZPart zp = parts[p];
+  s3s_zstd::Lanes L{(int)threadIdx.x, kWave};
+  int64_t total = 0, need = 0;
+  int rc = s3s_zstd::ZS_OK;
+  if (zp.size > 0)
+    rc = s3s_zstd::decode_partition(w, zp.src, zp.size, zp.dst, zp.cap, execute != 0, lit_base ? lit_base + zp.lit_off : nullptr,
+                                    L, &total, &need);
+  if (threadIdx.x == 0) {
+    ZRes r;
+    r.total = total;
+    r.lit_need = need;
+    r.rc = rc;
+    r.pad = 0;
+    res[p] = r;
+  }
+}
+
+}  // namespace
+
+static_assert(s3s_zstd::ZS_BAD == S3S_E_BAD_FRAME && s3s_zstd::ZS_CAPACITY == S3S_E_CAPACITY &&
+                  s3s_zstd::ZS_UNSUPPORTED == S3S_E_UNSUPPORTED, "decoder codes are the ABI's");
+
+// Verify + decode n_ranges fetched ranges (device buffers).  size_only: pass 1 alone, out_len = decoded bytes.
+// Per range: status / out_len / bad_partition as s3s_decompress_range_device reports them.  Returns the first error.
+int zstd_decompress_ranges(s3s_ctx* ctx, int checksum_algo, s3s_fetch_range* R, int32_t n_ranges, bool size_only) {
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  for (auto& v : ctx->stage_ms) v = 0;
+  int64_t n_parts64 = 0, n_segs64 = 0;
+  for (int32_t r = 0; r < n_ranges; r++) {
+    s3s_fetch_range& k = R[r];
+    k.status = S3S_OK;
+    k.out_len = 0;
+    k.bad_partition = -1;
+    n_parts64 += k.num_partitions;
+    for (int32_t p = 0; p < k.num_partitions; p++) n_segs64 += worst_segs(k.part_offsets[p + 1] - k.part_offsets[p]);
+  }
+  if (n_parts64 > 0x7fffff00ll || n_segs64 > 0x7fffff00ll) return fail(ctx, S3S_E_UNSUPPORTED, "batch too large for one call");
+  const int32_t n_parts = (int32_t)n_parts64;
+  auto first_error = [&]() -> int {
+    for (int32_t r = 0; r < n_ranges; r++)
+      if (R[r].status != S3S_OK) {
+        const s3s_fetch_range& k = R[r];
+        if (k.status == S3S_E_CHECKSUM) return fail(ctx, k.status, "Invalid checksum detected for partition %d of range %d", k.bad_partition, r);
+        if (k.status == S3S_E_CAPACITY) return fail(ctx, k.status, "range %d: dst_capacity %lld < %lld decoded bytes", r, (long long)k.dst_capacity, (long long)k.out_len);
+        if (k.status == S3S_E_UNSUPPORTED) return fail(ctx, k.status, "range %d: zstd frame with a dictionary id", r);
+        return fail(ctx, k.status, "Stream is corrupted (zstd, range %d)", r);
+      }
+    return S3S_OK;
+  };
+  if (n_parts == 0) return S3S_OK;
+  // pinned staging: [ZPart n_parts][ZRes n_parts][offsets + seg starts + sums per range]
+  auto al = [](size_t x) { return (x + 15) & ~size_t(15); };
+  const size_t o_parts = 0, o_res = al(o_parts + sizeof(ZPart) * (size_t)n_parts), o_off = al(o_res + sizeof(ZRes) * (size_t)n_parts),
+               o_seg = al(o_off + 8 * ((size_t)n_parts + (size_t)n_ranges)), o_sums = al(o_seg + 4 * ((size_t)n_parts + (size_t)n_ranges)),
+               stage_total = o_sums + 8 * (size_t)n_parts + 64;
+  int rc;
+  if ((rc = ensure_stage(ctx, stage_total))) return rc;
+  uint8_t* hs = static_cast<uint8_t*>(ctx->h_stage);
+  ZPart* h_parts = reinterpret_cast<ZPart*>(hs + o_parts);
+  ZRes* h_res = reinterpret_cast<ZRes*>(hs + o_res);
+  int64_t* h_off = reinterpret_cast<int64_t*>(hs + o_off);
+  int32_t* h_seg = reinterpret_cast<int32_t*>(hs + o_seg);
+  int64_t* h_sums = reinterpret_cast<int64_t*>(hs + o_sums);
+  record(ctx, 0);
+  // ---- per-partition Adler32 / CRC32 over the compressed bytes (S3ChecksumValidationStream) ---------------------
+  if (checksum_algo != S3S_CHECKSUM_NONE) {
+    if ((rc = ensure(ctx, B_OFFSETS, 8 * ((size_t)n_parts + (size_t)n_ranges)))) return rc;
+    if ((rc = ensure(ctx, B_SUMS, 8 * (size_t)n_parts))) return rc;
+    // (run_checksum re-sizes B_SEG_START / B_PARTIAL per call: size them once for the largest range, so that no
+    //  reallocation synchronises in the middle of the queue)
+    int64_t max_np = 0, max_segs = 0;
+    for (int32_t r = 0; r < n_ranges; r++) {
+      int64_t s = 0;
+      for (int32_t p = 0; p < R[r].num_partitions; p++) s += worst_segs(R[r].part_offsets[p + 1] - R[r].part_offsets[p]);
+      max_segs = s > max_segs ? s : max_segs;
+      max_np = R[r].num_partitions > max_np ? R[r].num_partitions : max_np;
+    }
+    if ((rc = ensure(ctx, B_SEG_START, 4 * (size_t)(max_np + 1)))) return rc;
+    if ((rc = ensure(ctx, B_PARTIAL, 16 * (size_t)(max_segs > 0 ? max_segs : 1)))) return rc;
+    int32_t pp = 0;
+    for (int32_t r = 0; r < n_ranges; r++) {
+      const s3s_fetch_range& k = R[r];
+      const int32_t np = k.num_partitions;
+      if (np == 0) continue;
+      int64_t* ho = h_off + pp + r;
+      int32_t* hg = h_seg + pp + r;
+      int32_t segs = 0;
+      for (int32_t p = 0; p < np; p++) {
+        ho[p] = k.part_offsets[p];
+        hg[p] = segs;
+        segs += worst_segs(k.part_offsets[p + 1] - k.part_offsets[p]);
+      }
+      ho[np] = k.part_offsets[np];
+      hg[np] = segs;
+      int64_t* d_off = dev<int64_t>(ctx, B_OFFSETS) + pp + r;
+      HIP_TRY(ctx, hipMemcpyAsync(d_off, ho, 8 * (size_t)(np + 1), hipMemcpyHostToDevice, ctx->stream));
+      if ((rc = run_checksum(ctx, checksum_algo, k.d_comp, d_off, np, hg, dev<int64_t>(ctx, B_SUMS) + pp, k.comp_len))) return rc;
+      pp += np;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(h_sums, ctx->buf[B_SUMS].p, 8 * (size_t)n_parts, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  record(ctx, 1);
+  // ---- pass 1: sizes -------------------------------------------------------------------------------------------------
+  {
+    int32_t pp = 0;
+    for (int32_t r = 0; r < n_ranges; r++)
+      for (int32_t p = 0; p < R[r].num_partitions; p++, pp++) {
+        ZPart& z = h_parts[pp];
+        z.src = R[r].d_comp + R[r].part_offsets[p];
+        z.size = R[r].part_offsets[p + 1] - R[r].part_offsets[p];
+        z.dst = nullptr;
+        z.cap = 0;
+        z.lit_off = 0;
+      }
+  }
+  if ((rc = ensure(ctx, B_RANGES, sizeof(ZPart) * (size_t)n_parts))) return rc;
+  if ((rc = ensure(ctx, B_FRAMES, sizeof(ZRes) * (size_t)n_parts))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_RANGES].p, h_parts, sizeof(ZPart) * (size_t)n_parts, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(zstd_partitions_kernel, dim3((unsigned)n_parts), dim3(kWave), 0, ctx->stream, dev<ZPart>(ctx, B_RANGES),
+                     n_parts, 0, (uint8_t*)nullptr, dev<ZRes>(ctx, B_FRAMES));
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(h_res, ctx->buf[B_FRAMES].p, sizeof(ZRes) * (size_t)n_parts, hipMemcpyDeviceToHost, ctx->stream));
+  record(ctx, 2);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  // ---- verdicts of the checksum and size passes, destination layout -------------------------------------------------------
+  int64_t lit_total = 0;
+  {
+    int32_t pp = 0;
+    for (int32_t r = 0; r < n_ranges; r++) {
+      s3s_fetch_range& k = R[r];
+      const int32_t p0 = pp;
+      if (checksum_algo != S3S_CHECKSUM_NONE)
+        for (int32_t p = 0; p < k.num_partitions && k.status == S3S_OK; p++)
+          if (h_sums[p0 + p] != k.ref_checksums[p]) {
+            k.status = S3S_E_CHECKSUM;
+            k.bad_partition = p;
+          }
+      int64_t total = 0;
+      for (int32_t p = 0; p < k.num_partitions; p++, pp++) {
+        if (k.status == S3S_OK && h_res[pp].rc != 0) k.status = h_res[pp].rc;
+        if (k.status != S3S_OK) continue;
+        h_parts[pp].dst = k.d_dst ? k.d_dst + total : nullptr;
+        h_parts[pp].cap = h_res[pp].total;
+        h_parts[pp].lit_off = lit_total;
+        total += h_res[pp].total;
+        lit_total += (h_res[pp].lit_need + 64 + 15) & ~int64_t(15);
+      }
+      if (k.status == S3S_OK) {
+        k.out_len = total;
+        if (!size_only && total > k.dst_capacity) k.status = S3S_E_CAPACITY;
+      }
+      if (k.status != S3S_OK)  // none of its partitions takes part in pass 2
+        for (int32_t q = p0; q < pp; q++) h_parts[q].size = 0;
+    }
+  }
+  if (size_only) {
+    if (ctx->profile) {
+      float ms = 0;
+      hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[2]); ctx->stage_ms[S3S_STAGE_TOTAL] = ms;
+      hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); ctx->stage_ms[S3S_STAGE_CHECKSUM] = ms;
+      hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]); ctx->stage_ms[S3S_STAGE_DISCOVER] = ms;
+    }
+    return first_error();
+  }
+  // ---- pass 2: decode ------------------------------------------------------------------------------------------------------
+  if ((rc = ensure(ctx, B_SLOTS, (size_t)lit_total + 64))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_RANGES].p, h_parts, sizeof(ZPart) * (size_t)n_parts, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(zstd_partitions_kernel, dim3((unsigned)n_parts), dim3(kWave), 0, ctx->stream, dev<ZPart>(ctx, B_RANGES),
+                     n_parts, 1, dev<uint8_t>(ctx, B_SLOTS), dev<ZRes>(ctx, B_FRAMES));
+  HIP_TRY(ctx, hipGetLastError());
+  record(ctx, 3);
+  HIP_TRY(ctx, hipMemcpyAsync(h_res, ctx->buf[B_FRAMES].p, sizeof(ZRes) * (size_t)n_parts, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->profile) {
+    float ms = 0;
+    hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]); ctx->stage_ms[S3S_STAGE_TOTAL] = ms;
+    hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); ctx->stage_ms[S3S_STAGE_CHECKSUM] = ms;
+    hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]); ctx->stage_ms[S3S_STAGE_DISCOVER] = ms;
+    hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); ctx->stage_ms[S3S_STAGE_CODEC] = ms;
+  }
+  {
+    int32_t pp = 0;
+    for (int32_t r = 0; r < n_ranges; r++) {
+      s3s_fetch_range& k = R[r];
+      for (int32_t p = 0; p < k.num_partitions; p++, pp++)
+        if (k.status == S3S_OK && h_parts[pp].size > 0 && (h_res[pp].rc != 0 || h_res[pp].total != h_parts[pp].cap))
+          k.status = h_res[pp].rc != 0 ? h_res[pp].rc : S3S_E_BAD_FRAME;
+    }
+  }
+  return first_error();
+}
+
+}  // namespace s3s

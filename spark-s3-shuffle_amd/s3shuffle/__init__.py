@@ -13,6 +13,7 @@ from .codec import (  # noqa: F401
     CODEC_LZ4,
     CODEC_NONE,
     CODEC_SNAPPY,
+    CODEC_ZSTD,
     Codec,
     CodecError,
     PinnedBuffer,

@@ -8,6 +8,7 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 
 CODEC_NONE, CODEC_LZ4, CODEC_SNAPPY = 0, 1, 2
+CODEC_ZSTD = 3  # reduce side only: decode of Zstandard frames (the compress entry points refuse it)
 CHECKSUM_NONE, CHECKSUM_ADLER32, CHECKSUM_CRC32 = 0, 1, 2
 
 OPT_LZ4_BLOCK_SIZE, OPT_SNAPPY_BLOCK_SIZE, OPT_PROFILE = 1, 2, 3

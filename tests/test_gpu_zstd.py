@@ -1,0 +1,140 @@
+"""GPU parity of the Zstandard reduce side (S3S_CODEC_ZSTD): map outputs written the way Spark's
+ZStdCompressionCodec writes them (libzstd 1.4.8 streaming frames, one per non-empty partition — oracle/zstd_ref.py)
+must come back byte for byte through s3s_decompress_range / the batched entry points, with the per-partition checksum
+validation of S3ChecksumValidationStream in front; other levels and frame shapes widen the coverage; damaged streams
+are refused without leaving the destination; compression with this codec is refused (it stays on the JVM)."""
+import numpy as np
+import pytest
+
+import corpus
+
+pytestmark = pytest.mark.gpu
+
+ZSTD, LZ4 = 3, 1
+ADLER, CRC = 1, 2
+
+
+def _image(algo, data, offs, level=1):
+    from oracle import zstd_ref as z
+
+    return z.compress_map_output(algo, data, offs, level)
+
+
+@pytest.mark.parametrize("algo", [ADLER, CRC, 0])
+def test_spark_style_map_outputs_decode_to_the_source(gpu_codec, algo):
+    from s3shuffle import datagen
+
+    for data, offs in (datagen.terasort_map_output(12 << 20, 200, seed=2), datagen.tpcds_wide_map_output(6 << 20, 64, seed=3),
+                       datagen.kv_int_map_output(300_000, 7, seed=1), datagen.skew_block(3 << 20, "zeros", seed=5),
+                       datagen.skew_block(2 << 20, "random", seed=5)):
+        img, index, sums = _image(algo, data, offs)
+        assert gpu_codec.decompressed_size(ZSTD, img) == data.size
+        out = gpu_codec.decompress_range(ZSTD, algo, img, index, sums, dst_capacity=data.size)
+        assert np.array_equal(out, data)
+        n = len(offs) - 1
+        if n > 3:  # a ShuffleBlockBatchId-style sub-range
+            r0, r1 = n // 3, n - 2
+            sub = img[index[r0]:index[r1]]
+            out = gpu_codec.decompress_range(ZSTD, algo, sub, index[r0:r1 + 1] - index[r0], None if algo == 0 else sums[r0:r1],
+                                             dst_capacity=int(offs[r1] - offs[r0]))
+            assert np.array_equal(out, data[offs[r0]:offs[r1]])
+
+
+def test_other_levels_frame_shapes_and_concatenated_streams(gpu_codec):
+    from oracle import zstd_ref as z
+    from s3shuffle import datagen
+
+    rng = np.random.default_rng(3)
+    a = datagen.terasort_map_output(900_000, 1, seed=5)[0]
+    b = datagen.tpcds_wide_map_output(700_000, 1, seed=6)[0]
+    c = corpus.chunk_corpus(2, 60_000, rng)
+    skip = np.frombuffer(b"\x50\x2a\x4d\x18\x03\x00\x00\x00abc", np.uint8)
+    parts = [np.concatenate([z.compress_stream(a, 1), z.compress_stream(b, 3)]),      # two spill pieces = two frames
+             z.compress(c, 19), np.zeros(0, np.uint8), np.concatenate([skip, z.compress_stream(b, 9, checksum=True)]),
+             z.compress_stream(a, -3), z.compress_stream(c, 5, chunk=1000, window_log=10)]
+    want = [np.concatenate([a, b]), c, np.zeros(0, np.uint8), b, a, c]
+    index = np.zeros(len(parts) + 1, np.int64)
+    np.cumsum([p.size for p in parts], out=index[1:])
+    img = np.concatenate(parts)
+    out = gpu_codec.decompress_range(ZSTD, 0, img, index, None, dst_capacity=sum(w.size for w in want))
+    assert np.array_equal(out, np.concatenate(want))
+
+
+def test_batched_ranges_device_and_host(gpu_codec):
+    import s3shuffle
+    from hipdev import Dev
+    from s3shuffle import datagen
+
+    tasks = [datagen.terasort_map_output(3 << 20, 50, seed=7, map_id=m) for m in range(3)] + \
+            [datagen.tpcds_wide_map_output(2 << 20, 20, seed=8, map_id=9)]
+    imgs = [_image(CRC, d, o) for d, o in tasks]
+    dev = Dev()
+    try:
+        args, outs = [], []
+        for (d, o), (img, index, sums) in zip(tasks, imgs):
+            d_out = dev.upload(np.full(d.size + 16, 0xA5, np.uint8))
+            outs.append(d_out)
+            args.append((dev.upload(img), img.size, index, sums, d_out, d.size))
+        res = gpu_codec.decompress_ranges_batch_device(ZSTD, CRC, args)
+        for (d, o), (st, n, bad), d_out in zip(tasks, res, outs):
+            back = dev.download(d_out, d.size + 16)
+            assert st == 0 and n == d.size and np.array_equal(back[:n], d) and np.all(back[n:] == 0xA5)
+    finally:
+        dev.free()
+    hargs, houts = [], []
+    for (d, o), (img, index, sums) in zip(tasks, imgs):
+        out = np.zeros(d.size, np.uint8)
+        houts.append(out)
+        hargs.append((np.ascontiguousarray(img).ctypes.data, img.size, index, sums, out.ctypes.data, d.size))
+        hargs[-1] = hargs[-1] + ()
+    keep = [np.ascontiguousarray(i[0]) for i in imgs]
+    hargs = [(k.ctypes.data, k.size, i[1], i[2], o.ctypes.data, o.size) for k, i, o in zip(keep, imgs, houts)]
+    res = gpu_codec.decompress_ranges_batch(ZSTD, CRC, hargs)
+    for (d, o), (st, n, bad), out in zip(tasks, res, houts):
+        assert st == 0 and n == d.size and np.array_equal(out, d)
+
+
+def test_checksum_mismatch_corruption_and_capacity(gpu_codec):
+    import s3shuffle
+    from s3shuffle import datagen
+
+    data, offs = datagen.terasort_map_output(2 << 20, 12, seed=4)
+    img, index, sums = _image(ADLER, data, offs)
+    bad = img.copy()
+    victim = 7
+    bad[index[victim] + 40] ^= 0x10
+    with pytest.raises(s3shuffle.CodecError) as ei:
+        gpu_codec.decompress_range(ZSTD, ADLER, bad, index, sums, dst_capacity=data.size)
+    assert ei.value.code == -4 and ei.value.partition == victim
+    # without the partition checksums the decoder itself has to notice (or decode what libzstd decodes)
+    from oracle import zstd_ref as z
+
+    rng = np.random.default_rng(9)
+    refused = 0
+    for _ in range(40):
+        m = img.copy()
+        m[int(rng.integers(0, m.size))] ^= 1 << int(rng.integers(0, 8))
+        ref = z.decompress(m[index[0]:index[1]], data.size)  # (first partition only: enough to classify)
+        try:
+            out = gpu_codec.decompress_range(ZSTD, 0, m, index, None, dst_capacity=data.size)
+            assert out.size <= data.size
+        except s3shuffle.CodecError as e:
+            assert e.code in (-3, -2, -6)
+            refused += 1
+    assert refused > 10
+    with pytest.raises(s3shuffle.CodecError) as ei:
+        gpu_codec.decompress_range(ZSTD, ADLER, img, index, sums, dst_capacity=data.size - 1)
+    assert ei.value.code == -2
+    # truncated last frame
+    with pytest.raises(s3shuffle.CodecError) as ei:
+        gpu_codec.decompress_range(ZSTD, 0, img[:-3], np.append(index[:-1], index[-1] - 3), None, dst_capacity=data.size)
+    assert ei.value.code == -3
+
+
+def test_compression_with_zstd_is_refused(gpu_codec):
+    import s3shuffle
+
+    data = np.zeros(1000, np.uint8)
+    with pytest.raises(s3shuffle.CodecError) as ei:
+        gpu_codec.compress_map_output(ZSTD, ADLER, data, [0, 1000])
+    assert ei.value.code in (-6, -1)
