@@ -23,9 +23,12 @@
 #ifdef S3S_ZSTD_DEVICE
 #define ZS_HD __device__ __forceinline__
 #define ZS_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
+// every lane holds the same value: say so (the value moves to a scalar register, what depends on it runs on the scalar unit)
+#define ZS_UNI32(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 #else
 #define ZS_HD static inline
 #define ZS_FENCE() ((void)0)
+#define ZS_UNI32(x) ((uint32_t)(x))
 #endif
 
 #ifdef ZS_TRACE  // host debugging only: which check refused the stream
@@ -41,6 +44,7 @@ enum { ZS_OK = 0, ZS_BAD = -3, ZS_CAPACITY = -2, ZS_UNSUPPORTED = -6 };
 constexpr int kMaxBlock = 1 << 17;
 constexpr int kHufLogMax = 11;
 constexpr int kLLLogMax = 9, kMLLogMax = 9, kOFLogMax = 8;
+constexpr int kRing = 4096, kLitW = 1024;
 
 // per-wavefront tables (LDS on the device: 4 KiB + 5 KiB + scratch)
 struct Work {
@@ -48,12 +52,20 @@ struct Work {
   uint32_t ll[1 << kLLLogMax];     // baseline | nbBits << 16 | symbol << 24
   uint32_t ml[1 << kMLLogMax];
   uint32_t of[1 << kOFLogMax];
+  uint32_t llv[1 << kLLLogMax];    // per state: literal-length base | extra bits << 24 (so the loop reads no constant tables)
+  uint32_t mlv[1 << kMLLogMax];    // per state: match-length base | extra bits << 24
   int16_t norm[256];               // normalized counts (FSE header), also Huffman weight scratch
   uint16_t next[256];              // symbolNext / rank starts
   uint8_t weights[256];
   uint32_t wtab[64];               // FSE table of the Huffman weights (tableLog <= 6)
   int32_t huf_log, ll_log, ml_log, of_log;
   int32_t have_huf, have_ll, have_ml, have_of;  // "repeat" modes need a previous table
+  int32_t vals_ll, vals_ml;
+  // the frame's most recent output (position q lives at ring[q & (kRing - 1)]): match sources come from here, not from
+  // global memory (a global source would need the stores of the sequences before it to have completed: ~1 us each)
+  uint8_t ring[kRing];
+  uint8_t litw[kLitW];             // window over the block's literals, refilled 1 KiB at a time
+  int64_t litw_base;               // literal position of litw[0] (-1: nothing loaded)
 };
 
 struct Lanes {  // who am I in the wavefront (host: lane 0 of 1)
@@ -71,56 +83,53 @@ ZS_HD int highbit(uint32_t v) { return 31 - __builtin_clz(v); }
 // The stream is bytes [0, size); its last byte carries a final 1 bit as end mark.  Bits are consumed from the top.
 // `pos` = number of unread bits below the cursor; a read of n bits takes bits [pos - n, pos).  Reading below bit 0 gives
 // zeros and makes pos negative: the callers check pos at the points where the format demands it.
-struct BitR {
+struct BitR {           // (a stream never exceeds one block, 128 KiB: 32-bit positions)
   const uint8_t* p;
-  int64_t size;
-  int64_t pos;
+  int32_t size;
+  int32_t pos;
   uint64_t cache;      // bits [cbase, cbase + 64)
-  int64_t cbase;
+  int32_t cbase;
+  bool uniform;        // every lane reads this stream in lock step (sequences, weights): values can live in scalar registers
 };
-ZS_HD uint64_t load_bits64(const uint8_t* p, int64_t size, int64_t byte0) {  // bytes [byte0, byte0+8) with zeros outside [0,size)
+ZS_HD uint64_t load_bits64(const uint8_t* p, int32_t size, int32_t byte0) {  // bytes [byte0, byte0+8) with zeros outside [0,size)
   uint64_t v = 0;
   if (byte0 >= 0 && byte0 + 8 <= size) {
     memcpy(&v, p + byte0, 8);
     return v;
   }
   for (int i = 0; i < 8; i++) {
-    const int64_t b = byte0 + i;
+    const int32_t b = byte0 + i;
     if (b >= 0 && b < size) v |= (uint64_t)p[b] << (8 * i);
   }
   return v;
 }
-ZS_HD bool bitr_init(BitR& r, const uint8_t* p, int64_t size) {
+ZS_HD bool bitr_init(BitR& r, const uint8_t* p, int64_t size64, bool uniform = true) {
+  r.uniform = uniform;
   r.p = p;
-  r.size = size;
-  r.cbase = 1;  // (no cache)
+  r.size = (int32_t)size64;
+  r.cbase = 1 << 30;  // (no cache)
   r.cache = 0;
   r.pos = 0;
-  if (size <= 0) return false;
-  const uint32_t last = p[size - 1];
+  if (size64 <= 0 || size64 > kMaxBlock) return false;
+  const uint32_t last = p[size64 - 1];
   if (last == 0) return false;  // no end mark
-  r.pos = (size - 1) * 8 + highbit(last);
-  r.cbase = -1000;
+  r.pos = (r.size - 1) * 8 + highbit(last);
   return true;
 }
-ZS_HD uint32_t bitr_peek(BitR& r, int n) {  // n <= 32
+ZS_HD uint32_t bitr_peek(BitR& r, int n) {  // n <= 32; bits below the start of the stream read as zero
   if (n == 0) return 0;
-  const int64_t lo = r.pos - n;
+  const int32_t lo = r.pos - n;
   if (!(lo >= r.cbase && r.pos <= r.cbase + 64)) {
-    // window whose top byte holds bit pos-1
-    const int64_t top = (r.pos - 1) >> 3;
-    const int64_t b0 = top - 7;
+    // window whose top byte holds bit pos-1 (arithmetic shift: positions below the stream stay consistent)
+    const int32_t top = (r.pos - 1) >> 3;
+    const int32_t b0 = top - 7;
     r.cbase = b0 * 8;
     r.cache = load_bits64(r.p, r.size, b0);
+#ifdef S3S_ZSTD_DEVICE
+    if (r.uniform) r.cache = (uint64_t)ZS_UNI32((uint32_t)r.cache) | ((uint64_t)ZS_UNI32((uint32_t)(r.cache >> 32)) << 32);
+#endif
   }
-  if (lo >= r.cbase) return (uint32_t)((r.cache >> (lo - r.cbase)) & ((n == 32) ? 0xFFFFFFFFull : ((1ull << n) - 1)));
-  // (only when pos < n: below the start of the stream) bits under 0 read as zero
-  uint32_t v = 0;
-  for (int i = 0; i < n; i++) {
-    const int64_t b = lo + i;
-    if (b >= 0 && b < r.size * 8) v |= (uint32_t)((r.p[b >> 3] >> (b & 7)) & 1) << i;
-  }
-  return v;
+  return (uint32_t)((r.cache >> (lo - r.cbase)) & ((n == 32) ? 0xFFFFFFFFull : ((1ull << n) - 1)));
 }
 ZS_HD uint32_t bitr_read(BitR& r, int n) {
   const uint32_t v = bitr_peek(r, n);
@@ -371,7 +380,7 @@ ZS_HD int read_huf_table(Work& w, const uint8_t* p, int64_t size) {
 // one Huffman stream: n symbols into dst
 ZS_HD int huf_decode_stream(const Work& w, const uint8_t* p, int64_t size, uint8_t* dst, int64_t n) {
   BitR r;
-  if (!bitr_init(r, p, size)) return ZS_FAIL();
+  if (!bitr_init(r, p, size, false)) return ZS_FAIL();
   const int log = w.huf_log;
   for (int64_t i = 0; i < n; i++) {
     const uint32_t v = bitr_peek(r, log);  // (bits below the start of the stream read as zero, like libzstd's container)
@@ -384,20 +393,69 @@ ZS_HD int huf_decode_stream(const Work& w, const uint8_t* p, int64_t size, uint8
 }
 
 // ---- cooperative copies ---------------------------------------------------------------------------------------------------------
-ZS_HD void copy_plain(uint8_t* dst, const uint8_t* src, int64_t n, Lanes L) {  // disjoint ranges
-  for (int64_t i = L.lane; i < n; i += L.n) dst[i] = src[i];
+// Every output byte goes to global memory AND into the ring.  out = the frame's output base, q = position in the frame.
+ZS_HD void put_plain(Work& w, uint8_t* out, int64_t q, const uint8_t* src, int64_t n, Lanes L) {  // src: global, not the output
+  for (int64_t i = L.lane; i < n; i += L.n) {
+    const uint8_t v = src[i];
+    w.ring[(q + i) & (kRing - 1)] = v;
+    out[q + i] = v;
+  }
 }
-ZS_HD void fill_byte(uint8_t* dst, uint8_t v, int64_t n, Lanes L) {
-  for (int64_t i = L.lane; i < n; i += L.n) dst[i] = v;
+ZS_HD void put_fill(Work& w, uint8_t* out, int64_t q, uint8_t v, int64_t n, Lanes L) {
+  for (int64_t i = L.lane; i < n; i += L.n) {
+    w.ring[(q + i) & (kRing - 1)] = v;
+    out[q + i] = v;
+  }
 }
-// match copy: out[i] = out[i - offset], i in [0, n); with offset < n the source repeats with period `offset`, and every
-// byte of the period was written BEFORE this copy started, so no lane depends on another lane's store
-ZS_HD void copy_match(uint8_t* out, int64_t offset, int64_t n, Lanes L) {
-  const uint8_t* pat = out - offset;
-  if (offset >= n) {
-    for (int64_t i = L.lane; i < n; i += L.n) out[i] = pat[i];
-  } else {
-    for (int64_t i = L.lane; i < n; i += L.n) out[i] = pat[i % offset];
+// literals [lp, lp + n) of the block: through the LDS window when the run fits it (one coalesced refill per 2 KiB of
+// literals instead of a global round trip per sequence)
+ZS_HD void put_literals(Work& w, uint8_t* out, int64_t q, const uint8_t* lit, int64_t lit_total, int64_t lp, int64_t n, Lanes L) {
+  if (n > kLitW) {
+    put_plain(w, out, q, lit + lp, n, L);
+    return;
+  }
+  if (w.litw_base < 0 || lp < w.litw_base || lp + n > w.litw_base + kLitW) {
+    const int64_t left = lit_total - lp;
+    const int64_t m = left < kLitW ? left : kLitW;
+    for (int64_t i = L.lane; i < m; i += L.n) w.litw[i] = lit[lp + i];
+    w.litw_base = lp;
+#ifdef S3S_ZSTD_DEVICE
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#endif
+  }
+  const int64_t o = lp - w.litw_base;
+  for (int64_t i = L.lane; i < n; i += L.n) {
+    const uint8_t v = w.litw[o + i];
+    w.ring[(q + i) & (kRing - 1)] = v;
+    out[q + i] = v;
+  }
+}
+// match: out[q + i] = out[q + i - offset], i in [0, n); with offset < n the source repeats with period `offset`, and every
+// byte of the period was written BEFORE this copy started, so no lane depends on another lane's store.  near = the
+// source is still in the ring (offset + n <= kRing: this copy does not overwrite what it reads).
+ZS_HD void put_match(Work& w, uint8_t* out, int64_t q, int64_t offset, int64_t n, bool near, Lanes L) {
+  const int64_t s0 = q - offset;
+  if (near) {
+    if (offset >= n) {
+      for (int64_t i = L.lane; i < n; i += L.n) {
+        const uint8_t v = w.ring[(s0 + i) & (kRing - 1)];
+        w.ring[(q + i) & (kRing - 1)] = v;
+        out[q + i] = v;
+      }
+    } else {
+      for (int64_t i = L.lane; i < n; i += L.n) {
+        const uint8_t v = w.ring[(s0 + i % offset) & (kRing - 1)];
+        w.ring[(q + i) & (kRing - 1)] = v;
+        out[q + i] = v;
+      }
+    }
+    return;
+  }
+  const uint8_t* pat = out + s0;
+  for (int64_t i = L.lane; i < n; i += L.n) {
+    const uint8_t v = pat[offset >= n ? i : i % offset];
+    w.ring[(q + i) & (kRing - 1)] = v;
+    out[q + i] = v;
   }
 }
 
@@ -457,6 +515,7 @@ ZS_HD int decode_frame(Work& w, const uint8_t* src, int64_t size, uint8_t* dst, 
   uint32_t rep[3] = {1, 4, 8};
   int64_t lit_need = 0;
   w.have_huf = w.have_ll = w.have_ml = w.have_of = 0;
+  w.vals_ll = w.vals_ml = 0;
   int64_t op = 0;          // bytes produced in this frame
   int64_t visible = 0;     // bytes of this frame's output every lane may read (fence issued behind them)
   for (;;) {
@@ -470,7 +529,7 @@ ZS_HD int decode_frame(Work& w, const uint8_t* src, int64_t size, uint8_t* dst, 
       if (bsize > kMaxBlock || ip + bsize > size) return ZS_FAIL();
       if (execute) {
         if (op + bsize > cap) return ZS_CAPACITY;
-        copy_plain(dst + op, src + ip, bsize, L);
+        put_plain(w, dst, op, src + ip, bsize, L);
       }
       ip += bsize;
       op += bsize;
@@ -478,7 +537,7 @@ ZS_HD int decode_frame(Work& w, const uint8_t* src, int64_t size, uint8_t* dst, 
       if (bsize > kMaxBlock || ip + 1 > size) return ZS_FAIL();
       if (execute) {
         if (op + bsize > cap) return ZS_CAPACITY;
-        fill_byte(dst + op, src[ip], bsize, L);
+        put_fill(w, dst, op, src[ip], bsize, L);
       }
       ip += 1;
       op += bsize;
@@ -588,6 +647,7 @@ ZS_HD int decode_frame(Work& w, const uint8_t* src, int64_t size, uint8_t* dst, 
       }
       int64_t lit_pos = 0;
       int64_t bop = op;  // output position at the start of the block
+      w.litw_base = -1;
       if (nseq > 0) {
         if (b >= bend) return ZS_FAIL();
         const int modes = b[0];
@@ -624,13 +684,29 @@ ZS_HD int decode_frame(Work& w, const uint8_t* src, int64_t size, uint8_t* dst, 
             return ZS_FAIL();
           }
         }
+        if (modes >> 6 != 3 || !w.vals_ll)  // (a repeated table keeps its values)
+          for (int u = L.lane; u < (1 << w.ll_log); u += L.n) {
+            const int c = (int)(w.ll[u] >> 24);
+            w.llv[u] = ll_base(c) | ((uint32_t)ll_bits(c) << 24);
+          }
+        if (((modes >> 2) & 3) != 3 || !w.vals_ml)
+          for (int u = L.lane; u < (1 << w.ml_log); u += L.n) {
+            const int c = (int)(w.ml[u] >> 24);
+            w.mlv[u] = ml_base(c) | ((uint32_t)ml_bits(c) << 24);
+          }
+        w.vals_ll = w.vals_ml = 1;
+#ifdef S3S_ZSTD_DEVICE
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (lane-strided LDS fills above, read by every lane below)
+        __builtin_amdgcn_s_barrier();
+#endif
         BitR r;
         if (!bitr_init(r, b, bend - b)) return ZS_FAIL();
         uint32_t sl = bitr_read(r, w.ll_log), so = bitr_read(r, w.of_log), sm = bitr_read(r, w.ml_log);
         if (r.pos < 0) return ZS_FAIL();
         for (int64_t i = 0; i < nseq; i++) {
-          const uint32_t el = w.ll[sl], eo = w.of[so], em = w.ml[sm];
-          const int cl = (int)(el >> 24), co = (int)(eo >> 24), cm = (int)(em >> 24);
+          const uint32_t el = ZS_UNI32(w.ll[sl]), eo = ZS_UNI32(w.of[so]), em = ZS_UNI32(w.ml[sm]);
+          const uint32_t vl = ZS_UNI32(w.llv[sl]), vm = ZS_UNI32(w.mlv[sm]);
+          const int co = (int)(eo >> 24);
           if (co > 31) return ZS_FAIL();
           // extra bits: offset, match length, literal length
           uint32_t ov;
@@ -641,8 +717,8 @@ ZS_HD int decode_frame(Work& w, const uint8_t* src, int64_t size, uint8_t* dst, 
             ov = bitr_read(r, co);
           }
           const uint64_t oval = (1ull << co) + ov;
-          const int64_t mlen = (int64_t)ml_base(cm) + bitr_read(r, ml_bits(cm));
-          const int64_t llen = (int64_t)ll_base(cl) + bitr_read(r, ll_bits(cl));
+          const int64_t mlen = (int64_t)(vm & 0xFFFFFFu) + bitr_read(r, (int)(vm >> 24));
+          const int64_t llen = (int64_t)(vl & 0xFFFFFFu) + bitr_read(r, (int)(vl >> 24));
           if (i + 1 < nseq) {  // state updates: LL, ML, OF
             sl = (el & 0xFFFFu) + bitr_read(r, (int)((el >> 16) & 0xff));
             sm = (em & 0xFFFFu) + bitr_read(r, (int)((em >> 16) & 0xff));
@@ -679,17 +755,19 @@ ZS_HD int decode_frame(Work& w, const uint8_t* src, int64_t size, uint8_t* dst, 
           if (execute) {
             if (op + llen + mlen > cap) return ZS_CAPACITY;
             if (llen) {
-              if (lit_rle >= 0) fill_byte(dst + op, (uint8_t)lit_rle, llen, L);
-              else copy_plain(dst + op, lit + lit_pos, llen, L);
+              if (lit_rle >= 0) put_fill(w, dst, op, (uint8_t)lit_rle, llen, L);
+              else put_literals(w, dst, op, lit, regen, lit_pos, llen, L);
             }
-            // the match may read what other lanes wrote since the last fence
-            const int64_t mstart = op + llen - (int64_t)offset;
-            const int64_t mend = (int64_t)offset >= mlen ? mstart + mlen : op + llen;
-            if (mend > visible) {
-              ZS_FENCE();
-              visible = op + llen;
+            const bool near = (int64_t)offset + mlen <= kRing;
+            if (!near) {  // a far source comes from global memory: what was stored since the last fence must have landed
+              const int64_t mstart = op + llen - (int64_t)offset;
+              const int64_t mend = (int64_t)offset >= mlen ? mstart + mlen : op + llen;
+              if (mend > visible) {
+                ZS_FENCE();
+                visible = op + llen;
+              }
             }
-            copy_match(dst + op + llen, (int64_t)offset, mlen, L);
+            put_match(w, dst, op + llen, (int64_t)offset, mlen, near, L);
           }
           lit_pos += llen;
           op += llen + mlen;
@@ -704,8 +782,8 @@ ZS_HD int decode_frame(Work& w, const uint8_t* src, int64_t size, uint8_t* dst, 
       if (execute) {
         if (op + rest > cap) return ZS_CAPACITY;
         if (rest) {
-          if (lit_rle >= 0) fill_byte(dst + op, (uint8_t)lit_rle, rest, L);
-          else copy_plain(dst + op, lit + lit_pos, rest, L);
+          if (lit_rle >= 0) put_fill(w, dst, op, (uint8_t)lit_rle, rest, L);
+          else put_literals(w, dst, op, lit, regen, lit_pos, rest, L);
         }
       }
       op += rest;
