@@ -750,6 +750,17 @@ class Program:
                     a, ok = _dpp_src(w, i, a, None)
                     r = f(a, b)
                     w.wv32(i.ops[0], np.where(ok, r, w.v[i.ops[0][1]]))
+                elif i.mods.get("clamp"):
+                    # integer clamp: the result saturates instead of wrapping (hipcc: `cond ? 0 : x - 4` -> v_sub_u32 ... clamp)
+                    if base == "v_sub_u32":
+                        w.wv32(i.ops[0], np.where(a >= b, a - b, np.uint32(0)))
+                    elif base == "v_subrev_u32":
+                        w.wv32(i.ops[0], np.where(b >= a, b - a, np.uint32(0)))
+                    elif base == "v_add_u32":
+                        r = a.astype(np.uint64) + b.astype(np.uint64)
+                        w.wv32(i.ops[0], np.minimum(r, np.uint64(0xFFFFFFFF)).astype(np.uint32))
+                    else:
+                        raise EmuError("clamp not modelled for " + base)
                 else:
                     w.wv32(i.ops[0], f(a, b))
             return run
@@ -817,7 +828,7 @@ class Program:
              "ubyte_d16": 1, "ubyte_d16_hi": 1, "short_d16": 2, "short_d16_hi": 2}[ty]
 
         def run(w, i, n=n, ty=ty):
-            addrs = self._gaddr(w, i, i.ops[1], i.ops[2])
+            addrs = self._gaddr(w, i, i.ops[1], i.ops[2] if len(i.ops) > 2 else ("off",))  # (flat_load: no saddr)
             e = w.em()
             raw = w.mem.load(addrs, e, n)
             d = i.ops[0][1]
@@ -845,7 +856,7 @@ class Program:
         n = {"byte": 1, "short": 2, "dword": 4, "dwordx2": 8, "dwordx3": 12, "dwordx4": 16}[ty]
 
         def run(w, i, n=n):
-            addrs = self._gaddr(w, i, i.ops[0], i.ops[2])
+            addrs = self._gaddr(w, i, i.ops[0], i.ops[2] if len(i.ops) > 2 else ("off",))  # (flat_store: no saddr)
             e = w.em()
             d = i.ops[1][1]
             if n >= 4:
@@ -1335,6 +1346,22 @@ class Program:
         addrs = self._gaddr(w, i, i.ops[0], i.ops[2])
         data = w.v[i.ops[1][1]].astype("<u4").view(np.uint8).reshape(64, 4)
         w.mem.store(addrs, w.em(), np.ascontiguousarray(data))
+
+    def x_global_atomic_add(self, w, i):
+        # with return: global_atomic_add vdst, vaddr, vdata, saddr sc0 — lanes take their turn in lane order
+        ret = len(i.ops) == 4
+        vaddr, vdata, saddr = (i.ops[1], i.ops[2], i.ops[3]) if ret else (i.ops[0], i.ops[1], i.ops[2])
+        addrs = self._gaddr(w, i, vaddr, saddr)
+        e = w.em()
+        for lane in np.flatnonzero(e):
+            one = np.zeros(64, dtype=bool)
+            one[lane] = True
+            old = w.mem.load(addrs, one, 4).view("<u4")[lane, 0]
+            new = np.zeros((64, 4), dtype=np.uint8)
+            new[lane] = np.array([(int(old) + int(w.v[vdata[1]][lane])) & 0xFFFFFFFF], dtype="<u4").view(np.uint8)
+            w.mem.store(addrs, one, new)
+            if ret:
+                w.v[i.ops[0][1]][lane] = old
 
     def x_v_bitop3_b32(self, w, i):
         # result bit = table[(a << 2) | (b << 1) | c]   (a, b, c = the bits of src0, src1, src2)
