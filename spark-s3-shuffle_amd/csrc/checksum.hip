@@ -51,25 +51,45 @@ __device__ __forceinline__ uint32_t x8n(const uint32_t* x2n, uint64_t n) {
   return p;
 }
 
-__device__ __forceinline__ uint32_t block_reduce_xor(uint32_t v, uint32_t* scratch) {
+// CRC-32 without LDS (round 3).  The slice-by-4 tables cost 4 random LDS reads per 4 input bytes: ~4-way bank conflicts, and
+// next to a codec kernel every byte of LDS is booked, so the checksum workgroups waited for a parse to finish.  A table
+// lookup is linear over GF(2): T[b] = T[b & 0x0f] ^ T[b & 0xf0], so a 256-entry table is two 16-entry ones — and 16 entries
+// fit the lanes of ONE register.  Eight registers hold the nibble tables of the four slice positions; a lookup is a
+// ds_bpermute_b32 with the nibble as lane index (the LDS crossbar, no LDS memory; lanes that read the same source lane
+// are a broadcast, different ones hit different banks: conflict-free by construction).
+struct NibbleTabs {
+  uint32_t t[8];  // t[2 j + h]: lane v holds slice[3 - j][h ? v << 4 : v]   (j = byte of the word, h = high nibble)
+};
+__device__ __forceinline__ NibbleTabs load_nibble_tabs(const Tables* tabs, int lane) {
+  NibbleTabs n;
+  const uint32_t v = (uint32_t)lane & 15u;
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v ^= __shfl_xor(v, d);
-  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
-  __syncthreads();
-  uint32_t r = 0;
-  for (int w = 0; w < kThreads / kWave; w++) r ^= scratch[w];
-  __syncthreads();
-  return r;
+  for (int k = 0; k < 8; k++) n.t[k] = tabs->slice[3 - (k >> 1)][(k & 1) ? (v << 4) : v];
+  return n;
 }
-__device__ __forceinline__ uint32_t block_reduce_add(uint32_t v, uint32_t* scratch) {
+__device__ __forceinline__ uint32_t nib_lookup(uint32_t table_reg, uint32_t idx_times_4) {
+  return (uint32_t)__builtin_amdgcn_ds_bpermute((int)idx_times_4, (int)table_reg);
+}
+// one slice-by-4 step: c (already xor-ed with the next word) -> crc after these four bytes
+__device__ __forceinline__ uint32_t crc_word(const NibbleTabs& n, uint32_t c) {
+  const uint32_t a0 = nib_lookup(n.t[0], (c << 2) & 0x3cu), a1 = nib_lookup(n.t[1], (c >> 2) & 0x3cu);
+  const uint32_t a2 = nib_lookup(n.t[2], (c >> 6) & 0x3cu), a3 = nib_lookup(n.t[3], (c >> 10) & 0x3cu);
+  const uint32_t a4 = nib_lookup(n.t[4], (c >> 14) & 0x3cu), a5 = nib_lookup(n.t[5], (c >> 18) & 0x3cu);
+  const uint32_t a6 = nib_lookup(n.t[6], (c >> 22) & 0x3cu), a7 = nib_lookup(n.t[7], (c >> 26) & 0x3cu);
+  return (a0 ^ a1 ^ a2) ^ (a3 ^ a4 ^ a5) ^ (a6 ^ a7);
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
-  __syncthreads();
-  uint32_t r = 0;
-  for (int w = 0; w < kThreads / kWave; w++) r += scratch[w];
-  __syncthreads();
-  return r;
+  for (int d = 32; d >= 1; d >>= 1) {
+    const int o = __shfl_xor(v, d);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+// one byte: crc = slice[0][(c ^ b) & 0xff] ^ (c >> 8); slice[0] is position j = 3: registers 6, 7
+__device__ __forceinline__ uint32_t crc_byte(const NibbleTabs& n, uint32_t c, uint32_t b) {
+  const uint32_t x = c ^ b;
+  return nib_lookup(n.t[6], (x << 2) & 0x3cu) ^ nib_lookup(n.t[7], (x >> 2) & 0x3cu) ^ (c >> 8);
 }
 
 // partial[seg] = { A|crc, B, seg_len, 0 }
@@ -78,8 +98,6 @@ __global__ __launch_bounds__(kThreads) void checksum_segments_kernel(
     const uint8_t* __restrict__ data, const int64_t* __restrict__ offsets, int32_t n,
     const int32_t* __restrict__ seg_start, const Tables* __restrict__ tabs,
     uint32_t* __restrict__ partial, int64_t data_len) {
-  __shared__ uint32_t lds_slice[4 * 256];
-  __shared__ uint32_t scratch[kThreads / kWave];
   const int b = blockIdx.x, tid = threadIdx.x;
   // which range owns worst-case segment slot b
   int lo = 0, hi = n;  // seg_start[lo] <= b < seg_start[hi]
@@ -98,14 +116,39 @@ __global__ __launch_bounds__(kThreads) void checksum_segments_kernel(
   if (pstart + soff + seg_len > data_len) return;
   const uint8_t* g = data + pstart + soff;
 
-  if (ALGO == S3S_CHECKSUM_CRC32) {
-    for (int i = tid; i < 4 * 256; i += kThreads) lds_slice[i] = (&tabs->slice[0][0])[i];
-    __syncthreads();
-  }
+  NibbleTabs nt;
+  if (ALGO == S3S_CHECKSUM_CRC32) nt = load_nibble_tabs(tabs, tid);
   // pieces are right-aligned: thread t of T owns [seg_len - 64*(T-t), seg_len - 64*(T-1-t))
   const int T = (seg_len + kPiece - 1) / kPiece;
   uint32_t v0 = 0, v1 = 0;
-  if (tid < T) {
+  if (ALGO == S3S_CHECKSUM_CRC32) {
+    // every lane of the wavefront takes part in the cross-lane lookups: no early-out per thread; idle threads chew zeros
+    const bool mine = tid < T;
+    const int end = mine ? seg_len - kPiece * (T - 1 - tid) : 0;
+    const int beg = end - kPiece > 0 ? end - kPiece : 0;
+    const int pl = end - beg;
+    uint32_t c = 0xFFFFFFFFu;
+    const bool full = pl == kPiece;
+    uint4 q[4] = {};
+    if (full) __builtin_memcpy(q, g + beg, 64);
+    const uint32_t* wds = reinterpret_cast<const uint32_t*>(q);
+    if (__ballot(full)) {  // (wave-uniform: the lookups below are executed by all 64 lanes)
+      uint32_t cf = 0xFFFFFFFFu;
+#pragma unroll
+      for (int j = 0; j < 16; j++) cf = crc_word(nt, cf ^ wds[j]);
+      c = full ? cf : c;
+    }
+    // the segment's first piece may be short (right-aligned pieces): byte steps, by whoever has one
+    const int maxpl = __builtin_amdgcn_readfirstlane(wave_max_i32(full ? 0 : pl));
+    for (int k = 0; k < maxpl; k++) {
+      const bool on = !full && k < pl;
+      const uint32_t bv = on ? (uint32_t)g[beg + k] : 0u;
+      const uint32_t cn = crc_byte(nt, c, bv);
+      c = on ? cn : c;
+    }
+    c = ~c;
+    v0 = mine ? multmodp(tabs->pow_piece[T - 1 - tid], c) : 0u;  // shift by the bytes after this piece
+  } else if (tid < T) {
     const int end = seg_len - kPiece * (T - 1 - tid);
     const int beg = end - kPiece > 0 ? end - kPiece : 0;
     const int pl = end - beg;
@@ -133,23 +176,6 @@ __global__ __launch_bounds__(kThreads) void checksum_segments_kernel(
       const uint32_t after = (uint32_t)(seg_len - end);  // < 16384
       v0 = s1;                              // <= 16320
       v1 = (s2 + s1 * after) % kAdlerMod;   // < 2^32 before the mod
-    } else {
-      uint32_t c = 0xFFFFFFFFu;
-      if (pl == kPiece) {
-        uint4 q[4];
-        __builtin_memcpy(q, g + beg, 64);
-        const uint32_t* wds = reinterpret_cast<const uint32_t*>(q);
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-          c ^= wds[j];
-          c = lds_slice[768 + (c & 0xff)] ^ lds_slice[512 + ((c >> 8) & 0xff)] ^
-              lds_slice[256 + ((c >> 16) & 0xff)] ^ lds_slice[c >> 24];
-        }
-      } else {
-        for (int k = 0; k < pl; k++) c = lds_slice[(c ^ g[beg + k]) & 0xff] ^ (c >> 8);
-      }
-      c = ~c;
-      v0 = multmodp(tabs->pow_piece[T - 1 - tid], c);  // shift by the bytes after this piece
     }
   }
   uint32_t* out = partial + 4 * (size_t)b;
@@ -170,11 +196,12 @@ __global__ __launch_bounds__(kThreads) void checksum_segments_kernel(
     }
     if (tid == 0) out[2] = (uint32_t)seg_len;
   } else {
-    const uint32_t c = block_reduce_xor(v0, scratch);
-    if (tid == 0) {
-      out[0] = c;
-      out[2] = (uint32_t)seg_len;
-    }
+    // NO LDS either: wavefront xor, then one atomic per wavefront into the zero-initialised partial
+    uint32_t c = v0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c ^= __shfl_xor(c, d);
+    if ((tid & 63) == 0) atomicXor(&out[0], c);
+    if (tid == 0) out[2] = (uint32_t)seg_len;
   }
 }
 
@@ -183,8 +210,6 @@ __global__ __launch_bounds__(kThreads) void checksum_combine_kernel(
     const int64_t* __restrict__ offsets, int32_t n, const int32_t* __restrict__ seg_start,
     const Tables* __restrict__ tabs, const uint32_t* __restrict__ partial,
     int64_t* __restrict__ out) {
-  __shared__ uint32_t scratch[kThreads / kWave];
-  __shared__ uint32_t lds_x2n[32];
   const int p = blockIdx.x, tid = threadIdx.x;
   if (p >= n) return;
   const int64_t plen = offsets[p + 1] - offsets[p];
@@ -211,24 +236,25 @@ __global__ __launch_bounds__(kThreads) void checksum_combine_kernel(
       out[p] = (int64_t)(((uint64_t)fb << 16) | fa);
     }
   } else {
-    if (tid < 32) lds_x2n[tid] = tabs->x2n[tid];
-    __syncthreads();
-    // thread j folds a contiguous run of segments Horner-style, then shifts the run to the end
-    const int64_t run = (nseg + kThreads - 1) / kThreads;
+    // one wavefront per partition, no LDS (see checksum_segments_kernel): lane j folds a contiguous run of segments
+    // Horner-style, shifts the run to the end of the partition, the runs are xor-ed across the wave
+    const uint32_t* x2n = tabs->x2n;
+    const int64_t run = (nseg + kWave - 1) / kWave;
     const int64_t s0 = (int64_t)tid * run, s1 = (s0 + run) < nseg ? (s0 + run) : nseg;
     uint32_t c = 0;
     int64_t end = 0;
     if (s0 < s1) {
-      const uint32_t xseg = x8n(lds_x2n, kChecksumSegBytes);
+      const uint32_t xseg = x8n(x2n, kChecksumSegBytes);
       for (int64_t s = s0; s < s1; s++) {
         const uint32_t len = part[4 * s + 2];
-        c = multmodp(c, len == (uint32_t)kChecksumSegBytes ? xseg : x8n(lds_x2n, len)) ^ part[4 * s];
+        c = multmodp(c, len == (uint32_t)kChecksumSegBytes ? xseg : x8n(x2n, len)) ^ part[4 * s];
         end = s * kChecksumSegBytes + len;
       }
-      c = multmodp(c, x8n(lds_x2n, (uint64_t)(plen - end)));
+      c = multmodp(c, x8n(x2n, (uint64_t)(plen - end)));
     }
-    const uint32_t r = block_reduce_xor(c, scratch);
-    if (tid == 0) out[p] = (int64_t)(uint64_t)r;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c ^= __shfl_xor(c, d);
+    if (tid == 0) out[p] = (int64_t)(uint64_t)c;
   }
 }
 
@@ -278,11 +304,13 @@ void launch_checksum_with_tables(int algo, const uint8_t* d_data, const int64_t*
     hipLaunchKernelGGL(checksum_combine_kernel<S3S_CHECKSUM_ADLER32>, dim3((unsigned)n),
                        dim3(kWave), 0, st, d_offsets, n, d_seg_start, tabs, d_partial, d_out);
   } else {
-    if (total_segs > 0)
+    if (total_segs > 0) {
+      (void)hipMemsetAsync(d_partial, 0, 16 * (size_t)total_segs, st);  // wavefront results are xor-ed in atomically
       hipLaunchKernelGGL(checksum_segments_kernel<S3S_CHECKSUM_CRC32>, dim3((unsigned)total_segs),
                          dim3(kThreads), 0, st, d_data, d_offsets, n, d_seg_start, tabs, d_partial, data_len);
+    }
     hipLaunchKernelGGL(checksum_combine_kernel<S3S_CHECKSUM_CRC32>, dim3((unsigned)n),
-                       dim3(kThreads), 0, st, d_offsets, n, d_seg_start, tabs, d_partial, d_out);
+                       dim3(kWave), 0, st, d_offsets, n, d_seg_start, tabs, d_partial, d_out);
   }
 }
 

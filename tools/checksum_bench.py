@@ -1,12 +1,14 @@
-"""s3s_checksum_ranges_device alone: Adler32 / CRC32 over 256 MiB resident in HBM (HIP-event time of the call)."""
+"""s3s_checksum_ranges_device alone: Adler32 / CRC32 over N MiB resident in HBM (default 1 GiB: past the 256 MiB MALL),
+HIP-event time of the call.  usage: python tools/checksum_bench.py [MiB]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "spark-s3-shuffle_amd")); sys.path.insert(0, ROOT)
 import numpy as np, torch, zlib
 import s3shuffle
-n = 256 << 20
+n = (int(sys.argv[1]) if len(sys.argv) > 1 else 1024) << 20
 rng = np.random.default_rng(1)
 data = rng.integers(0, 256, n, dtype=np.uint8)
+print('bytes', n, flush=True)
 d = torch.from_numpy(data).cuda()
 c = s3shuffle.Codec(0); c.set_option(3, 1)
 for nranges in (1, 200, 2000):
