@@ -394,68 +394,95 @@ ZS_HD int huf_decode_stream(const Work& w, const uint8_t* p, int64_t size, uint8
 
 // ---- cooperative copies ---------------------------------------------------------------------------------------------------------
 // Every output byte goes to global memory AND into the ring.  out = the frame's output base, q = position in the frame.
-ZS_HD void put_plain(Work& w, uint8_t* out, int64_t q, const uint8_t* src, int64_t n, Lanes L) {  // src: global, not the output
-  for (int64_t i = L.lane; i < n; i += L.n) {
+// (32-bit lane arithmetic on purpose: the runs are tens of bytes, 64-bit index math per lane was half of the decode pass)
+ZS_HD void put_plain(Work& w, uint8_t* out, int64_t q, const uint8_t* src, int64_t n64, Lanes L) {  // src: global, not the output
+  uint8_t* o = out + q;
+  const uint32_t rq = (uint32_t)q, n = (uint32_t)n64;  // (a block's output is at most 128 KiB)
+  for (uint32_t i = (uint32_t)L.lane; i < n; i += (uint32_t)L.n) {
     const uint8_t v = src[i];
-    w.ring[(q + i) & (kRing - 1)] = v;
-    out[q + i] = v;
+    w.ring[(rq + i) & (kRing - 1)] = v;
+    o[i] = v;
   }
 }
-ZS_HD void put_fill(Work& w, uint8_t* out, int64_t q, uint8_t v, int64_t n, Lanes L) {
-  for (int64_t i = L.lane; i < n; i += L.n) {
-    w.ring[(q + i) & (kRing - 1)] = v;
-    out[q + i] = v;
+ZS_HD void put_fill(Work& w, uint8_t* out, int64_t q, uint8_t v, int64_t n64, Lanes L) {
+  uint8_t* o = out + q;
+  const uint32_t rq = (uint32_t)q, n = (uint32_t)n64;
+  for (uint32_t i = (uint32_t)L.lane; i < n; i += (uint32_t)L.n) {
+    w.ring[(rq + i) & (kRing - 1)] = v;
+    o[i] = v;
   }
 }
-// literals [lp, lp + n) of the block: through the LDS window when the run fits it (one coalesced refill per 2 KiB of
+// literals [lp, lp + n) of the block: through the LDS window when the run fits it (one coalesced refill per 1 KiB of
 // literals instead of a global round trip per sequence)
-ZS_HD void put_literals(Work& w, uint8_t* out, int64_t q, const uint8_t* lit, int64_t lit_total, int64_t lp, int64_t n, Lanes L) {
-  if (n > kLitW) {
-    put_plain(w, out, q, lit + lp, n, L);
+ZS_HD void put_literals(Work& w, uint8_t* out, int64_t q, const uint8_t* lit, int64_t lit_total, int64_t lp64, int64_t n64, Lanes L) {
+  if (n64 > kLitW) {
+    put_plain(w, out, q, lit + lp64, n64, L);
     return;
   }
-  if (w.litw_base < 0 || lp < w.litw_base || lp + n > w.litw_base + kLitW) {
-    const int64_t left = lit_total - lp;
-    const int64_t m = left < kLitW ? left : kLitW;
-    for (int64_t i = L.lane; i < m; i += L.n) w.litw[i] = lit[lp + i];
+  const int32_t lp = (int32_t)lp64, n = (int32_t)n64;
+  int32_t base = (int32_t)w.litw_base;
+  if (base < 0 || lp < base || lp + n > base + kLitW) {
+    const int32_t left = (int32_t)lit_total - lp;
+    const int32_t m = left < kLitW ? left : kLitW;
+    for (int32_t i = L.lane; i < m; i += L.n) w.litw[i] = lit[lp + i];
     w.litw_base = lp;
+    base = lp;
 #ifdef S3S_ZSTD_DEVICE
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 #endif
   }
-  const int64_t o = lp - w.litw_base;
-  for (int64_t i = L.lane; i < n; i += L.n) {
-    const uint8_t v = w.litw[o + i];
-    w.ring[(q + i) & (kRing - 1)] = v;
-    out[q + i] = v;
+  uint8_t* o = out + q;
+  const uint32_t rq = (uint32_t)q;
+  const uint8_t* wsrc = w.litw + (lp - base);
+  for (uint32_t i = (uint32_t)L.lane; i < (uint32_t)n; i += (uint32_t)L.n) {
+    const uint8_t v = wsrc[i];
+    w.ring[(rq + i) & (kRing - 1)] = v;
+    o[i] = v;
   }
 }
 // match: out[q + i] = out[q + i - offset], i in [0, n); with offset < n the source repeats with period `offset`, and every
 // byte of the period was written BEFORE this copy started, so no lane depends on another lane's store.  near = the
 // source is still in the ring (offset + n <= kRing: this copy does not overwrite what it reads).
-ZS_HD void put_match(Work& w, uint8_t* out, int64_t q, int64_t offset, int64_t n, bool near, Lanes L) {
-  const int64_t s0 = q - offset;
+ZS_HD void put_match(Work& w, uint8_t* out, int64_t q, int64_t offset64, int64_t n64, bool near, Lanes L) {
+  uint8_t* o = out + q;
+  const uint32_t rq = (uint32_t)q, n = (uint32_t)n64;
   if (near) {
-    if (offset >= n) {
-      for (int64_t i = L.lane; i < n; i += L.n) {
-        const uint8_t v = w.ring[(s0 + i) & (kRing - 1)];
-        w.ring[(q + i) & (kRing - 1)] = v;
-        out[q + i] = v;
+    const uint32_t off = (uint32_t)offset64, rs = rq - off;
+    if (off >= n) {
+      for (uint32_t i = (uint32_t)L.lane; i < n; i += (uint32_t)L.n) {
+        const uint8_t v = w.ring[(rs + i) & (kRing - 1)];
+        w.ring[(rq + i) & (kRing - 1)] = v;
+        o[i] = v;
+      }
+    } else if (off == 1) {  // a run of one byte
+      const uint8_t v = w.ring[rs & (kRing - 1)];
+      for (uint32_t i = (uint32_t)L.lane; i < n; i += (uint32_t)L.n) {
+        w.ring[(rq + i) & (kRing - 1)] = v;
+        o[i] = v;
       }
     } else {
-      for (int64_t i = L.lane; i < n; i += L.n) {
-        const uint8_t v = w.ring[(s0 + i % offset) & (kRing - 1)];
-        w.ring[(q + i) & (kRing - 1)] = v;
-        out[q + i] = v;
+      for (uint32_t i = (uint32_t)L.lane; i < n; i += (uint32_t)L.n) {
+        const uint8_t v = w.ring[(rs + i % off) & (kRing - 1)];
+        w.ring[(rq + i) & (kRing - 1)] = v;
+        o[i] = v;
       }
     }
     return;
   }
-  const uint8_t* pat = out + s0;
-  for (int64_t i = L.lane; i < n; i += L.n) {
-    const uint8_t v = pat[offset >= n ? i : i % offset];
-    w.ring[(q + i) & (kRing - 1)] = v;
-    out[q + i] = v;
+  const uint8_t* pat = o - offset64;
+  if (offset64 >= n64) {
+    for (uint32_t i = (uint32_t)L.lane; i < n; i += (uint32_t)L.n) {
+      const uint8_t v = pat[i];
+      w.ring[(rq + i) & (kRing - 1)] = v;
+      o[i] = v;
+    }
+  } else {  // (offset + n > kRing and offset < n: a long run, rare)
+    const uint32_t off = (uint32_t)offset64;
+    for (uint32_t i = (uint32_t)L.lane; i < n; i += (uint32_t)L.n) {
+      const uint8_t v = pat[i % off];
+      w.ring[(rq + i) & (kRing - 1)] = v;
+      o[i] = v;
+    }
   }
 }
 
@@ -752,6 +779,9 @@ ZS_HD int decode_frame(Work& w, const uint8_t* src, int64_t size, uint8_t* dst, 
           }
           if (lit_pos + llen > regen) return ZS_FAIL();
           if ((int64_t)offset > op + llen || offset == 0) return ZS_FAIL();  // (no dictionary: history starts with the frame)
+#ifdef ZS_STATS_HOOK
+          ZS_STATS_HOOK((int64_t)offset, mlen, llen);
+#endif
           if (execute) {
             if (op + llen + mlen > cap) return ZS_CAPACITY;
             if (llen) {
