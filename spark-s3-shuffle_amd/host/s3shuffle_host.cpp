@@ -74,13 +74,30 @@ S3ShuffleDispatcher::S3ShuffleDispatcher(const Conf& conf) : conf_(conf) {
   ngpu_ = conf.numGpus > 0 ? std::min(conf.numGpus, std::max(visible, 1)) : std::max(visible, 1);
 }
 
+// JavaUtils.nonNegativeHash(String): String.hashCode (s[0]*31^(n-1) + ... in 32-bit wrap-around), abs, MIN_VALUE -> 0
+static int32_t java_non_negative_hash(const std::string& s) {
+  uint32_t h = 0;
+  for (unsigned char c : s) h = 31u * h + c;
+  const int32_t v = (int32_t)h;
+  return v == INT32_MIN ? 0 : (v < 0 ? -v : v);
+}
+
 std::string S3ShuffleDispatcher::getPath(const BlockId& id) const {
+  if (conf_.useSparkShuffleFetch) {
+    // ${rootDir}${appId}/${shuffleId}/${nonNegativeHash(name)}/${name}: Spark's FallbackStorage layout (:132-141); only the
+    // three stored block kinds have a place there
+    if (id.kind != BlockId::SHUFFLE_DATA && id.kind != BlockId::SHUFFLE_INDEX && id.kind != BlockId::SHUFFLE_CHECKSUM)
+      throw SparkException("Unsupported block id type: " + id.name());
+    const std::string name = id.name();
+    return root_ + conf_.appId + "/" + std::to_string(id.shuffleId) + "/" + std::to_string(java_non_negative_hash(name)) + "/" + name;
+  }
   // ${rootDir}${mapId % folderPrefixes}/${appId}/${shuffleId}/${blockId.name}   (:142-143)
   const long long idx = (long long)(id.mapId % conf_.folderPrefixes);
   return root_ + std::to_string(idx) + "/" + conf_.appId + "/" + std::to_string(id.shuffleId) + "/" + id.name();
 }
 
 std::vector<BlockId> S3ShuffleDispatcher::listShuffleIndices(int shuffleId) const {
+  if (conf_.useSparkShuffleFetch) throw SparkException("Not supported.");  // (:147-149)
   std::vector<BlockId> out;
   for (int idx = 0; idx < conf_.folderPrefixes; idx++) {
     const std::string dir = root_ + std::to_string(idx) + "/" + conf_.appId + "/" + std::to_string(shuffleId) + "/";
@@ -522,6 +539,9 @@ void* s3sh_dispatcher_create(const char* rootDir, const char* appId, int folderP
   return r;
 }
 void s3sh_dispatcher_destroy(void* d) { delete static_cast<S3ShuffleDispatcher*>(d); }
+int s3sh_dispatcher_set_use_spark_shuffle_fetch(void* d, int on) {
+  return guarded([&] { static_cast<S3ShuffleDispatcher*>(d)->setUseSparkShuffleFetch(on != 0); });
+}
 int s3sh_get_path(void* d, int kind, int shuffleId, long long mapId, int r0, int r1, char* out, int cap) {
   return guarded([&] {
     BlockId id{(BlockId::Kind)kind, shuffleId, mapId, r0, r1};

@@ -73,6 +73,7 @@ struct Conf {
   std::string appId = "app";                 // spark.app.id
   int folderPrefixes = 10;                   // spark.shuffle.s3.folderPrefixes
   bool alwaysCreateIndex = false;            // spark.shuffle.s3.alwaysCreateIndex
+  bool useSparkShuffleFetch = false;         // spark.shuffle.s3.useSparkShuffleFetch: the fallback-storage object layout
   bool checksumEnabled = true;               // spark.shuffle.checksum.enabled
   std::string checksumAlgorithm = "ADLER32";  // spark.shuffle.checksum.algorithm
   bool compress = true;                      // spark.shuffle.compress
@@ -101,6 +102,7 @@ class S3ShuffleDispatcher {
   int codecId() const;      // S3S_CODEC_*
   int checksumId() const;   // S3S_CHECKSUM_*; throws UnsupportedOperationException-like for unknown names
   int deviceForMap(int64_t mapId) const;
+  void setUseSparkShuffleFetch(bool on) { conf_.useSparkShuffleFetch = on; }
   void setPrefetch(int64_t maxBufferSizeTask, int maxConcurrencyTask, int gpuDecodeThreads, int64_t gpuMaxDecodedBufferSizeTask) {
     if (maxBufferSizeTask > 0) conf_.maxBufferSizeTask = maxBufferSizeTask;
     if (maxConcurrencyTask > 0) conf_.maxConcurrencyTask = maxConcurrencyTask;

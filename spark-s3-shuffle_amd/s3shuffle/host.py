@@ -38,6 +38,7 @@ def _lib():
                                              ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
         vp = ctypes.c_void_p
         L.s3sh_dispatcher_destroy.argtypes = [vp]
+        L.s3sh_dispatcher_set_use_spark_shuffle_fetch.argtypes = [vp, ctypes.c_int]
         L.s3sh_get_path.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
         L.s3sh_device_for_map.argtypes = [vp, ctypes.c_longlong]
         L.s3sh_write_partition_lengths.argtypes = [vp, ctypes.c_int, ctypes.c_longlong, vp, ctypes.c_int]
@@ -100,6 +101,11 @@ class Dispatcher:
         if self._h:
             _lib().s3sh_dispatcher_destroy(self._h)
             self._h = None
+
+    def set_use_spark_shuffle_fetch(self, on: bool = True):
+        """spark.shuffle.s3.useSparkShuffleFetch: objects live where Spark's FallbackStorage looks for them
+        (S3ShuffleDispatcher.scala:132-141)."""
+        _check(_lib().s3sh_dispatcher_set_use_spark_shuffle_fetch(self._h, int(on)))
 
     def get_path(self, kind: int, shuffle_id: int, map_id: int, r0: int = 0, r1: int = 1) -> str:
         buf = ctypes.create_string_buffer(1024)

@@ -43,9 +43,23 @@ def block_name(shuffle_id: int, map_id: int, kind: str) -> str:
     return f"shuffle_{shuffle_id}_{map_id}_0.{kind}"
 
 
+def java_non_negative_hash(name: str) -> int:
+    """JavaUtils.nonNegativeHash(String): String.hashCode in 32-bit wrap-around arithmetic, absolute value, MIN_VALUE -> 0."""
+    h = 0
+    for c in name:
+        h = (31 * h + ord(c)) & 0xFFFFFFFF
+    v = h - (1 << 32) if h & 0x80000000 else h
+    return 0 if v == -(1 << 31) else abs(v)
+
+
 def block_path(root_dir: str, app_id: str, shuffle_id: int, map_id: int, kind: str,
-               folder_prefixes: int = 10) -> str:
+               folder_prefixes: int = 10, use_spark_shuffle_fetch: bool = False) -> str:
     """`${rootDir}${mapId % folderPrefixes}/${appId}/${shuffleId}/${blockId.name}`
-    (S3ShuffleDispatcher.getPath, S3ShuffleDispatcher.scala:120-144, default layout)."""
+    (S3ShuffleDispatcher.getPath, S3ShuffleDispatcher.scala:120-144, default layout), or with
+    spark.shuffle.s3.useSparkShuffleFetch Spark's fallback-storage layout
+    `${rootDir}${appId}/${shuffleId}/${nonNegativeHash(name)}/${name}` (:132-141)."""
     root = root_dir if root_dir.endswith("/") else root_dir + "/"
-    return f"{root}{map_id % folder_prefixes}/{app_id}/{shuffle_id}/{block_name(shuffle_id, map_id, kind)}"
+    name = block_name(shuffle_id, map_id, kind)
+    if use_spark_shuffle_fetch:
+        return f"{root}{app_id}/{shuffle_id}/{java_non_negative_hash(name)}/{name}"
+    return f"{root}{map_id % folder_prefixes}/{app_id}/{shuffle_id}/{name}"

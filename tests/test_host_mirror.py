@@ -60,6 +60,35 @@ def test_paths_and_index_format(codec_lib, root, tmp_path):
     d.close()
 
 
+def test_fallback_storage_layout(codec_lib, root, tmp_path):
+    """spark.shuffle.s3.useSparkShuffleFetch: ${rootDir}${appId}/${shuffleId}/${JavaUtils.nonNegativeHash(name)}/${name}
+    (S3ShuffleDispatcher.scala:132-141); listing is not supported there (:147-149).  String.hashCode known answers:
+    "" -> 0, "a" -> 97, "abc" -> 96354, "polygenelubricants" -> Integer.MIN_VALUE (nonNegativeHash: 0)."""
+    from s3shuffle import host, sharding
+
+    assert [sharding.java_non_negative_hash(x) for x in ("", "a", "abc", "polygenelubricants")] == [0, 97, 96354, 0]
+    assert sharding.java_non_negative_hash("shuffle_3_27_0.data") == abs(_java_hash("shuffle_3_27_0.data"))
+    d = host.Dispatcher(root, app_id="app-7", folder_prefixes=10)
+    d.set_use_spark_shuffle_fetch(True)
+    base = str(tmp_path / "spark-s3-shuffle")
+    for kind, ext in ((host.KIND_DATA, "data"), (host.KIND_INDEX, "index"), (host.KIND_CHECKSUM, "checksum")):
+        want = sharding.block_path(base, "app-7", 3, 27, ext, use_spark_shuffle_fetch=True)
+        assert d.get_path(kind, 3, 27) == want
+        assert want == f"{base}/app-7/3/{sharding.java_non_negative_hash('shuffle_3_27_0.' + ext)}/shuffle_3_27_0.{ext}"
+    with pytest.raises(host.SparkException, match="Unsupported block id type"):
+        d.get_path(host.KIND_SHUFFLE, 3, 27, 0, 1)
+    d.write_partition_lengths(3, 27, [5, 0, 7])
+    assert d.read_block_as_array(host.KIND_INDEX, 3, 27).tolist() == [0, 5, 5, 12]
+    d.close()
+
+
+def _java_hash(s):
+    h = 0
+    for c in s:
+        h = (31 * h + ord(c)) & 0xFFFFFFFF
+    return h - (1 << 32) if h & 0x80000000 else h
+
+
 def test_staging_pool_selftest(codec_lib):
     """PinnedPool (host/s3shuffle_prefetch.cpp): budget accounting and reuse, a waiter released by a release, a
     request larger than the budget running alone, cancel(), the non-blocking process pool.  On a CPU-only box the
