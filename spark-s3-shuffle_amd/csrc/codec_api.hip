@@ -819,6 +819,15 @@ int s3s_debug_read_dec(unsigned long long* out, int reset) {
   }
   return 0;
 }
+extern __device__ unsigned long long g_bdec_dbg[16];
+int s3s_debug_read_bdec(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bdec_dbg), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_bdec_dbg), z, sizeof z) != hipSuccess) return -1;
+  }
+  return 0;
+}
 extern __device__ unsigned long long g_lz4_dbg[32];
 int s3s_debug_read(unsigned long long* out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lz4_dbg), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;

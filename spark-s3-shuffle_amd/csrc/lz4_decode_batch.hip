@@ -27,6 +27,10 @@
 // liblz4 incl. malformed blocks); malformed input ends in S3S_E_BAD_FRAME, never out of bounds.
 #include "s3s_internal.h"
 
+#ifdef S3S_LZ4_TIMING
+__device__ unsigned long long g_bdec_dbg[16];  // (instrumented build: phase ticks of batch_decode_kernel)
+#endif
+
 namespace s3s {
 namespace {
 
@@ -41,10 +45,12 @@ constexpr int kBWin = S3S_BWIN;    // staged output bytes (multiple of 16); with
 constexpr int kBHist = S3S_BHIST;  // history a slide keeps
 static_assert(kBWin % 16 == 0 && kBHist % 16 == 0 && kBWin >= kBHist + 1024, "window geometry");
 constexpr int kBPad = 64;
-#ifndef S3S_SMALL_ML
-#define S3S_SMALL_ML 16
+#ifdef S3S_DEC_RING
+// (experiment, -DS3S_DEC_RING) The parse windows read the compressed stream through a ring in LDS (two halves of 256 bytes, one dword per lane per
+// refill, the next half prefetched into a register while the current one is parsed): a window's two dependent reads
+// cost two LDS round trips instead of two trips to L2.  + 4: the ring's first dword again, for reads across the end.
+constexpr int kSRing = 512, kSHalf = 256;
 #endif
-constexpr int kSmallMl = S3S_SMALL_ML;  // matches up to this length are copied one lane per sequence (4 dwords + tail in registers)
 constexpr int kSmallLit = 16; // literal runs up to this length are copied one lane per sequence
 
 constexpr uint32_t XP1 = 2654435761u, XP2 = 2246822519u, XP3 = 3266489917u, XP4 = 668265263u, XP5 = 374761393u;
@@ -57,10 +63,17 @@ __device__ __forceinline__ uint32_t g_ld32(const uint8_t* p) {
 __device__ __forceinline__ uint32_t l2_ld8(const uint8_t* p) {
   return (uint32_t)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// four bytes at an arbitrarily aligned address, served by L2 (the bytes were written by this wave's own flush)
-__device__ __forceinline__ uint32_t l2_ld32u(const uint8_t* p) {
-  return l2_ld8(p) | (l2_ld8(p + 1) << 8) | (l2_ld8(p + 2) << 16) | (l2_ld8(p + 3) << 24);
+// four bytes at an arbitrarily aligned address, served by L2 (the bytes were written by this wave's own flush):
+// gfx950 takes unaligned dword addresses, and the cache policy bit is all the atomic is for
+__device__ __forceinline__ uint32_t l2_ld32(const uint8_t* p) {
+  return __hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// Unaligned LDS dwords: gfx950 serves a ds_read / ds_write whose address is not a multiple of its width one lane at a
+// time (tools/probe/lds_align_probe.hip: 65 LDS cycles per wavefront instruction against 3.4 - 5 aligned).  A version
+// of the copies below that reads and writes aligned dwords only (v_alignbyte_b32 for the shifts, byte stores at the
+// ends of a span) removed every such stall and halved the LDS pipe's busy time — and was 7 % SLOWER: the CU's scalar
+// and vector issue (one of each per cycle for all its waves) is what this kernel runs out of, and the aligned form
+// costs 10 % more instructions (profiles/r03_experiments.md §7).
 __device__ __forceinline__ uint32_t lds_ld32(const uint8_t* p) {
   uint32_t v;
   __builtin_memcpy(&v, p, 4);  // gfx950: unaligned ds_read_b32
@@ -71,8 +84,52 @@ __device__ __forceinline__ void lds_st16(uint8_t* p, uint32_t v) {
   const uint16_t h = (uint16_t)v;
   __builtin_memcpy(p, &h, 2);
 }
+// 16 bytes at any address with ONE instruction each way (the compiler splits what it cannot prove aligned; the
+// hardware takes any address, at the unaligned cost of one dword access).  The read waits for its data; the stores
+// are ordinary in-order LDS operations (the compiler's lgkmcnt bookkeeping only gets more conservative by them).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)reinterpret_cast<uintptr_t>(p); }
+__device__ __forceinline__ u32x4 lds_ld128u(const uint8_t* p) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_addr(p)) : "memory");
+  return v;
+}
+__device__ __forceinline__ void lds_st128u(uint8_t* p, u32x4 v) {
+  asm volatile("ds_write_b128 %0, %1" : : "v"(lds_addr(p)), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_st64u(uint8_t* p, uint32_t lo, uint32_t hi) {
+  const uint64_t v = (uint64_t)lo | ((uint64_t)hi << 32);
+  asm volatile("ds_write_b64 %0, %1" : : "v"(lds_addr(p)), "v"(v) : "memory");
+}
+// the first n (1..16) bytes of x to d
+__device__ __forceinline__ void lds_store16(uint8_t* d, u32x4 x, int n) {
+  if (n == 16) {
+    lds_st128u(d, x);
+  } else {
+    const bool h8 = (n & 8) != 0;
+    if (h8) lds_st64u(d, x.x, x.y);
+    const uint32_t a = h8 ? x.z : x.x, b = h8 ? x.w : x.y;
+    if (n & 4) lds_st32(d + (n & 8), a);
+    const uint32_t tw = (n & 4) ? b : a;
+    if (n & 2) lds_st16(d + (n & 12), tw);
+    if (n & 1) d[n & 14] = (uint8_t)(tw >> ((n & 2) * 8));
+  }
+}
 
 enum { kFmtLz4 = 0, kFmtSnappy = 1 };
+
+#ifdef S3S_LZ4_TIMING
+// phase accounting of the batch decoder (instrumented build only; tools/dec_timing.py): s_memtime ticks per phase
+#define BT_DECL unsigned long long bt_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long bt_t0_ = __builtin_readcyclecounter(), bt_start_ = bt_t0_
+#define BT_MARK(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); bt_[k] += t_ - bt_t0_; bt_t0_ = t_; } while (0)
+#define BT_COUNT(k) bt_[k]++
+#define BT_DONE() do { if (lane == 0) { bt_[8] = __builtin_readcyclecounter() - bt_start_; for (int k_ = 0; k_ < 12; k_++) atomicAdd(&g_bdec_dbg[k_], bt_[k_]); atomicAdd(&g_bdec_dbg[12], 1ull); } } while (0)
+#else
+#define BT_DECL
+#define BT_MARK(k)
+#define BT_COUNT(k)
+#define BT_DONE()
+#endif
 #ifndef S3S_PWALK_TOKENS
 #define S3S_PWALK_TOKENS 12
 #endif
@@ -88,6 +145,9 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
     const int64_t* __restrict__ frame_out, uint8_t* dst, int32_t* __restrict__ status) {
   __shared__ __attribute__((aligned(16))) uint8_t win[kBWin + kBPad];
   __shared__ uint2 rec[kWave];
+#ifdef S3S_DEC_RING
+  __shared__ __attribute__((aligned(4))) uint8_t sring[kSRing + 8];
+#endif
   const int f = blockIdx.x;
   if (f >= n_frames) return;
   const Frame fr = frames[f];
@@ -136,6 +196,7 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
     bool need_drain = false;  // stores of a flush may still be in flight (matters to far matches only)
     int last_tokens = 0;      // tokens found in the previous parse window (picks the walk for this one)
     bool open_lit = false;    // Snappy: the batch's last record is a literal element that a following copy may join
+    BT_DECL;
 
     // ---- window management ---------------------------------------------------------------------------
     auto flush_to = [&](int upto) __attribute__((always_inline)) {  // window -> out for output bytes [flushed, upto)
@@ -168,6 +229,14 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
     };
     auto room = [&]() __attribute__((always_inline)) -> int { return wb + kBWin - (op + sh); };
 
+    // l0 stream bytes from position r0 to window index didx, by the whole wave (arguments uniform)
+    auto stream_to_window = [&](int didx, int r0, int l0) __attribute__((always_inline)) {
+      uint8_t* d = win + didx;
+      const int body = l0 >> 2;
+      for (int j = lane; j < body; j += kWave) lds_st32(d + 4 * j, g_ld32(c + r0 + 4 * j));
+      if (lane < (l0 & 3)) d[4 * body + lane] = c[r0 + 4 * body + lane];
+    };
+
     // ---- generic emitters: any length, chunked by the room of the window (all arguments uniform) ------
     auto emit_literals = [&](int src, int n) __attribute__((always_inline)) -> bool {
       if (n < 0 || n > clen - src || n > olen - op) return false;
@@ -175,10 +244,7 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
         if (room() == 0) slide();
         int k = room();
         k = k < n ? k : n;
-        uint8_t* d = win + (op + sh - wb);
-        const int body = k >> 2;
-        for (int j = lane; j < body; j += kWave) lds_st32(d + 4 * j, g_ld32(c + src + 4 * j));
-        if (lane < (k & 3)) d[4 * body + lane] = c[src + 4 * body + lane];
+        stream_to_window(op + sh - wb, src, k);
         op += k;
         src += k;
         n -= k;
@@ -268,34 +334,88 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
     // ---- the batch: one sequence per lane -------------------------------------------------------------
     auto flush_batch = [&]() __attribute__((always_inline)) -> bool {
       if (nseq == 0) return true;
+      BT_MARK(0);
       const uint2 rc = rec[lane];
       const bool act = lane < nseq;
       const int lit = act ? (int)(rc.x & 0xffffu) : 0;
       const int ml = act ? (int)(rc.x >> 16) : 0;
       const int off = (int)(rc.y & 0xffffu);
       const int src = (int)(rc.y >> 16);
-      // inclusive prefix sum of the sequence lengths
-      int end = lit + ml;
+      // Pieces: a match of up to 64 bytes that is not an odd periodic pattern is copied as 1..4 PIECES of 16 bytes, one
+      // lane per piece (`npc`); one inclusive prefix sum gives the output positions (low 22 bits; a lane's share is
+      // clamped so that a malformed batch cannot carry into the piece count: its `end` is above olen either way) and
+      // the piece positions (high bits).
+      const bool patok = off >= ml || off == 1 || off == 2 || off == 4;
+      const int npc = (ml > 0 && ml <= kWave && patok) ? (ml + 15) >> 4 : 0;
+      const int len0 = lit + ml;
+      int pk = (len0 < kMaxBlock + 1 ? len0 : kMaxBlock + 1) | (npc << 22);
 #pragma unroll
       for (int d = 1; d < kWave; d <<= 1) {
-        const int up = __shfl_up(end, d);
-        end += lane >= d ? up : 0;
+        const int up = __shfl_up(pk, d);
+        pk += lane >= d ? up : 0;
       }
-      end += op;
+      const int end = (pk & 0x3fffff) + op, lpe = pk >> 22, lpx = lpe - npc;  // (pieces up to and including / in front of this lane)
       const int start = end - lit - ml, mstart = end - ml;
       const bool wrong = act && ((ml > 0 && (off == 0 || off > mstart)) || end > olen || src + lit > clen);
       if (__ballot(wrong)) return false;
-      // dep: the first sequence of the batch whose match may start a round that contains this lane's match,
-      // i.e. the number of sequences t with mstart[t] < source end (binary search over the sorted mstart)
-      const int srcend = ml > 0 ? mstart - off + ml : 0;  // (a literal-only element depends on nothing)
-      int dep = 0;
-#pragma unroll
-      for (int step = 32; step >= 1; step >>= 1) {
-        const int probe = dep + step - 1;  // candidate index
-        const int mv = __shfl(mstart, probe & 63);
-        const bool take = probe < nseq && mv < srcend;
-        dep = take ? dep + step : dep;
+      // piece list (in the record array, which is free until the next parse window): piece p -> lane | index << 8
+      {
+        uint16_t* pl = reinterpret_cast<uint16_t*>(rec) + lpx;
+        if (npc > 0) pl[0] = (uint16_t)lane;
+        if (npc > 1) pl[1] = (uint16_t)(lane | 0x100);
+        if (npc > 2) pl[2] = (uint16_t)(lane | 0x200);
+        if (npc > 3) pl[3] = (uint16_t)(lane | 0x300);
       }
+      // ---- where a match really reads from ----
+      // The bytes a match needs are [a, a + need): its source, or the `off` bytes in front of it if it overlaps its
+      // own output.  count(e) = number of sequences t with mstart[t] < e (binary search over the sorted mstart): the
+      // match may run in a round that starts at sequence cur iff count(a + need) <= cur.  Two refinements cut the
+      // dependency chains (TeraSort: every record copies from the record before it):
+      //   * a range that lies in the literals of the batch (or in front of its first match) is final from the start,
+      //     because all literals are copied before the first round;
+      //   * a range that lies inside the output of ONE earlier match t reads what t copied: out[q] = out[q - off[t]]
+      //     for every q there, so it can read from t's source instead — and so on along the chain (pointer doubling
+      //     over the lanes; a match that overlaps its own output ends a chain, its bytes are not a plain shift).
+      const uint32_t me = (uint32_t)mstart | ((uint32_t)end << 16);
+      auto count_below = [&](int e) __attribute__((always_inline)) -> int {
+        int n = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) {
+          const int probe = n + step - 1;  // candidate index
+          const int mv = (int)(__shfl(me, probe & 63) & 0xffffu);
+          const bool take = probe < nseq && mv < e;
+          n = take ? n + step : n;
+        }
+        return n;
+      };
+      const int need = off < ml ? off : ml;
+      int a2 = mstart - off;
+      int dep = count_below(a2 + need);  // (<= lane: mstart[t] < a + need <= mstart[lane])
+      const int t1 = dep > 0 ? dep - 1 : 0;
+      const uint32_t m1 = __shfl(me, t1);
+      const int ms1 = (int)(m1 & 0xffffu), en1 = (int)(m1 >> 16);
+      bool ground = ml == 0 || dep == 0 || a2 >= en1;  // in the literals of sequence `dep` / in front of the batch's matches
+      const bool inside = ml > 0 && dep > 0 && a2 >= ms1 && a2 + need <= en1;  // inside the output of match t1
+      if (__ballot(inside)) {
+        int shift = off;  // how far the output of this match is from the bytes it is a copy of
+        int nx = (inside && off >= ml) ? t1 : -1;
+        while (__ballot(nx >= 0)) {
+          const int s2 = __shfl(shift, nx & 63), n2 = __shfl(nx, nx & 63);
+          shift += nx >= 0 ? s2 : 0;
+          nx = nx >= 0 ? n2 : nx;
+        }
+        const int st1 = __shfl(shift, t1);
+        a2 -= inside ? st1 : 0;
+        dep = count_below(a2 + need);
+        const int t2 = dep > 0 ? dep - 1 : 0;
+        const int en2 = (int)(__shfl(me, t2) >> 16);
+        ground = ml == 0 || dep == 0 || a2 >= en2;
+      }
+      if (ground) dep = 0;
+      // what a piece's lane fetches from its sequence
+      const uint32_t W1 = (uint32_t)mstart | ((uint32_t)ml << 16);
+      const uint32_t W2 = (uint32_t)a2 | ((uint32_t)(off < ml ? off : 0) << 16);
+      BT_MARK(1);
       int s0 = 0;
       while (s0 < nseq) {
         // sequences [s0, s1) fit into the window
@@ -306,6 +426,7 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
         if (nfit == 0) {
           if (op + sh - wb > kBHist + 16) {
             slide();
+            BT_MARK(6);
             continue;
           }
           // one sequence larger than the free part of a freshly slid window
@@ -314,6 +435,7 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
           if (!emit_literals(r0, l0)) return false;
           if (m0 > 0 && !emit_match(o0, m0)) return false;
           s0++;
+          BT_MARK(7);
           continue;
         }
         const bool in = lane >= s0 && lane < s1;
@@ -324,16 +446,9 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
           if (__ballot(smalll && lit > 0)) {
             if (smalll && lit > 0) {
               if (src + 16 <= clen) {
-                uint4 x;
+                u32x4 x;
                 __builtin_memcpy(&x, c + src, 16);
-                if (lit >= 4) lds_st32(d, x.x);
-                if (lit >= 8) lds_st32(d + 4, x.y);
-                if (lit >= 12) lds_st32(d + 8, x.z);
-                if (lit >= 16) lds_st32(d + 12, x.w);
-                const int q = lit >> 2;
-                const uint32_t tw = q == 0 ? x.x : (q == 1 ? x.y : (q == 2 ? x.z : x.w));
-                if (lit & 2) lds_st16(d + 4 * q, tw);
-                if (lit & 1) d[(lit & ~1)] = (uint8_t)(tw >> ((lit & 2) * 8));
+                lds_store16(d, x, lit);
               } else {
                 for (int j = 0; j < lit; j++) d[j] = c[src + j];  // a literal run in the last bytes of the block
               }
@@ -345,87 +460,70 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
             big &= big - 1;
             const int l0 = __builtin_amdgcn_readlane(lit, s), r0 = __builtin_amdgcn_readlane(src, s);
             const int st0 = __builtin_amdgcn_readlane(start, s);
-            uint8_t* dd = win + (st0 + sh - wb);
-            const int body = l0 >> 2;
-            for (int j = lane; j < body; j += kWave) lds_st32(dd + 4 * j, g_ld32(c + r0 + 4 * j));
-            if (lane < (l0 & 3)) dd[4 * body + lane] = c[r0 + 4 * body + lane];
+            stream_to_window(st0 + sh - wb, r0, l0);
           }
         }
+        BT_MARK(2);
         // ---- matches of [s0, s1) in dependency rounds ----
-        // A "plain" match (source inside the window, not overlapping its destination, <= 64 bytes) whose
-        // source ends at or before the first byte the round writes (dep <= cur) can be copied side by side
-        // with its neighbours: short ones (<= 16 bytes) one LANE per match, up to 64 per round; longer ones
-        // one QUARTER WAVE per match (16 lanes x 4 bytes), four per round.  Anything else goes alone.
-        // (a source entirely in front of the window was flushed long ago: those lanes read it back from L2)
-        const bool near = mstart - off + sh >= wb, far = mstart - off + ml + sh <= wb;
-        const bool plain = in && off >= ml && (near || far) && ml <= kWave;
-        if (need_drain && __ballot(plain && far)) {
+        // A round takes the longest run of sequences from `cur` whose matches have pieces (see above), read bytes
+        // that are final (dep <= cur) wholly inside or wholly in front of the window, and need at most 64 pieces
+        // together: every piece's lane reads its 16 bytes, then writes them.  Anything else (longer than 64 bytes,
+        // an odd periodic pattern, a source that straddles the window base) goes alone, by the whole wave.
+        // (a source in front of the window was flushed long ago: those lanes read it back from L2)
+        const bool near = a2 + sh >= wb, far = a2 + need + sh <= wb;
+        const bool pieces = in && npc > 0 && (near || far);
+        if (need_drain && __ballot(pieces && !near)) {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           need_drain = false;
         }
-        const uint64_t P64 = __ballot(plain), P16 = __ballot(plain && ml <= kSmallMl);
+        const uint64_t PM = __ballot(pieces || (in && ml == 0));
+        const uint16_t* plist = reinterpret_cast<const uint16_t*>(rec);
         int cur = s0;
         while (cur < s1) {
-          const uint64_t dok = __ballot(dep <= cur);
-          const uint64_t a64 = (dok & P64) >> cur, a16 = (dok & P16) >> cur;
-          const int run = (~a64 == 0ull) ? kWave - cur : __builtin_ctzll(~a64);
-          const int run16 = (~a16 == 0ull) ? kWave - cur : __builtin_ctzll(~a16);
+          const int lp0 = __builtin_amdgcn_readlane(lpx, cur);  // pieces in front of sequence cur
+          const uint64_t dok = __ballot(dep <= cur && lpe - lp0 <= kWave);
+          const uint64_t am = (dok & PM) >> cur;
+          const int run = (~am == 0ull) ? kWave - cur : __builtin_ctzll(~am);
           if (run == 0) {
-            // long, overlapping or far: by the whole wave, 64 bytes per step (no slide: the range fits)
             const int m0 = __builtin_amdgcn_readlane(ml, cur), o0 = __builtin_amdgcn_readlane(off, cur);
             const int ms0 = __builtin_amdgcn_readlane(mstart, cur);
             copy_match_fit(ms0, o0, m0);
             cur++;
-          } else if (run16 >= 4 || run16 == run) {
-            // lanes [cur, cur + run16): one short match each
-            const bool mine = lane >= cur && lane < cur + run16;
-            const uint8_t* s = win + (mstart - off + sh - wb);
-            uint8_t* d = win + (mstart + sh - wb);
-            uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-            if (mine && near) {
-              w0 = lds_ld32(s);
-              if (ml > 4) w1 = lds_ld32(s + 4);
-              if (ml > 8) w2 = lds_ld32(s + 8);
-              if (ml > 12) w3 = lds_ld32(s + 12);
-            }
-            if (mine && !near) {
-              const uint8_t* gsrc = out + (mstart - off);
-              w0 = l2_ld32u(gsrc);
-              if (ml > 4) w1 = l2_ld32u(gsrc + 4);
-              if (ml > 8) w2 = l2_ld32u(gsrc + 8);
-              if (ml > 12) w3 = l2_ld32u(gsrc + 12);
-            }
-            if (mine) {
-              if (ml >= 4) lds_st32(d, w0);
-              if (ml >= 8) lds_st32(d + 4, w1);
-              if (ml >= 12) lds_st32(d + 8, w2);
-              if (ml >= 16) lds_st32(d + 12, w3);
-              const int q = ml >> 2;
-              const uint32_t tw = q == 0 ? w0 : (q == 1 ? w1 : (q == 2 ? w2 : w3));
-              if (ml & 2) lds_st16(d + 4 * q, tw);
-              if (ml & 1) d[(ml & ~1)] = (uint8_t)(tw >> ((ml & 2) * 8));
-            }
-            cur += run16;
-          } else {
-            // quarter waves: lanes 16g..16g+15 copy match cur+g, four bytes per lane
-            const int g = lane >> 4, b0 = (lane & 15) * 4;
-            const int sq = cur + g;
-            const int msq = __shfl(mstart, sq & 63), ofq = __shfl(off, sq & 63), mlq = __shfl(ml, sq & 63);
-            const int take = run < 4 ? run : 4;
-            if (g < take && b0 < mlq) {
-              const uint32_t w = (msq - ofq + sh >= wb) ? lds_ld32(win + (msq - ofq + sh - wb) + b0)
-                                                        : l2_ld32u(out + (msq - ofq) + b0);
-              uint8_t* d = win + (msq + sh - wb) + b0;
-              const int r = mlq - b0;
-              if (r >= 4) {
-                lds_st32(d, w);
-              } else {
-                if (r & 2) lds_st16(d, w);
-                if (r & 1) d[r & 2] = (uint8_t)(w >> ((r & 2) * 8));
-              }
-            }
-            cur += take;
+            BT_MARK(5);
+            BT_COUNT(11);
+            continue;
           }
+          const int np = __builtin_amdgcn_readlane(lpe, cur + run - 1) - lp0;  // <= 64
+          const int pi = lp0 + lane < 255 ? lp0 + lane : 255;
+          const uint32_t pe = plist[pi];
+          const int sq = (int)(pe & 63u), k16 = (int)(pe >> 8) << 4;
+          const uint32_t w1 = __shfl(W1, sq), w2 = __shfl(W2, sq);
+          const bool actp = lane < np;
+          const int msq = (int)(w1 & 0xffffu), mlq = (int)(w1 >> 16);
+          const int aq = (int)(w2 & 0xffffu), pat = (int)(w2 >> 16);
+          int n = mlq - k16;
+          n = n < 16 ? n : 16;
+          const int so = aq + (pat ? 0 : k16);
+          const bool nearp = aq + sh >= wb;
+          // every lane reads 16 bytes of the window (an idle lane, or one whose source is in L2: the first 16)
+          u32x4 x = lds_ld128u(win + ((actp && nearp) ? so + sh - wb : 0));
+          if (__ballot(actp && !nearp)) {
+            if (actp && !nearp) {
+              const uint8_t* gsrc = out + so;
+              x.x = l2_ld32(gsrc);
+              if (n > 4 && !pat) x.y = l2_ld32(gsrc + 4);
+              if (n > 8 && !pat) x.z = l2_ld32(gsrc + 8);
+              if (n > 12 && !pat) x.w = l2_ld32(gsrc + 12);
+            }
+          }
+          if (__ballot(actp && pat != 0)) {  // period 1, 2 or 4: every dword of the output is the same
+            const uint32_t sp = pat == 1 ? (x.x & 0xffu) * 0x01010101u : (pat == 2 ? (x.x & 0xffffu) * 0x00010001u : x.x);
+            if (pat) x.x = x.y = x.z = x.w = sp;
+          }
+          if (actp) lds_store16(win + (msq + k16 + sh - wb), x, n);
+          cur += run;
+          BT_MARK(3);
+          BT_COUNT(9);
         }
         op = __builtin_amdgcn_readlane(end, s1 - 1);
         s0 = s1;
@@ -521,8 +619,46 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
       return 0;
     };
 
+#ifdef S3S_DEC_RING
+    // ---- the stream ring: bytes [s_hi - 512, s_hi) of the stream (those below clen), `s_pre` = the dwords behind ----
+    int s_hi = 0;
+    uint32_t s_pre = 0;
+    auto stream_dword = [&](int p) __attribute__((always_inline)) -> uint32_t {  // lane's dword at p + 4 * lane, clamped
+      const int q = p + 4 * lane;
+      uint32_t v = 0;
+      if (q + 4 <= clen) {
+        v = g_ld32(c + q);
+      } else {
+        for (int k = 0; k < 4; k++)
+          if (q + k < clen) v |= (uint32_t)c[q + k] << (8 * k);
+      }
+      return v;
+    };
+    auto ring_ld32 = [&](int p) __attribute__((always_inline)) -> uint32_t {  // the stream's dword at p (aligned reads)
+      const int r = p & (kSRing - 1);
+      const uint8_t* q = sring + (r & ~3);
+      return __builtin_amdgcn_alignbyte(*reinterpret_cast<const uint32_t*>(q + 4), *reinterpret_cast<const uint32_t*>(q), (uint32_t)r & 3u);
+    };
+    auto refill = [&]() __attribute__((always_inline)) {  // afterwards: s_hi >= ip + 256 or s_hi >= clen
+      while (s_hi - ip < kSHalf && s_hi < clen) {
+        if (ip >= s_hi) {  // first window / the byte-wise path ran ahead: start over where the parse is
+          s_hi = ip & ~(kSHalf - 1);
+          s_pre = stream_dword(s_hi);
+        }
+        const int ri = s_hi & (kSRing - 1);
+        *reinterpret_cast<uint32_t*>(sring + ri + 4 * lane) = s_pre;
+        if (ri == 0 && lane == 0) *reinterpret_cast<uint32_t*>(sring + kSRing) = s_pre;
+        s_hi += kSHalf;
+        if (s_hi < clen) s_pre = stream_dword(s_hi);
+      }
+    };
+
+#endif
     // ---- main loop: parse windows of 64 stream bytes ---------------------------------------------------
     for (;;) {
+#ifdef S3S_DEC_RING
+      refill();
+#endif
       bool eob = false;
       bool cx = true, is_lit = false;
       int nxt = 0;
@@ -534,7 +670,11 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
       } else {
         const int cpos = ip + lane;
         if (cpos + 4 <= clen) {
+#ifdef S3S_DEC_RING
+          const uint32_t d0 = ring_ld32(cpos);
+#else
           const uint32_t d0 = g_ld32(c + cpos);
+#endif
           if constexpr (kFmt == kFmtSnappy) {
             const uint32_t tag = d0 & 0xffu, ty = tag & 3u, n6 = tag >> 2;
             if (ty == 0u) {
@@ -573,7 +713,11 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
             }
             const int p2 = cpos + hdr + lit;
             if (p2 + 4 <= clen) {
+#ifdef S3S_DEC_RING
+              const uint32_t d1 = p2 + 4 <= s_hi ? ring_ld32(p2) : g_ld32(c + p2);
+#else
               const uint32_t d1 = g_ld32(c + p2);
+#endif
               int ml = (int)(tok & 15u), adv = 2;
               if (ml == 15) {
                 const uint32_t e = (d1 >> 16) & 0xffu;
@@ -616,12 +760,27 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
         if (CXR) rel = __builtin_ctzll(CXR);
         else rel = __builtin_amdgcn_readlane(nrel, 63 - __builtin_clzll(mask));  // (lane 0 is on the chain: mask != 0)
       } else {
-        for (;;) {
-          const int n = __builtin_amdgcn_readlane(nrel, rel);
-          if (n < 0) break;
+        // for (;;) { n = nrel[rel]; if (n < 0) break; mask |= 1 << rel; rel = n; if (rel >= 64) break; } — five
+        // instructions per token, both ends of the chain in one unsigned compare (the compiler's loop has thirteen,
+        // and the CU's one scalar issue per cycle is what its 26 decoder waves wait for)
+        int n;
+        asm volatile(
+            "v_readlane_b32 %[n], %[v], %[rel]\n"
+            "s_cmp_lt_u32 %[n], 64\n"
+            "s_cbranch_scc0 .Lwalk_out%=\n"
+            ".Lwalk_next%=:\n"
+            "s_bitset1_b64 %[m], %[rel]\n"
+            "s_mov_b32 %[rel], %[n]\n"
+            "v_readlane_b32 %[n], %[v], %[rel]\n"
+            "s_cmp_lt_u32 %[n], 64\n"
+            "s_cbranch_scc1 .Lwalk_next%=\n"
+            ".Lwalk_out%=:\n"
+            : [m] "+s"(mask), [rel] "+s"(rel), [n] "=&s"(n)
+            : [v] "v"(nrel)
+            : "scc");
+        if (n >= 0) {  // the chain left the window: its last token is a real one
           mask |= 1ull << rel;
           rel = n;
-          if (rel >= kWave) break;
         }
       }
       last_tokens = __builtin_popcountll(mask);
@@ -658,7 +817,9 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
       }
       if (eob) break;
       if (mask == 0ull) {
+        BT_MARK(0);
         const int r = slow_sequence();
+        BT_MARK(7);
         if (r < 0) { bad = true; break; }
         if (r == 1) break;
         continue;
@@ -682,7 +843,10 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
     }
     if (!bad && nseq != 0) bad = true;  // (a block always ends in the byte-wise path, behind a flush)
     if (!bad && op != olen) bad = true;
+    BT_MARK(0);
     if (!bad) flush_to(op);
+    BT_MARK(6);
+    BT_DONE();
   }
   if (bad) {
     if (lane == 0) atomicExch(status, S3S_E_BAD_FRAME);

@@ -154,7 +154,7 @@ class Inst:
         self.target = None
 
 
-_MOD_RE = re.compile(r"\b(offset|dst_sel|dst_unused|src0_sel|src1_sel|row_shr|row_shl|row_ror|wave_shr|wave_shl|wave_ror|"
+_MOD_RE = re.compile(r"\b(offset0|offset1|offset|dst_sel|dst_unused|src0_sel|src1_sel|row_shr|row_shl|row_ror|wave_shr|wave_shl|wave_ror|"
                      r"wave_rol|row_mask|bank_mask|bound_ctrl|quad_perm|row_bcast|op_sel|op_sel_hi|bitop3)\s*:\s*(\[[^\]]*\]|\S+)")
 _FLAG_RE = re.compile(r"\b(glc|slc|sc0|sc1|nt|row_mirror|row_half_mirror|clamp|lds)\b")
 
@@ -797,6 +797,9 @@ class Program:
         m = re.match(r"^ds_write_(b8|b16|b32|b64|b96|b128)$", base)
         if m:
             return self._mk_dswrite(m.group(1))
+        m = re.match(r"^ds_(read|write)2_(b32|b64)$", base)
+        if m:
+            return self._mk_ds2(m.group(1) == "read", 4 if m.group(2) == "b32" else 8)
         m = re.match(r"^s_load_dword(x2|x4|x8|x16)?$", base)
         if m:
             n = {None: 1, "x2": 2, "x4": 4, "x8": 8, "x16": 16}[m.group(1)]
@@ -871,7 +874,7 @@ class Program:
 
         def run(w, i, n=n, ty=ty):
             e = w.em()
-            addr = w.v[i.ops[1][1]].astype(np.int64) + int(i.mods.get("offset", "0"), 0)
+            addr = (w.v[i.ops[1][1]].astype(np.int64) + int(i.mods.get("offset", "0"), 0)) & 0xFFFFFFFF  # (32-bit add)
             a = np.where(e, addr, 0)
             if e.any() and (a[e].min() < 0 or a[e].max() + n > w.lds_limit):
                 raise MemFault("LDS read out of bounds: %s" % i.text)
@@ -890,12 +893,36 @@ class Program:
             w.v[d] = np.where(e, val, w.v[d])
         return run
 
+    def _mk_ds2(self, is_read, n):
+        """ds_read2_b32 / _b64, ds_write2_b32 / _b64: two elements at addr + offset0 * n and addr + offset1 * n"""
+        def run(w, i, is_read=is_read, n=n):
+            e = w.em()
+            base = w.v[i.ops[1 if is_read else 0][1]].astype(np.int64)
+            k = n // 4
+            for which, mod in enumerate(("offset0", "offset1")):
+                addr = (base + int(i.mods.get(mod, "0"), 0) * n) & 0xFFFFFFFF  # (32-bit add: a negative base wraps)
+                a = np.where(e, addr, 0)
+                if e.any() and (a[e].min() < 0 or a[e].max() + n > w.lds_limit):
+                    raise MemFault("LDS access out of bounds: %s" % i.text)
+                if is_read:
+                    raw = np.ascontiguousarray(w.lds[a[:, None] + np.arange(n)]).view("<u4")
+                    d = i.ops[0][1] + which * k
+                    for j in range(k):
+                        w.v[d + j] = np.where(e, raw[:, j], w.v[d + j])
+                else:
+                    d = i.ops[1 + which][1]
+                    data = np.stack([w.v[d + j] for j in range(k)], axis=1).astype("<u4").view(np.uint8).reshape(64, n)
+                    for lane in np.flatnonzero(e):
+                        al = int(addr[lane])
+                        w.lds[al:al + n] = data[lane]
+        return run
+
     def _mk_dswrite(self, ty):
         n = {"b8": 1, "b16": 2, "b32": 4, "b64": 8, "b96": 12, "b128": 16}[ty]
 
         def run(w, i, n=n):
             e = w.em()
-            addr = w.v[i.ops[0][1]].astype(np.int64) + int(i.mods.get("offset", "0"), 0)
+            addr = (w.v[i.ops[0][1]].astype(np.int64) + int(i.mods.get("offset", "0"), 0)) & 0xFFFFFFFF
             d = i.ops[1][1]
             if n >= 4:
                 data = np.stack([w.v[d + k] for k in range(n // 4)], axis=1).astype("<u4").view(np.uint8).reshape(64, n)

@@ -44,6 +44,12 @@ struct Model {
   // statistics
   long st_seqs = 0, st_roundseqs = 0, st_brk_len = 0, st_brk_dep = 0, st_brk_far = 0, st_windows = 0, st_batches = 0, st_rounds = 0, st_single = 0, st_slow = 0, st_slides = 0, st_far = 0;
 
+  // which output bytes have their final value (test instrumentation: a round may only read such bytes)
+  uint8_t fin[32768 + 64];
+  bool hazard = false;
+  uint16_t plist[256];
+  void fin_set(int o) { if (o >= 0 && o < (int)sizeof fin) fin[o] = 1; }
+  bool fin_get(int o) const { return o >= 0 && o < (int)sizeof fin && fin[o] != 0; }
   uint8_t rdc(int pos) {
     if (pos < 0 || pos >= clen) { oob = true; return 0; }
     return c[pos];
@@ -85,7 +91,7 @@ struct Model {
     while (n > 0) {
       if (room() == 0) slide();
       const int k = std::min(n, room());
-      for (int j = 0; j < k; j++) L(op + j) = rdc(src + j);
+      for (int j = 0; j < k; j++) { L(op + j) = rdc(src + j); fin_set(op + j); }
       op += k;
       src += k;
       n -= k;
@@ -102,11 +108,11 @@ struct Model {
         st_far++;
         k = std::min(k, wb - sh - srco);
         if (srco + k > flushed) { oob = true; return false; }
-        for (int j = 0; j < k; j++) L(op + j) = out[srco + j];
+        for (int j = 0; j < k; j++) { L(op + j) = out[srco + j]; fin_set(op + j); }
       } else if (off >= k) {
-        for (int j = 0; j < k; j++) L(op + j) = L(srco + j);
+        for (int j = 0; j < k; j++) { L(op + j) = L(srco + j); fin_set(op + j); }
       } else {  // overlapping: periodic pattern
-        for (int j = 0; j < k; j++) L(op + j) = L(srco + (j % off));
+        for (int j = 0; j < k; j++) { L(op + j) = L(srco + (j % off)); fin_set(op + j); }
       }
       op += k;
       ml -= k;
@@ -133,6 +139,70 @@ struct Model {
       if (r_src[s] + r_lit[s] > clen) bad = true;
     }
     if (bad) return false;
+    // ---- pieces and real sources (same arithmetic as the kernel, lane by lane) ----
+    int npc[W], lpe[W], need[W], a2[W], dep[W];
+    bool ground[W], inside[W];
+    int t1[W];
+    auto count_below = [&](int e) {  // number of sequences t with mstart[t] < e
+      int n = 0;
+      for (int step = 32; step >= 1; step >>= 1) {
+        const int probe = n + step - 1;
+        if (probe < nseq && mstart[probe] < e) n += step;
+      }
+      return n;
+    };
+    int pacc = 0;
+    for (int s = 0; s < nseq; s++) {
+      const int ml = r_ml[s], off = r_off[s];
+      const bool patok = off >= ml || off == 1 || off == 2 || off == 4;
+      npc[s] = (ml > 0 && ml <= W && patok) ? (ml + 15) >> 4 : 0;
+      pacc += npc[s];
+      lpe[s] = pacc;
+      for (int k = 0; k < npc[s]; k++) plist[lpe[s] - npc[s] + k] = (uint16_t)(s | (k << 8));
+      need[s] = off < ml ? off : ml;
+      a2[s] = mstart[s] - off;
+      dep[s] = count_below(a2[s] + need[s]);
+      if (dep[s] > s) oob = true;  // (cannot happen: mstart[t] < a + need <= mstart[s])
+      t1[s] = dep[s] > 0 ? dep[s] - 1 : 0;
+      ground[s] = ml == 0 || dep[s] == 0 || a2[s] >= end[t1[s]];
+      inside[s] = ml > 0 && dep[s] > 0 && a2[s] >= mstart[t1[s]] && a2[s] + need[s] <= end[t1[s]];
+    }
+    {
+      bool any = false;
+      for (int s = 0; s < nseq; s++) any = any || inside[s];
+      if (any) {
+        int shift[W] = {0}, nx[W];
+        for (int s = 0; s < W; s++) nx[s] = -1;
+        for (int s = 0; s < nseq; s++) {
+          shift[s] = r_off[s];
+          nx[s] = (inside[s] && r_off[s] >= r_ml[s]) ? t1[s] : -1;
+        }
+        for (;;) {  // pointer doubling: all lanes read, then all lanes update
+          bool go = false;
+          for (int s = 0; s < nseq; s++) go = go || nx[s] >= 0;
+          if (!go) break;
+          int s2[W], n2[W];
+          for (int s = 0; s < nseq; s++) {
+            s2[s] = shift[nx[s] & 63];
+            n2[s] = nx[nx[s] & 63];
+          }
+          for (int s = 0; s < nseq; s++)
+            if (nx[s] >= 0) {
+              shift[s] += s2[s];
+              nx[s] = n2[s];
+            }
+        }
+        for (int s = 0; s < nseq; s++) {
+          if (inside[s]) a2[s] -= shift[t1[s]];
+          if (a2[s] < 0) { oob = true; a2[s] = 0; }
+          dep[s] = count_below(a2[s] + need[s]);
+          const int t2 = dep[s] > 0 ? dep[s] - 1 : 0;
+          ground[s] = r_ml[s] == 0 || dep[s] == 0 || a2[s] >= end[t2];
+        }
+      }
+    }
+    for (int s = 0; s < nseq; s++)
+      if (ground[s]) dep[s] = 0;
     int s0 = 0;
     while (s0 < nseq) {
       // how many of the pending sequences fit into the window
@@ -149,25 +219,24 @@ struct Model {
         s0++;
         continue;
       }
+      bool fardone[W] = {false};
       // literals of [s0, s1): small ones per lane, big ones cooperatively
       for (int s = s0; s < s1; s++)
-        for (int j = 0; j < r_lit[s]; j++) L(start[s] + j) = rdc(r_src[s] + j);
-      // matches in dependency rounds: plain matches (source in the window, no overlap, <= 64 bytes) whose
-      // source ends at or before the round's first output byte go side by side — short ones one lane each,
-      // longer ones one quarter wave each (four per round); anything else alone
+        for (int j = 0; j < r_lit[s]; j++) { L(start[s] + j) = rdc(r_src[s] + j); fin_set(start[s] + j); }
+      // matches in dependency rounds: the longest run of sequences from cur whose matches have pieces, read final
+      // bytes wholly inside or wholly in front of the window and need at most 64 pieces together; anything else alone
       int cur = s0;
       while (cur < s1) {
-        const int round_op = mstart[cur];
-        auto ok = [&](int s, int cap) {
-          const bool near = mstart[s] - r_off[s] + sh >= wb, far = mstart[s] - r_off[s] + r_ml[s] + sh <= wb;
-          if (s < s1 && r_ml[s] == 0) return true;  // a literal-only element depends on nothing
-          return s < s1 && r_ml[s] <= cap && r_off[s] >= r_ml[s] && (near || far) &&
-                 mstart[s] - r_off[s] + r_ml[s] <= round_op;
+        const int lp0 = cur > 0 ? lpe[cur - 1] : 0;
+        auto ok = [&](int s) {
+          if (s >= s1) return false;
+          if (!(dep[s] <= cur && lpe[s] - lp0 <= W)) return false;
+          if (r_ml[s] == 0) return true;  // a literal-only element depends on nothing
+          const bool near = a2[s] + sh >= wb, far = a2[s] + need[s] + sh <= wb;
+          return npc[s] > 0 && (near || far);
         };
-        int run = 0, run16 = 0;
-        while (ok(cur + run, W)) run++;
-        while (ok(cur + run16, kSmallMl)) run16++;
-        int take;
+        int run = 0;
+        while (ok(cur + run)) run++;
         if (run == 0) {
           st_single++;
           op = mstart[cur];
@@ -177,29 +246,41 @@ struct Model {
           if (!emit_match(r_off[cur], r_ml[cur])) return false;
           cur++;
           continue;
-        } else if (run16 >= 4 || run16 == run) {
-          take = run16;
-        } else {
-          take = run < 4 ? run : 4;
         }
         st_rounds++;
-        st_roundseqs += take;
-        // all reads of a round happen before its writes in the kernel; the condition above makes the
-        // order irrelevant (sources end at or before the first byte the round writes)
-        static thread_local uint8_t tmp[W][W];
-        for (int s = cur; s < cur + take; s++)
-          for (int j = 0; j < r_ml[s]; j++) {
-            const int so = mstart[s] - r_off[s] + j;
-            if (mstart[s] - r_off[s] + sh >= wb) {
-              tmp[s][j] = L(so);
+        st_roundseqs += run;
+        const int np = lpe[cur + run - 1] - lp0;
+        if (np > W) oob = true;
+        // all reads of a round happen before its writes in the kernel
+        uint8_t tmp[W][16];
+        int pn[W], pd[W];
+        for (int l = 0; l < np; l++) {
+          const uint16_t pe = plist[lp0 + l];
+          const int sq = pe & 63, k16 = (pe >> 8) << 4;
+          if (sq < cur || sq >= cur + run) oob = true;
+          pn[l] = 0;
+          if (fardone[sq]) continue;
+          const int pat = r_off[sq] < r_ml[sq] ? r_off[sq] : 0;
+          int n = r_ml[sq] - k16;
+          n = n < 16 ? n : 16;
+          if (n <= 0) oob = true;
+          pn[l] = n;
+          pd[l] = mstart[sq] + k16;
+          const int so = a2[sq] + (pat ? 0 : k16);
+          for (int j = 0; j < n; j++) {
+            const int o = so + (pat ? j % pat : j);
+            if (!fin_get(o)) hazard = true;  // the byte must be final when the round starts
+            if (a2[sq] + sh >= wb) {
+              tmp[l][j] = L(o);
             } else {  // a source in front of the window: read back from `out` (must have been flushed)
-              if (so < 0 || so >= flushed) oob = true;
-              else tmp[s][j] = out[so];
+              if (o < 0 || o >= flushed) { oob = true; tmp[l][j] = 0; }
+              else tmp[l][j] = out[o];
             }
           }
-        for (int s = cur; s < cur + take; s++)
-          for (int j = 0; j < r_ml[s]; j++) L(mstart[s] + j) = tmp[s][j];
-        cur += take;
+        }
+        for (int l = 0; l < np; l++)
+          for (int j = 0; j < pn[l]; j++) { L(pd[l] + j) = tmp[l][j]; fin_set(pd[l] + j); }
+        cur += run;
       }
       op = end[s1 - 1];
       s0 = s1;
@@ -456,6 +537,7 @@ extern "C" int batch_decode_model(int fmt, const uint8_t* comp, int clen, uint8_
   m.olen = olen;
   m.sh = out_misalign & 15;
   int rc = m.run();
+  if (m.hazard) rc = -3;  // a round read a byte that was not final yet: always a bug
   if (m.oob) rc = -2;  // the model touched something out of bounds: always a bug
   if (stats) {
     stats[0] = m.st_windows;

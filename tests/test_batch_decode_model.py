@@ -98,6 +98,68 @@ def test_lz4_hand_made_blocks(model):
                 assert run(model, LZ4, blk, olen)[0] == -1, (i, olen)
 
 
+def _chain_sequences(rng, n_seq):
+    """Random (literal length, offset, match length) lists in which matches copy from inside earlier matches, from
+    literal runs, from periodic patterns and across several of them — what the decoder's source redirection
+    (a match inside the output of one earlier match reads from that match's source) has to get right."""
+    seqs, pos, regions = [], 0, []  # regions: (start, end) of earlier match outputs
+    for _ in range(n_seq):
+        lit = int(rng.choice([0, 0, 0, 1, 2, 3, 5, 10, 14, 15, 16, 40]))
+        pos += lit
+        if pos == 0:
+            lit = 4
+            pos = 4
+        ml = int(rng.choice([4, 5, 7, 8, 15, 16, 17, 19, 29, 32, 33, 48, 59, 64, 65, 100]))
+        how = rng.integers(0, 8)
+        if how <= 2 and regions:      # wholly inside one earlier match output (the last few)
+            rs, re_ = regions[-int(rng.integers(1, min(len(regions), 6) + 1))]
+            ml = min(ml, re_ - rs)
+            src = int(rng.integers(rs, re_ - ml + 1))
+            off = pos - src
+        elif how == 3:                # short period
+            off = int(rng.choice([1, 2, 3, 4, 5, 8]))
+        elif how == 4 and regions:    # straddles the end of an earlier match output
+            rs, re_ = regions[-1]
+            off = pos - max(re_ - 2, 0)
+        elif how == 5:                # into the own literals
+            off = max(1, min(lit, pos))
+        else:
+            off = int(rng.integers(1, pos + 1))
+        off = max(1, min(off, pos, 65535))
+        seqs.append((lit, off, ml))
+        regions.append((pos, pos + ml))
+        pos += ml
+        if pos > 30000:
+            break
+    return seqs
+
+
+def test_redirected_sources(model):
+    rng = np.random.default_rng(11)
+    for it in range(300):
+        seqs = _chain_sequences(rng, int(rng.integers(1, 400)))
+        blk = framing.lz4_block([(rng.integers(0, 256, l).astype(np.uint8).tobytes(), o, m) for l, o, m in seqs],
+                                rng.integers(0, 256, 5 + int(rng.integers(0, 20))).astype(np.uint8).tobytes())
+        want = framing.lz4_decode_py(blk)
+        assert want is not None and len(want) <= 32768
+        rc, got = run(model, LZ4, blk, len(want), it)
+        assert rc == 0 and got.tobytes() == want, it
+        # the same structure as Snappy elements (copies of up to 64 bytes)
+        els = []
+        for l, o, m in seqs:
+            if l:
+                els.append(("lit", rng.integers(0, 256, l).astype(np.uint8).tobytes()))
+            while m > 0:
+                k = min(m, 64)
+                els.append(("copy", o, k, 2 if (o > 2047 or k > 11 or k < 4 or rng.integers(0, 2)) else 1))
+                m -= k
+        sblk = framing.snappy_block(els)
+        swant = framing.snappy_decode_py(sblk)
+        if swant is not None and 0 < len(swant) <= 32768:
+            rc, got = run(model, SNAPPY, sblk, len(swant), it)
+            assert rc == 0 and got.tobytes() == swant, it
+
+
 def test_lz4_malformed_blocks_are_refused(model):
     z = b"abcdefgh"
     bad = [
