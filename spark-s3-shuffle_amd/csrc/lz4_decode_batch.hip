@@ -116,6 +116,21 @@ __device__ __forceinline__ void lds_store16(uint8_t* d, u32x4 x, int n) {
   }
 }
 
+// (HIP's __ballot takes an int: the compiler first materialises the condition as 0 / 1 and compares it again)
+__device__ __forceinline__ uint64_t ballot64(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+
+// inclusive prefix sum over the 64 lanes in the DPP network (no LDS round trips): Hillis-Steele inside each row of
+// 16 lanes, then lane 15 of rows 0 / 2 into rows 1 / 3, then lane 31 into rows 2 and 3
+__device__ __forceinline__ int wave_scan_add(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
 enum { kFmtLz4 = 0, kFmtSnappy = 1 };
 
 #ifdef S3S_LZ4_TIMING
@@ -130,12 +145,19 @@ enum { kFmtLz4 = 0, kFmtSnappy = 1 };
 #define BT_COUNT(k)
 #define BT_DONE()
 #endif
+// The tokens of a parse window are marked by a scalar walk over the chain (five instructions per token, see the loop)
+// or, when the previous window held at least this many tokens, by pointer doubling through LDS (≈ 110 instructions
+// whatever the count).  Round 2 measured the compiler's 13-instruction walk: always scalar 295 / 148 GB/s on TeraSort /
+// wide rows, always doubling 291 / 164, hence a threshold of 12 for LZ4 and doubling always for Snappy.  With the
+// 5-instruction walk the break-even is above what a window can hold for LZ4 (21 tokens) and ≈ 24 for Snappy.
 #ifndef S3S_PWALK_TOKENS
-#define S3S_PWALK_TOKENS 12
+#define S3S_PWALK_TOKENS 24
 #endif
-// LZ4: windows are walked by pointer doubling when the previous window held at least this many tokens (measured:
-// always scalar 295 / 148 GB/s on TeraSort / wide rows, always doubling 291 / 164)
+#ifndef S3S_SWALK_TOKENS
+#define S3S_SWALK_TOKENS 24
+#endif
 constexpr int kParallelWalkTokens = S3S_PWALK_TOKENS;
+constexpr int kSnappyWalkTokens = S3S_SWALK_TOKENS;
 
 // kFmt selects the front end (token parse + byte-wise path); batches, rounds and the output window are the same:
 // a Snappy element is a sequence with either literals only (ml = 0) or a copy only (lit = 0).
@@ -349,15 +371,11 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
       const int npc = (ml > 0 && ml <= kWave && patok) ? (ml + 15) >> 4 : 0;
       const int len0 = lit + ml;
       int pk = (len0 < kMaxBlock + 1 ? len0 : kMaxBlock + 1) | (npc << 22);
-#pragma unroll
-      for (int d = 1; d < kWave; d <<= 1) {
-        const int up = __shfl_up(pk, d);
-        pk += lane >= d ? up : 0;
-      }
+      pk = wave_scan_add(pk);
       const int end = (pk & 0x3fffff) + op, lpe = pk >> 22, lpx = lpe - npc;  // (pieces up to and including / in front of this lane)
       const int start = end - lit - ml, mstart = end - ml;
       const bool wrong = act && ((ml > 0 && (off == 0 || off > mstart)) || end > olen || src + lit > clen);
-      if (__ballot(wrong)) return false;
+      if (ballot64(wrong)) return false;
       // piece list (in the record array, which is free until the next parse window): piece p -> lane | index << 8
       {
         uint16_t* pl = reinterpret_cast<uint16_t*>(rec) + lpx;
@@ -396,10 +414,10 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
       const int ms1 = (int)(m1 & 0xffffu), en1 = (int)(m1 >> 16);
       bool ground = ml == 0 || dep == 0 || a2 >= en1;  // in the literals of sequence `dep` / in front of the batch's matches
       const bool inside = ml > 0 && dep > 0 && a2 >= ms1 && a2 + need <= en1;  // inside the output of match t1
-      if (__ballot(inside)) {
+      if (ballot64(inside)) {
         int shift = off;  // how far the output of this match is from the bytes it is a copy of
         int nx = (inside && off >= ml) ? t1 : -1;
-        while (__ballot(nx >= 0)) {
+        while (ballot64(nx >= 0)) {
           const int s2 = __shfl(shift, nx & 63), n2 = __shfl(nx, nx & 63);
           shift += nx >= 0 ? s2 : 0;
           nx = nx >= 0 ? n2 : nx;
@@ -419,7 +437,7 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
       int s0 = 0;
       while (s0 < nseq) {
         // sequences [s0, s1) fit into the window
-        const uint64_t fits = __ballot(act && lane >= s0 && end + sh <= wb + kBWin);
+        const uint64_t fits = ballot64(act && lane >= s0 && end + sh <= wb + kBWin);
         const uint64_t fr0 = fits >> s0;
         const int nfit = (~fr0 == 0ull) ? kWave - s0 : __builtin_ctzll(~fr0);
         const int s1 = s0 + nfit;
@@ -443,7 +461,7 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
         {
           uint8_t* d = win + (start + sh - wb);
           const bool smalll = in && lit <= kSmallLit;
-          if (__ballot(smalll && lit > 0)) {
+          if (ballot64(smalll && lit > 0)) {
             if (smalll && lit > 0) {
               if (src + 16 <= clen) {
                 u32x4 x;
@@ -454,7 +472,7 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
               }
             }
           }
-          uint64_t big = __ballot(in && lit > kSmallLit);
+          uint64_t big = ballot64(in && lit > kSmallLit);
           while (big) {
             const int s = __builtin_ctzll(big);
             big &= big - 1;
@@ -472,16 +490,16 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
         // (a source in front of the window was flushed long ago: those lanes read it back from L2)
         const bool near = a2 + sh >= wb, far = a2 + need + sh <= wb;
         const bool pieces = in && npc > 0 && (near || far);
-        if (need_drain && __ballot(pieces && !near)) {
+        if (need_drain && ballot64(pieces && !near)) {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           need_drain = false;
         }
-        const uint64_t PM = __ballot(pieces || (in && ml == 0));
+        const uint64_t PM = ballot64(pieces || (in && ml == 0));
         const uint16_t* plist = reinterpret_cast<const uint16_t*>(rec);
         int cur = s0;
         while (cur < s1) {
           const int lp0 = __builtin_amdgcn_readlane(lpx, cur);  // pieces in front of sequence cur
-          const uint64_t dok = __ballot(dep <= cur && lpe - lp0 <= kWave);
+          const uint64_t dok = ballot64(dep <= cur && lpe - lp0 <= kWave);
           const uint64_t am = (dok & PM) >> cur;
           const int run = (~am == 0ull) ? kWave - cur : __builtin_ctzll(~am);
           if (run == 0) {
@@ -507,7 +525,7 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
           const bool nearp = aq + sh >= wb;
           // every lane reads 16 bytes of the window (an idle lane, or one whose source is in L2: the first 16)
           u32x4 x = lds_ld128u(win + ((actp && nearp) ? so + sh - wb : 0));
-          if (__ballot(actp && !nearp)) {
+          if (ballot64(actp && !nearp)) {
             if (actp && !nearp) {
               const uint8_t* gsrc = out + so;
               x.x = l2_ld32(gsrc);
@@ -516,7 +534,7 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
               if (n > 12 && !pat) x.w = l2_ld32(gsrc + 12);
             }
           }
-          if (__ballot(actp && pat != 0)) {  // period 1, 2 or 4: every dword of the output is the same
+          if (ballot64(actp && pat != 0)) {  // period 1, 2 or 4: every dword of the output is the same
             const uint32_t sp = pat == 1 ? (x.x & 0xffu) * 0x01010101u : (pat == 2 ? (x.x & 0xffffu) * 0x00010001u : x.x);
             if (pat) x.x = x.y = x.z = x.w = sp;
           }
@@ -738,11 +756,10 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
       const int nrel = cx ? -1 : nxt - ip;
       uint64_t mask = 0;
       int rel = 0;
-      if (kFmt == kFmtSnappy || last_tokens >= kParallelWalkTokens) {
-        // Snappy elements are 2-3 bytes long on match-dense data (25 per window): the scalar walk (8 instructions
-        // per token) would dominate, so the chain is followed by pointer doubling instead — six rounds of "lanes on
-        // the chain mark the lane 2^k tokens behind them" through 64 bytes of LDS (the window's pad), whatever the
-        // number of tokens.
+      if (last_tokens >= (kFmt == kFmtSnappy ? kSnappyWalkTokens : kParallelWalkTokens)) {
+        // many short tokens (Snappy elements are 2-3 bytes long on match-dense data, 25 and more per window): the chain
+        // is followed by pointer doubling — six rounds of "lanes on the chain mark the lane 2^k tokens behind them"
+        // through 64 bytes of LDS (the window's pad), whatever the number of tokens.
         uint8_t* mark = win + kBWin;  // (only ever over-read otherwise)
         int jmp = cx ? kWave : (nrel < kWave ? nrel : kWave);
         bool reach = lane == 0;
@@ -754,8 +771,8 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
           const int j2 = __shfl(jmp, jmp & 63);
           jmp = jmp < kWave ? j2 : kWave;
         }
-        const uint64_t RM = __ballot(reach);
-        const uint64_t CXR = __ballot(reach && cx);  // the (at most one) complex token the chain runs into
+        const uint64_t RM = ballot64(reach);
+        const uint64_t CXR = ballot64(reach && cx);  // the (at most one) complex token the chain runs into
         mask = RM & ~CXR;
         if (CXR) rel = __builtin_ctzll(CXR);
         else rel = __builtin_amdgcn_readlane(nrel, 63 - __builtin_clzll(mask));  // (lane 0 is on the chain: mask != 0)
@@ -792,11 +809,11 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
       uint64_t S = mask, J = 0ull;
       bool joined = false;
       if constexpr (kFmt == kFmtSnappy) {
-        const uint64_t LM = __ballot(is_lit) & mask;
+        const uint64_t LM = ballot64(is_lit) & mask;
         const uint64_t below = mask & ((1ull << lane) - 1ull);
         const bool prev_lit = below ? ((LM >> (63 - __builtin_clzll(below))) & 1ull) != 0ull : open_lit;
         joined = ((mask >> lane) & 1ull) != 0ull && !is_lit && prev_lit;
-        J = __ballot(joined);
+        J = ballot64(joined);
         S = mask & ~J;
       }
       int cnt = __builtin_popcountll(S);
@@ -835,7 +852,7 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
           h16[1] = (uint16_t)(r0 >> 16);  // match length
           h16[2] = (uint16_t)r1;          // offset
         }
-        const uint64_t LM = __ballot(is_lit) & mask;
+        const uint64_t LM = ballot64(is_lit) & mask;
         open_lit = ((LM >> (63 - __builtin_clzll(mask))) & 1ull) != 0ull;  // the window's last token is a literal
       }
       nseq += cnt;
