@@ -26,9 +26,14 @@ prof() {  # prof <name> <bench args...>
   cd $R
   python tools/summarize_prof.py $P --md > $P/summary.md 2>&1
 }
-prof compress
-prof snappy_compress --workload tpcds-wide-100g-200p-snappy
-prof decompress --direction decompress
+SETS=${2:-compress snappy_compress decompress}
+for s in $SETS; do
+  case $s in
+    compress) prof compress ;;
+    snappy_compress) prof snappy_compress --workload tpcds-wide-100g-200p-snappy ;;
+    decompress) prof decompress --direction decompress ;;
+  esac
+done
 for f in $O/bench*.json; do python - "$f" <<'PY'
 import json, sys
 try:
@@ -39,4 +44,4 @@ except Exception as e:
     print(sys.argv[1], "FAILED", e)
 PY
 done
-head -20 $O/prof_compress/summary.md | cut -c1-220
+head -20 $O/prof_${SETS%% *}/summary.md | cut -c1-220

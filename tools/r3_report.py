@@ -5,6 +5,7 @@ usage: python tools/r3_report.py <tag> <commit>
 Derived per dominant kernel (per launch):
   cycles        GRBM_GUI_ACTIVE / 8 (the counter is summed over the 8 XCDs; PMC passes serialise the kernels)
   issue util    (SALU + VALU + LDS + VMEM_RD + VMEM_WR instructions) / (1024 SIMDs x cycles)
+  scalar / vector issue busy   SALU (VALU) instructions / (256 CUs x cycles): a CU issues one of each per cycle
   waves / CU    4 x SQ_WAVE_CYCLES / (cycles x 256)        (SQ_*_CYCLES count quad-cycles)
   wait share    SQ_WAIT_ANY / SQ_WAVE_CYCLES
   L2 hit rate   TCC_HIT / (TCC_HIT + TCC_MISS)
@@ -47,6 +48,10 @@ for name, (kernel, key, cmd) in SETS.items():
         "kernel_cycles_alone": round(cyc), "kernel_ms_alone_at_2.4GHz": round(cyc / 2.4e6, 3),
         "instructions_per_launch": round(insts),
         "issue_slot_utilisation": round(insts / (1024 * cyc), 4) if cyc else None,
+        # a CU issues at most ONE scalar and ONE vector instruction per cycle for all of its wavefronts (the scalar unit is
+        # shared by the four SIMDs; a wave64 vector instruction occupies its SIMD16 for four cycles)
+        "scalar_issue_busy": round(c.get("SQ_INSTS_SALU", 0) / (256 * cyc), 4) if cyc else None,
+        "vector_issue_busy": round(c.get("SQ_INSTS_VALU", 0) / (256 * cyc), 4) if cyc else None,
         "resident_waves_per_cu_avg": round(4 * c.get("SQ_WAVE_CYCLES", 0) / (cyc * 256), 2) if cyc else None,
         "wait_share_of_wave_cycles": round(c.get("SQ_WAIT_ANY", 0) / max(c.get("SQ_WAVE_CYCLES", 1), 1), 3),
         "l2_hit_rate": round(c.get("TCC_HIT_sum", 0) / max(c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0), 1), 3),
