@@ -781,15 +781,26 @@ __global__ __launch_bounds__(kWave) void lz4_compress_l2_kernel(
 #else
   __shared__ __attribute__((aligned(16))) uint16_t table[8192];
 #endif
+  const int lane = threadIdx.x;
+#ifdef S3S_X_PERSIST  // experiment (profiles/r03_experiments.md §8): a persistent grid, wavefront b takes items b, b + grid, ...
+  for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+  const Item item = items[it];
+  const int kind = item.kind & 0xff;
+  if (kind != kItemLz4Chunk) {
+    if (lane == 0 && kind == kItemLz4End) item_size[it] = kLz4FrameHeader;
+    continue;
+  }
+  __syncthreads();
+#else
   const int it = blockIdx.x;
   if (it >= n_items) return;
   const Item item = items[it];
   const int kind = item.kind & 0xff;
-  const int lane = threadIdx.x;
   if (kind != kItemLz4Chunk) {
     if (lane == 0 && kind == kItemLz4End) item_size[it] = kLz4FrameHeader;
     return;
   }
+#endif
   {
     uint4* tz = reinterpret_cast<uint4*>(table);
     for (int i = lane; i < 16384 / 16; i += kWave) tz[i] = make_uint4(0, 0, 0, 0);
@@ -812,6 +823,9 @@ __global__ __launch_bounds__(kWave) void lz4_compress_l2_kernel(
   const int clen = lz4_compress_wave<SrcGlobal, kWindows>(SrcGlobal{src + item.src_off}, TabLds{(lds_u16*)table},
                                                       item.len, slot + kSlotHeader, lane);
   finish_frame(slot, item.len, clen, check, item.kind >> 8, item_size + it, lane);
+#ifdef S3S_X_PERSIST
+  }
+#endif
 }
 
 #ifdef S3S_X_GTAB
@@ -909,11 +923,18 @@ void launch_lz4_compress(const uint8_t* d_src, const Item* d_items, int32_t n_it
     }
   }
 #endif
+  unsigned grid = (unsigned)n_items;
+#ifdef S3S_X_PERSIST
+  {
+    static const int pg = getenv("S3S_X_PERSIST_GRID") ? atoi(getenv("S3S_X_PERSIST_GRID")) : 2560;
+    if ((int)grid > pg) grid = (unsigned)pg;
+  }
+#endif
   if (variant == 1)
-    hipLaunchKernelGGL(lz4_compress_l2_kernel<false>, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
+    hipLaunchKernelGGL(lz4_compress_l2_kernel<false>, dim3(grid), dim3(kWave), 0, st, d_src,
                        d_items, n_items, d_item_check, d_slots, d_item_size);
   else
-    hipLaunchKernelGGL(lz4_compress_l2_kernel<true>, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src,
+    hipLaunchKernelGGL(lz4_compress_l2_kernel<true>, dim3(grid), dim3(kWave), 0, st, d_src,
                        d_items, n_items, d_item_check, d_slots, d_item_size);
 }
 
