@@ -773,34 +773,60 @@ __device__ __forceinline__ uint32_t xxh32_wave(const uint8_t* g, int len, uint32
 // ---- variant B: chunk read in place, only the table in LDS ----------------------------------
 template <bool kWindows>
 __global__ __launch_bounds__(kWave) void lz4_compress_l2_kernel(
-    const uint8_t* __restrict__ src, const Item* __restrict__ items, int32_t n_items,
-    const uint32_t* __restrict__ item_check, uint8_t* __restrict__ slots,
-    uint32_t* __restrict__ item_size) {
+    const uint8_t* __restrict__ src_, const Item* __restrict__ items_, int32_t n_items_,
+    const uint32_t* __restrict__ item_check_, uint8_t* __restrict__ slots_,
+    uint32_t* __restrict__ item_size_, uint32_t* __restrict__ work_) {  // (read through the kernarg segment, see the loop)
 #ifdef S3S_ABL_LDS_PAD  // occupancy experiment: fewer wavefronts per CU (timing only)
   __shared__ __attribute__((aligned(16))) uint16_t table[8192 + S3S_ABL_LDS_PAD / 2];
 #else
   __shared__ __attribute__((aligned(16))) uint16_t table[8192];
 #endif
   const int lane = threadIdx.x;
-#ifdef S3S_X_PERSIST  // experiment (profiles/r03_experiments.md §8): a persistent grid, wavefront b takes items b, b + grid, ...
-  for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
-  const Item item = items[it];
+  // A persistent grid (10 wavefronts per CU, what the 16 KiB tables allow): every wavefront takes the next block from
+  // a counter until none is left.  Against one workgroup per block: no workgroup launches between blocks, the blocks in
+  // flight stay neighbours in memory, and a launch that is alone on the chip packs its last round
+  // (profiles/r03_experiments.md §8).
+  // The arguments are read again from the kernarg segment in every round (the empty asm hides from the compiler that
+  // the pointer is the same): kept in registers across the parse they cost 15 SGPRs next to the ones the window block
+  // pins, and the compiler spills more scalars into VGPR lanes.
+  struct KArgs {
+    const uint8_t* src;
+    const Item* items;
+    int32_t n_items, pad;
+    const uint32_t* item_check;
+    uint8_t* slots;
+    uint32_t* item_size;
+    uint32_t* work;
+  };
+  typedef const KArgs __attribute__((address_space(4))) * KArgsPtr;
+  for (;;) {
+  KArgsPtr ka = (KArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ka));
+  const uint8_t* const src = ka->src;
+  const Item* const items = ka->items;
+  const int n_items = ka->n_items;
+  const uint32_t* const item_check = ka->item_check;
+  uint8_t* const slots = ka->slots;
+  uint32_t* const item_size = ka->item_size;
+  uint32_t it0 = 0;
+  if (lane == 0) it0 = atomicAdd(ka->work, 1u);
+  const int it = (int)__builtin_amdgcn_readfirstlane(it0);
+  if (it >= n_items) break;
+  Item item = items[it];
+  {  // (a vector load through a pointer the compiler knows nothing about: the fields are uniform, say so)
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)item.src_off);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)item.src_off >> 32));
+    item.src_off = (int64_t)(((uint64_t)hi << 32) | lo);
+    item.len = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)item.len);
+    item.kind = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)item.kind);
+    item.chunk = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)item.chunk);
+  }
   const int kind = item.kind & 0xff;
   if (kind != kItemLz4Chunk) {
     if (lane == 0 && kind == kItemLz4End) item_size[it] = kLz4FrameHeader;
     continue;
   }
   __syncthreads();
-#else
-  const int it = blockIdx.x;
-  if (it >= n_items) return;
-  const Item item = items[it];
-  const int kind = item.kind & 0xff;
-  if (kind != kItemLz4Chunk) {
-    if (lane == 0 && kind == kItemLz4End) item_size[it] = kLz4FrameHeader;
-    return;
-  }
-#endif
   {
     uint4* tz = reinterpret_cast<uint4*>(table);
     for (int i = lane; i < 16384 / 16; i += kWave) tz[i] = make_uint4(0, 0, 0, 0);
@@ -823,9 +849,7 @@ __global__ __launch_bounds__(kWave) void lz4_compress_l2_kernel(
   const int clen = lz4_compress_wave<SrcGlobal, kWindows>(SrcGlobal{src + item.src_off}, TabLds{(lds_u16*)table},
                                                       item.len, slot + kSlotHeader, lane);
   finish_frame(slot, item.len, clen, check, item.kind >> 8, item_size + it, lane);
-#ifdef S3S_X_PERSIST
   }
-#endif
 }
 
 #ifdef S3S_X_GTAB
@@ -877,7 +901,7 @@ __global__ __launch_bounds__(kWave) void xxh32_items_wave_kernel(
 }  // namespace
 
 void launch_lz4_compress(const uint8_t* d_src, const Item* d_items, int32_t n_items,
-                         uint32_t* d_item_check, uint8_t* d_slots, uint32_t* d_item_size,
+                         uint32_t* d_item_check, uint8_t* d_slots, uint32_t* d_item_size, uint32_t* d_work, int resident_waves,
                          int variant, hipStream_t st, hipEvent_t after_hash) {
   if (n_items <= 0) {
     if (after_hash) hipEventRecord(after_hash, st);
@@ -915,27 +939,28 @@ void launch_lz4_compress(const uint8_t* d_src, const Item* d_items, int32_t n_it
                              d_item_check, d_slots, d_item_size, tables, grid);
       }
       if (n_g < n_items)
-        hipLaunchKernelGGL(lz4_compress_l2_kernel<true>, dim3((unsigned)(n_items - n_g)), dim3(kWave), 0, st, d_src, d_items + n_g,
-                           n_items - n_g, d_item_check + n_g, d_slots, d_item_size + n_g);
+      {
+        (void)hipMemsetAsync(d_work, 0, sizeof(uint32_t), st);
+        hipLaunchKernelGGL(lz4_compress_l2_kernel<true>, dim3((unsigned)std::min(n_items - n_g, resident_waves)), dim3(kWave), 0, st, d_src,
+                           d_items + n_g, n_items - n_g, d_item_check + n_g, d_slots, d_item_size + n_g, d_work);
+      }
       (void)hipEventRecord(ev_b, st2);
       (void)hipStreamWaitEvent(st, ev_b, 0);
       return;
     }
   }
 #endif
-  unsigned grid = (unsigned)n_items;
-#ifdef S3S_X_PERSIST
-  {
-    static const int pg = getenv("S3S_X_PERSIST_GRID") ? atoi(getenv("S3S_X_PERSIST_GRID")) : 2560;
-    if ((int)grid > pg) grid = (unsigned)pg;
-  }
-#endif
+  // d_work: the launch's block counter (zeroed in stream order); resident_waves: 10 per CU
+  (void)hipMemsetAsync(d_work, 0, sizeof(uint32_t), st);
+  static const int grid_env = getenv("S3S_LZ4_GRID") ? atoi(getenv("S3S_LZ4_GRID")) : 0;  // (experiments)
+  int grid = grid_env > 0 ? grid_env : resident_waves;
+  if (grid > n_items) grid = n_items;
   if (variant == 1)
-    hipLaunchKernelGGL(lz4_compress_l2_kernel<false>, dim3(grid), dim3(kWave), 0, st, d_src,
-                       d_items, n_items, d_item_check, d_slots, d_item_size);
+    hipLaunchKernelGGL(lz4_compress_l2_kernel<false>, dim3((unsigned)grid), dim3(kWave), 0, st, d_src,
+                       d_items, n_items, d_item_check, d_slots, d_item_size, d_work);
   else
-    hipLaunchKernelGGL(lz4_compress_l2_kernel<true>, dim3(grid), dim3(kWave), 0, st, d_src,
-                       d_items, n_items, d_item_check, d_slots, d_item_size);
+    hipLaunchKernelGGL(lz4_compress_l2_kernel<true>, dim3((unsigned)grid), dim3(kWave), 0, st, d_src,
+                       d_items, n_items, d_item_check, d_slots, d_item_size, d_work);
 }
 
 }  // namespace s3s

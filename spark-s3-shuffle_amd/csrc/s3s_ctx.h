@@ -24,6 +24,7 @@ enum BufId {
   B_PARTIAL, B_STATUS, B_TABLES, B_SRC, B_DST, B_OFFSETS, B_FRAMES, B_PART_NFRAMES,
   B_FRAME_OUT, B_REF_SUMS, B_ITEM_CHECK, B_RANGES, B_TILE_RANGE,
   B_HB_IN0, B_HB_IN1, B_HB_OUT0, B_HB_OUT1,  // host-buffer batch pipeline (host_batch.hip): double-buffered device staging
+  B_WORK,  // block counter of the persistent codec grid
   B_COUNT
 };
 
@@ -49,6 +50,7 @@ struct s3s_ctx {
   int lz4_decode_variant = 4;  // 4 = batch decoder (lz4_decode_batch.hip), 3 = ring decoder on the vector ALU
   int snappy_variant = 1;
   s3s::DevBuf buf[s3s::B_COUNT];
+  int cu_count = 256;  // compute units of the device (persistent grids: resident wavefronts per CU x this)
   void* h_stage = nullptr;  // pinned
   size_t h_stage_cap = 0;
   hipEvent_t ev[S3S_STAGE_COUNT + 1] = {};

@@ -49,7 +49,7 @@ constexpr uint32_t kRawFlag = 0x80000000u;
 //   variant 0: chunk staged in LDS (3 wavefronts/CU); 1: chunk read through L1/L2 (10/CU);
 //   2: as 1 plus the window-speculative parse (default)
 void launch_lz4_compress(const uint8_t* d_src, const Item* d_items, int32_t n_items,
-                         uint32_t* d_item_check, uint8_t* d_slots, uint32_t* d_item_size,
+                         uint32_t* d_item_check, uint8_t* d_slots, uint32_t* d_item_size, uint32_t* d_work, int resident_waves,
                          int variant, hipStream_t st, hipEvent_t after_hash = nullptr);
 // Snappy: same for kItemSnappyChunk.
 bool snappy_compress_available();

@@ -85,8 +85,16 @@ def compress_chunks(chunks, windows=True, flags=(), profile=None, lds_order=None
     a_check = mem.map(checks, "item_check", writable=False)
     a_slots = mem.map(slots, "slots")
     a_sizes = mem.map(sizes, "item_size")
-    kernarg = struct.pack("<QQiiQQQ", a_src, a_items, n, 0, a_check, a_slots, a_sizes)
-    waves = emu.launch(prog, entry, mem, kernarg, n, 16384, profile=profile, lds_order=lds_order, hooks=hooks)
+    # The kernel is a persistent grid (every wavefront takes blocks from a counter until none is left); the interpreter
+    # runs wavefronts one after the other, so each chunk gets its own one-item launch and its own wavefront's statistics
+    work = np.zeros(16, dtype=np.uint32)
+    a_work = mem.map(work, "work")
+    waves = []
+    for k in range(n):
+        work[:] = 0
+        kernarg = struct.pack("<QQiiQQQQ", a_src, a_items + 24 * k, 1, 0, a_check + 4 * k, a_slots, a_sizes + 4 * k, a_work)
+        waves += emu.launch(prog, entry, mem, kernarg, 1, 16384, profile=profile, lds_order=lds_order, hooks=hooks)
+        assert work[0] == 2, "the wavefront takes its block and then finds the counter exhausted"
     out = []
     for k in range(n):
         sz = int(sizes[k])

@@ -147,3 +147,48 @@ def test_batched_decode_equals_single_ranges(gpu_codec, oracle, codec, algo):
                     assert n == data.size and np.array_equal(dev.download(ranges[t][4], n), data), t
     finally:
         dev.free()
+
+
+def test_fresh_context_that_only_ever_batches(codec_lib, oracle):
+    """Regression (round 3): a context whose first and only map-side call is the batched entry point — what bench.py
+    and a Spark executor with a commit queue do.  The shared fixture's context has been through the single-task
+    entry point long before it batches; a buffer that only that path allocates (the block counter of the persistent
+    LZ4 grid) stayed null here."""
+    import threading
+
+    import s3shuffle
+
+    rng = np.random.default_rng(123)
+    outs = []
+
+    def worker(seed):
+        c = s3shuffle.Codec(0)
+        dev = _Dev()
+        try:
+            r = np.random.default_rng(seed)
+            host, tasks = [], []
+            for _ in range(3):
+                data, offs = corpus.ragged_map_output(r, n_parts=int(r.integers(2, 20)), max_len=200_000)
+                cap = c.max_compressed_size(LZ4, offs)
+                host.append((data, offs))
+                tasks.append((dev.upload(data), offs, dev.alloc(cap), cap))
+            res = c.compress_map_outputs_batch_device(LZ4, ADLER, tasks)
+            got = [(total, index, sums, dev.download(t[2], total)) for t, (total, index, sums) in zip(tasks, res)]
+            outs.append((host, got))
+        finally:
+            dev.free()
+            c.close()
+
+    # two contexts at once: calls that overlap take half the chip each (the other branch of the grid choice)
+    seeds = [int(rng.integers(1, 1 << 30)) for _ in range(2)]
+    threads = [threading.Thread(target=worker, args=(s,)) for s in seeds]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert len(outs) == 2, "a worker did not finish"
+    for host, got in outs:
+        for (data, offs), (total, index, sums, img) in zip(host, got):
+            r_img, r_index, r_sums = oracle.compress_map_output(LZ4, ADLER, data, offs)
+            assert total == r_img.size and np.array_equal(index, r_index) and np.array_equal(sums, r_sums)
+            assert np.array_equal(img, r_img)
