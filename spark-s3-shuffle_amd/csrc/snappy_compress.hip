@@ -580,6 +580,18 @@ __global__ __launch_bounds__(kWave) void snappy_compress_kernel(
     for (int i = lane; i < (int)(sizeof(table) / 16); i += kWave) tz[i] = make_uint4(0, 0, 0, 0);
   }
   __syncthreads();
+  // touch the whole block first (32 independent 1 KiB rows, one wait), as the LZ4 kernel does: the parse's dependent
+  // gathers then hit in this XCD's L2 (wide rows 30.6 -> 32.0 GB/s)
+  {
+    const uint8_t* g = src + item.src_off;
+    uint32_t acc = 0;
+    for (int i = lane * 16; i + 16 <= item.len; i += kWave * 16) {
+      uint4 x;
+      __builtin_memcpy(&x, g + i, 16);
+      acc ^= x.x ^ x.y ^ x.z ^ x.w;
+    }
+    if (acc == 0x12345678u && item.len < 0) table[0] = 1;  // (never taken: keeps the loads)
+  }
   uint8_t* slot = slots + (size_t)item.chunk * (size_t)slot_stride;
   const int clen = snappy_compress_wave<kWin>(src + item.src_off, (lds_u16*)table, item.len, slot + kSlotHeader, lane);
   // SnappyOutputStream.dumpOutput(): i32 BE compressed length in front of the raw block
