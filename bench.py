@@ -588,6 +588,9 @@ def run_workload(args, rank: int, local_rank: int, world: int, dist):
                 "traffic": None,
                 "avg_launch_ms": round(codec_ms, 4),
                 "concurrent_launches": n_threads,  # one per task thread / stream; they share the GPU
+                "launch_shape": ("persistent grid: 10 wavefronts per CU, 5 when map-side calls overlap (two launches resident "
+                                 "together) - avg_launch_ms is the duration of ONE such launch while the others run"
+                                 if codec_name == "lz4" and not decompress else "one workgroup (wavefront) per block / frame"),
                 "achieved_all_streams": round(achieved * n_threads, 3),
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "frac_of_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBPS, 6),
