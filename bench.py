@@ -189,7 +189,7 @@ def parse_args():
     ap.add_argument("--host-path-only", action="store_true", help="run only the host-buffer leg (run_host_path) and print it")
     ap.add_argument("--dry-run", action="store_true",
                     help="no timing: every rank reports (rank, local rank, device, its map ids); rank 0 checks that "
-                         "mapId % nGPU covers every map task exactly once and prints the table as one JSON line "
+                         "mapId %% nGPU covers every map task exactly once and prints the table as one JSON line "
                          "(backend nccl on GPUs, gloo without)")
     return ap.parse_args()
 
