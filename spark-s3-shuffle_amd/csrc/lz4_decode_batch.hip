@@ -186,6 +186,20 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
   uint8_t* out = dst + frame_out[f];
   bool bad = false;
   int ip_start = 0;
+#ifndef S3S_DEC_NO_PREFETCH
+  // Touch the frame's compressed bytes once (a few independent 1 KiB rows, one wait): the parse reads the stream through
+  // dependent loads, one new cache line every other window, and a line that comes from HBM instead of L2 is on the chain.
+  {
+    uint32_t acc = 0;
+    const int lim = clen < kMaxBlock + kMaxBlock / 6 + 64 ? clen : kMaxBlock + kMaxBlock / 6 + 64;
+    for (int i = lane * 16; i + 16 <= lim; i += kWave * 16) {
+      uint4 x;
+      __builtin_memcpy(&x, c + i, 16);
+      acc ^= x.x ^ x.y ^ x.z ^ x.w;
+    }
+    if (acc == 0x12345678u && clen < 0) win[0] = 1;  // (never taken: keeps the loads)
+  }
+#endif
   if (kFmt == kFmtSnappy) {
     // preamble: varint32 uncompressed length (scalar, once per block)
     uint32_t ulen = 0;
