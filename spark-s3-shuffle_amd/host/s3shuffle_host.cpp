@@ -542,6 +542,9 @@ void s3sh_dispatcher_destroy(void* d) { delete static_cast<S3ShuffleDispatcher*>
 int s3sh_dispatcher_set_use_spark_shuffle_fetch(void* d, int on) {
   return guarded([&] { static_cast<S3ShuffleDispatcher*>(d)->setUseSparkShuffleFetch(on != 0); });
 }
+int s3sh_dispatcher_set_fetch_thread_predictor(void* d, int on) {
+  return guarded([&] { static_cast<S3ShuffleDispatcher*>(d)->setFetchThreadPredictor(on != 0); });
+}
 int s3sh_get_path(void* d, int kind, int shuffleId, long long mapId, int r0, int r1, char* out, int cap) {
   return guarded([&] {
     BlockId id{(BlockId::Kind)kind, shuffleId, mapId, r0, r1};

@@ -84,6 +84,28 @@ struct Conf {
   int maxConcurrencyTask = 10;               // spark.shuffle.s3.maxConcurrencyTask: fetch threads per task
   int gpuDecodeThreads = 2;                  // spark.shuffle.s3.gpu.decodeThreads: contexts (streams) decoding per task
   int64_t gpuMaxDecodedBufferSizeTask = 512ll << 20;  // spark.shuffle.s3.gpu.maxDecodedBufferSizeTask (pinned, decoded)
+  // spark.shuffle.s3.gpu.fetchThreadPredictor: let the reference's ThreadPredictor choose how many of the
+  // maxConcurrencyTask fetch threads run (default off: all of them do — against a local / tmpfs store the consumer
+  // never waits and the predictor would stay at one thread)
+  bool fetchThreadPredictor = false;
+};
+
+// The fetch-thread tuner of the reference's prefetcher (storage/S3BufferedPrefetchIterator.scala:32-69), restated: it is
+// fed how long the consumer had to wait for a block; every 20 measurements (+ one per running thread) it records their sum
+// for the current number of threads and moves one thread down or up if that neighbour's recorded sum is smaller.
+class ThreadPredictor {
+ public:
+  explicit ThreadPredictor(int maxThreads);
+  int addMeasurementAndPredict(int64_t latencyNs);  // latencyNs < 0: no measurement, just the current answer
+  int current() const;
+
+ private:
+  int predict();
+  mutable std::mutex mu_;
+  int currentThreads_ = 1;
+  std::vector<int64_t> latencies_;      // [0] and [maxThreads + 1] are walls (Long.MaxValue)
+  int numMeasurements_ = 0;
+  int64_t measurementsNs_[20] = {0};
 };
 
 class S3ShuffleDispatcher {
@@ -103,6 +125,7 @@ class S3ShuffleDispatcher {
   int checksumId() const;   // S3S_CHECKSUM_*; throws UnsupportedOperationException-like for unknown names
   int deviceForMap(int64_t mapId) const;
   void setUseSparkShuffleFetch(bool on) { conf_.useSparkShuffleFetch = on; }
+  void setFetchThreadPredictor(bool on) { conf_.fetchThreadPredictor = on; }
   void setPrefetch(int64_t maxBufferSizeTask, int maxConcurrencyTask, int gpuDecodeThreads, int64_t gpuMaxDecodedBufferSizeTask) {
     if (maxBufferSizeTask > 0) conf_.maxBufferSizeTask = maxBufferSizeTask;
     if (maxConcurrencyTask > 0) conf_.maxConcurrencyTask = maxConcurrencyTask;
@@ -249,6 +272,7 @@ class S3BufferedPrefetchIterator {
   struct Stats {
     int64_t blocks = 0, compressedBytes = 0, decodedBytes = 0;
     double secondsWaiting = 0;  // consumer blocked in next()
+    int fetchThreads = 0;       // fetch threads allowed to run right now (the predictor's answer, or all of them)
     int64_t compHighWater = 0, decodedHighWater = 0;
   };
   Stats stats() const;
@@ -265,7 +289,7 @@ class S3BufferedPrefetchIterator {
     int errKind;  // 0 ok, 1 SparkException, 2 IOException
     std::string err;
   };
-  void fetchLoop();
+  void fetchLoop(int id);  // id 1..nFetch: with the predictor on, thread id runs while id <= the predicted count
   void decodeLoop();
   const S3ShuffleDispatcher& d_;
   std::vector<BlockRequest> reqs_;
@@ -278,6 +302,9 @@ class S3BufferedPrefetchIterator {
   bool stop_ = false;
   std::vector<std::thread> threads_;
   Stats stats_;
+  ThreadPredictor predictor_;
+  int desiredFetchers_ = 1;  // (guarded by mu_)
+  std::condition_variable cvPark_;
 };
 
 class S3ShuffleReader {

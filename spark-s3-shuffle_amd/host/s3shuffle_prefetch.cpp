@@ -12,8 +12,8 @@
 //                                           pinned buffer (budget gpuMaxDecodedBufferSizeTask)
 //   consumer                                next() in completion order, release() gives the memory back
 //
-// The reference's ThreadPredictor (latency-driven thread count, :32-69) is control-plane tuning and is
-// not mirrored: the fetch thread count is min(maxConcurrencyTask, number of blocks).
+// The reference's ThreadPredictor (latency-driven thread count, :32-69) is restated below and can be switched on
+// (Conf::fetchThreadPredictor); by default every one of the min(maxConcurrencyTask, number of blocks) fetch threads runs.
 #include <fcntl.h>
 #include <unistd.h>
 
@@ -254,18 +254,54 @@ void S3ShuffleDispatcher::readBlockRangeInto(const BlockId& id, int64_t pos, int
   ::close(fd);
 }
 
+// ---- ThreadPredictor (S3BufferedPrefetchIterator.scala:32-69) ----------------------------------------------
+ThreadPredictor::ThreadPredictor(int maxThreads) : latencies_((size_t)std::max(maxThreads, 1) + 2, 0) {
+  latencies_.front() = INT64_MAX;
+  latencies_.back() = INT64_MAX;
+}
+
+int ThreadPredictor::predict() {  // (:42-61)
+  if (numMeasurements_ < 20 + currentThreads_) return currentThreads_;
+  int64_t current = 0;
+  for (int64_t v : measurementsNs_) current += v;
+  if (current < 500) return currentThreads_;  // "less than 25 ns latency for each request"
+  latencies_[(size_t)currentThreads_] = current;
+  const int64_t prevValue = latencies_[(size_t)currentThreads_ - 1], nextValue = latencies_[(size_t)currentThreads_ + 1];
+  numMeasurements_ = 0;
+  if (prevValue < current) currentThreads_ -= 1;
+  else if (nextValue < current) currentThreads_ += 1;
+  return currentThreads_;
+}
+
+int ThreadPredictor::addMeasurementAndPredict(int64_t latencyNs) {  // (:63-69)
+  std::lock_guard<std::mutex> lk(mu_);
+  if (latencyNs >= 0) {
+    measurementsNs_[numMeasurements_ % 20] = latencyNs;
+    numMeasurements_++;
+  }
+  return predict();
+}
+
+int ThreadPredictor::current() const {
+  std::lock_guard<std::mutex> lk(mu_);
+  return currentThreads_;
+}
+
 // ---- the pipeline --------------------------------------------------------------------------------------
 S3BufferedPrefetchIterator::S3BufferedPrefetchIterator(const S3ShuffleDispatcher& d, std::vector<BlockRequest> requests)
     : d_(d),
       reqs_(std::move(requests)),
       comp_(d.conf().maxBufferSizeTask),
-      dec_(d.conf().gpuMaxDecodedBufferSizeTask) {
+      dec_(d.conf().gpuMaxDecodedBufferSizeTask),
+      predictor_(std::max(d.conf().maxConcurrencyTask, 1)) {
   const size_t n = reqs_.size();
   if (n == 0) return;
   const size_t nFetch = std::max<size_t>(1, std::min<size_t>((size_t)std::max(d.conf().maxConcurrencyTask, 1), n));
   const size_t nDecode = std::max<size_t>(1, std::min<size_t>((size_t)std::max(d.conf().gpuDecodeThreads, 1), n));
   fetchersLeft_ = nFetch;
-  for (size_t i = 0; i < nFetch; i++) threads_.emplace_back([this] { fetchLoop(); });
+  // "make sure that there's at least a single thread running" (:93): the predictor starts at one; without it all run
+  desiredFetchers_ = d.conf().fetchThreadPredictor ? predictor_.addMeasurementAndPredict(-1) : (int)nFetch;
+  for (size_t i = 0; i < nFetch; i++) threads_.emplace_back([this, i] { fetchLoop((int)i + 1); });
   for (size_t i = 0; i < nDecode; i++) threads_.emplace_back([this] { decodeLoop(); });
 }
 
@@ -279,18 +315,23 @@ S3BufferedPrefetchIterator::~S3BufferedPrefetchIterator() {
   dec_.cancel();
   cvFetched_.notify_all();
   cvDone_.notify_all();
+  cvPark_.notify_all();
   for (auto& t : threads_) t.join();
   for (auto& f : fetched_) comp_.release(f.comp);
   for (auto& dn : done_) dec_.release(dn.out);
 }
 
-void S3BufferedPrefetchIterator::fetchLoop() {
+void S3BufferedPrefetchIterator::fetchLoop(int id) {
   for (;;) {
     size_t i;
     {
-      std::lock_guard<std::mutex> lk(mu_);
+      std::unique_lock<std::mutex> lk(mu_);
+      // a thread above the predicted count parks until the count rises or the work is gone ("if (threadId >
+      // desiredActiveThreads.get()) return", :116-119 — here the thread is kept instead of being started again later)
+      cvPark_.wait(lk, [&] { return stop_ || nextReq_ >= reqs_.size() || id <= desiredFetchers_; });
       if (stop_ || nextReq_ >= reqs_.size()) break;
       i = nextReq_++;
+      if (nextReq_ >= reqs_.size()) cvPark_.notify_all();
     }
     const BlockRequest& rq = reqs_[i];
     uint8_t* buf = nullptr;
@@ -386,7 +427,15 @@ PrefetchedBlock S3BufferedPrefetchIterator::next() {
   done_.pop_front();
   delivered_++;
   stats_.blocks++;
-  stats_.secondsWaiting += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  const auto waited = std::chrono::steady_clock::now() - t0;
+  stats_.secondsWaiting += std::chrono::duration<double>(waited).count();
+  if (d_.conf().fetchThreadPredictor) {  // configureThreads(latency) (:77-91)
+    const int want = predictor_.addMeasurementAndPredict(std::chrono::duration_cast<std::chrono::nanoseconds>(waited).count());
+    if (want != desiredFetchers_) {
+      desiredFetchers_ = want;
+      cvPark_.notify_all();
+    }
+  }
   lk.unlock();
   if (dn.errKind == 1) throw SparkException(dn.err);
   if (dn.errKind == 2) throw IOException(dn.err);
@@ -407,6 +456,10 @@ S3BufferedPrefetchIterator::Stats S3BufferedPrefetchIterator::stats() const {
   }
   s.compHighWater = comp_.highWater();
   s.decodedHighWater = dec_.highWater();
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    s.fetchThreads = desiredFetchers_;
+  }
   return s;
 }
 
@@ -414,6 +467,13 @@ S3BufferedPrefetchIterator::Stats S3BufferedPrefetchIterator::stats() const {
 
 // ---- self-test of the staging pool (tests/test_host_mirror.py; runs on a CPU-only box too, where staging is
 // plain memory) ------------------------------------------------------------------------------------------------
+// the tuner alone: feeds `n` consumer wait times and returns the predicted thread count after each (tests/test_host_mirror.py
+// compares it with a line-by-line Python restatement of the Scala class)
+extern "C" void s3sh_thread_predictor_run(int maxThreads, const long long* latenciesNs, int n, int* out) {
+  s3shuffle::ThreadPredictor p(maxThreads);
+  for (int i = 0; i < n; i++) out[i] = p.addMeasurementAndPredict((int64_t)latenciesNs[i]);
+}
+
 extern "C" int s3sh_pool_selftest() {
   using namespace s3shuffle;
   try {

@@ -39,6 +39,9 @@ def _lib():
         vp = ctypes.c_void_p
         L.s3sh_dispatcher_destroy.argtypes = [vp]
         L.s3sh_dispatcher_set_use_spark_shuffle_fetch.argtypes = [vp, ctypes.c_int]
+        L.s3sh_dispatcher_set_fetch_thread_predictor.argtypes = [vp, ctypes.c_int]
+        L.s3sh_thread_predictor_run.restype = None
+        L.s3sh_thread_predictor_run.argtypes = [ctypes.c_int, vp, ctypes.c_int, vp]
         L.s3sh_get_path.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
         L.s3sh_device_for_map.argtypes = [vp, ctypes.c_longlong]
         L.s3sh_write_partition_lengths.argtypes = [vp, ctypes.c_int, ctypes.c_longlong, vp, ctypes.c_int]
@@ -106,6 +109,11 @@ class Dispatcher:
         """spark.shuffle.s3.useSparkShuffleFetch: objects live where Spark's FallbackStorage looks for them
         (S3ShuffleDispatcher.scala:132-141)."""
         _check(_lib().s3sh_dispatcher_set_use_spark_shuffle_fetch(self._h, int(on)))
+
+    def set_fetch_thread_predictor(self, on: bool = True):
+        """spark.shuffle.s3.gpu.fetchThreadPredictor: the reference's latency-driven fetch-thread count
+        (S3BufferedPrefetchIterator.scala:32-91) instead of all maxConcurrencyTask threads."""
+        _check(_lib().s3sh_dispatcher_set_fetch_thread_predictor(self._h, int(on)))
 
     def get_path(self, kind: int, shuffle_id: int, map_id: int, r0: int = 0, r1: int = 1) -> str:
         buf = ctypes.create_string_buffer(1024)
@@ -241,4 +249,14 @@ def read_shuffle(dispatcher: Dispatcher, shuffle_id: int, start_partition: int, 
             out.append((name.value.decode(), int(m.value), int(r0.value), int(r1.value), buf[:n]))
     finally:
         L.s3sh_result_destroy(r)
+    return out
+
+
+def thread_predictor_run(max_threads: int, latencies_ns):
+    """Predicted fetch-thread count after each consumer wait time (the host mirror's ThreadPredictor alone)."""
+    import numpy as np
+
+    lat = np.ascontiguousarray(np.asarray(latencies_ns, dtype=np.int64))
+    out = np.zeros(lat.size, dtype=np.int32)
+    _lib().s3sh_thread_predictor_run(int(max_threads), lat.ctypes.data, int(lat.size), out.ctypes.data)
     return out

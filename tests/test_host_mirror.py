@@ -60,6 +60,65 @@ def test_paths_and_index_format(codec_lib, root, tmp_path):
     d.close()
 
 
+def _thread_predictor_scala(max_threads, latencies):
+    """storage/S3BufferedPrefetchIterator.scala:32-69 (class ThreadPredictor), line by line."""
+    current_threads = 1
+    lat = [0] * (max_threads + 2)
+    lat[0] = lat[max_threads + 1] = (1 << 63) - 1
+    num = 0
+    meas = [0] * 20
+    out = []
+    for latency in latencies:
+        if latency >= 0:
+            meas[num % 20] = latency
+            num += 1
+        # predict()
+        if num < 20 + current_threads:
+            out.append(current_threads)
+            continue
+        cur = sum(meas)
+        if cur < 500:
+            out.append(current_threads)
+            continue
+        lat[current_threads] = cur
+        prev_v, next_v = lat[current_threads - 1], lat[current_threads + 1]
+        num = 0
+        if prev_v < cur:
+            current_threads -= 1
+        elif next_v < cur:
+            current_threads += 1
+        out.append(current_threads)
+    return out
+
+
+def test_fetch_thread_predictor_is_the_references(codec_lib):
+    """The host mirror's fetch-thread tuner against a restatement of the Scala class on the same wait times: a slow
+    store (the count climbs), a store that gets fast (it comes back down), no waiting at all (it stays), the walls at
+    1 and maxThreads."""
+    from s3shuffle import host
+
+    rng = np.random.default_rng(9)
+    cases = []
+    slow = [int(x) for x in rng.integers(200_000, 400_000, 400)]
+    cases.append((6, slow))
+    # latency that falls with the thread count the predictor currently believes in (a closed loop, replayed open-loop
+    # for both implementations from the same recorded trace)
+    trace, threads = [], 1
+    for i in range(1200):
+        trace.append(int(1_000_000 / threads + rng.integers(0, 2000)))
+        if i % 21 == 20:
+            threads = _thread_predictor_scala(8, trace)[-1]
+    cases.append((8, trace))
+    cases.append((4, [0] * 300))                               # "less than 25 ns for each request": stays at one
+    cases.append((3, [-1] * 50 + slow[:200] + [10] * 200 + slow))  # no-measurement calls, fast phase, slow again
+    cases.append((1, slow))                                    # one thread allowed: walls on both sides
+    for max_threads, lat in cases:
+        got = host.thread_predictor_run(max_threads, lat).tolist()
+        assert got == _thread_predictor_scala(max_threads, lat), max_threads
+        assert 1 <= min(got) and max(got) <= max_threads
+    assert max(host.thread_predictor_run(6, slow)) > 1         # it does move
+
+
 def test_fallback_storage_layout(codec_lib, root, tmp_path):
     """spark.shuffle.s3.useSparkShuffleFetch: ${rootDir}${appId}/${shuffleId}/${JavaUtils.nonNegativeHash(name)}/${name}
     (S3ShuffleDispatcher.scala:132-141); listing is not supported there (:147-149).  String.hashCode known answers:
