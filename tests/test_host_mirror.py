@@ -352,6 +352,26 @@ def test_prefetch_pipeline_equals_sequential_reader(gpu_codec, root, batch):
 
 
 @pytest.mark.gpu
+def test_prefetch_pipeline_with_the_thread_predictor(gpu_codec, root):
+    """spark.shuffle.s3.gpu.fetchThreadPredictor: fetch threads above the predicted count park instead of fetching;
+    whatever the count does, every block arrives once and decodes to the same bytes."""
+    from s3shuffle import host
+
+    d = host.Dispatcher(root)
+    _write_terasort_maps(d, 8, 1 << 20, 10)
+    want = host.read_shuffle(d, 0, 0, 10, False, sequential=True)
+    d.set_fetch_thread_predictor(True)
+    for (budget, fetchers, decoders, dec_budget) in [(0, 0, 0, 0), (2 << 20, 6, 2, 2 << 20)]:
+        d.set_prefetch(budget, fetchers, decoders, dec_budget)
+        got = host.read_shuffle(d, 0, 0, 10, False)
+        assert [g[:4] for g in got] == [w[:4] for w in want]
+        for g, w in zip(got, want):
+            assert np.array_equal(g[4], w[4]), g[0]
+    d.remove_root()
+    d.close()
+
+
+@pytest.mark.gpu
 def test_prefetch_pipeline_propagates_block_errors(gpu_codec, root):
     """A corrupted block surfaces from next() with the reference's exception (S3ChecksumValidationStream
     .scala:72-74), the other blocks still decode, and the pipeline shuts down cleanly mid-stream."""
