@@ -1460,7 +1460,11 @@ def scoreboard(w, i):
 
 
 class Cost:
-    """crude per-wave cycle model (tools/probe/issue_probe.hip): used for A/B estimates only"""
+    """crude per-wave cycle model (tools/probe/issue_probe.hip): used for A/B estimates only.
+    It is ONE wavefront alone: what the wavefronts of a CU share is not in it — the scalar and vector issue ports (one
+    instruction of each kind per cycle per CU: the batch decoder is bound by them, and there the instruction COUNT
+    predicted every hardware result of round 3 while this model's cycles did not), the LDS pipe (an access that is not
+    aligned to its width occupies it for 65 cycles, tools/probe/lds_align_probe.hip) and the L1 / L2 queues."""
     ISSUE = 5
     TAKEN = 25
     NOT_TAKEN = 11
