@@ -199,6 +199,43 @@ def test_compiled_decoder_valid_blocks(oracle):
     assert st == 0 and res == [c.tobytes() for c in chunks]
 
 
+def test_compiled_decoder_on_chained_sources(oracle):
+    """hand-made sequence lists whose matches copy from inside earlier matches, from literal runs and from periodic
+    patterns (the generator of tests/test_batch_decode_model.py): what the decoder's source redirection, its 16-byte
+    pieces and the period splats have to get right — through the COMPILED kernel, both formats, plus TeraSort blocks"""
+    import decode_kernel as dk
+    import framing
+    import test_batch_decode_model as tm
+    from s3shuffle import datagen
+
+    rng = np.random.default_rng(7)
+    lz, sn = [], []
+    for _ in range(8):
+        seqs = tm._chain_sequences(rng, int(rng.integers(50, 400)))
+        blk = framing.lz4_block([(rng.integers(0, 256, l).astype(np.uint8).tobytes(), o, m) for l, o, m in seqs], b"abcdefg")
+        lz.append((blk, framing.lz4_decode_py(blk)))
+        els = []
+        for l, o, m in seqs:
+            if l:
+                els.append(("lit", rng.integers(0, 256, l).astype(np.uint8).tobytes()))
+            while m > 0:
+                k = min(m, 64)
+                els.append(("copy", o, k, 2))
+                m -= k
+        sblk = framing.snappy_block(els)
+        want = framing.snappy_decode_py(sblk)
+        if want is not None and 0 < len(want) <= 32768:
+            sn.append((sblk, want))
+    data, _ = datagen.terasort_map_output(1 << 20, 10, seed=3)
+    for b in range(2):
+        c = data[b * 32768:(b + 1) * 32768]
+        lz.append((bytes(oracle.lz4_compress_block(c)), c.tobytes()))
+        sn.append((bytes(oracle.snappy_compress_block(c)), c.tobytes()))
+    for fmt, cases in ((0, lz), (1, sn)):
+        res, st, _ = dk.decode_blocks([(b, len(w)) for b, w in cases], fmt=fmt)
+        assert st == 0 and res == [w for _, w in cases], fmt
+
+
 def test_compiled_decoder_rejects_malformed_blocks_without_leaving_its_buffers():
     """the payload buffer ends with the block's last byte and the destination has exactly the declared size: any
     access outside either faults in the interpreter (MemFault), whatever the bytes say"""
