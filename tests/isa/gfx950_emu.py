@@ -8,6 +8,7 @@ use: the scalar and vector integer ALU, SDWA / DPP operand forms, LDS, global me
 SCC.  It does not model timing, the hardware's hazards (tests/isa/hazards.py checks the hand-written blocks for
 those), floating point, MFMA, or more than one wavefront per workgroup.
 """
+import copy
 import re
 import numpy as np
 
@@ -400,6 +401,13 @@ def _sdwa_sel(arr, sel, sext=False):
     raise EmuError("sdwa sel " + sel)
 
 
+def _rv_sdwa(w, o, sel):
+    """SDWA source: the selected byte / word of the register, sign-extended if written sext(vN)"""
+    if o[0] == "sext":
+        return _sdwa_sel(w.rv32(o[1]), sel, sext=True)
+    return _sdwa_sel(w.rv32(o), sel)
+
+
 def _sdwa_dst(old, new, sel, unused):
     if sel is None or sel == "DWORD":
         return new
@@ -724,10 +732,11 @@ class Program:
                     if ty == "i64":
                         x, y = x.astype(np.int64), y.astype(np.int64)
                 else:
-                    x, y = w.rv32(a), w.rv32(b)
                     if "src0_sel" in i.mods or "src1_sel" in i.mods:
-                        x = _sdwa_sel(x, i.mods.get("src0_sel"))
-                        y = _sdwa_sel(y, i.mods.get("src1_sel"))
+                        x = _rv_sdwa(w, a, i.mods.get("src0_sel"))
+                        y = _rv_sdwa(w, b, i.mods.get("src1_sel"))
+                    else:
+                        x, y = w.rv32(a), w.rv32(b)
                     if ty == "i32":
                         x, y = _i32(x), _i32(y)
                     elif ty == "u16":
@@ -740,13 +749,14 @@ class Program:
             f = V2[base]
 
             def run(w, i, f=f):
-                a, b = w.rv32(i.ops[1]), w.rv32(i.ops[2])
                 if i.op.endswith("_sdwa"):
-                    a = _sdwa_sel(a, i.mods.get("src0_sel"))
-                    b = _sdwa_sel(b, i.mods.get("src1_sel"))
+                    a = _rv_sdwa(w, i.ops[1], i.mods.get("src0_sel"))
+                    b = _rv_sdwa(w, i.ops[2], i.mods.get("src1_sel"))
                     r = _sdwa_dst(w.v[i.ops[0][1]], f(a, b), i.mods.get("dst_sel"), i.mods.get("dst_unused"))
                     w.wv32(i.ops[0], r)
-                elif i.op.endswith("_dpp"):
+                    return
+                a, b = w.rv32(i.ops[1]), w.rv32(i.ops[2])
+                if i.op.endswith("_dpp"):
                     a, ok = _dpp_src(w, i, a, None)
                     r = f(a, b)
                     w.wv32(i.ops[0], np.where(ok, r, w.v[i.ops[0][1]]))
@@ -797,9 +807,12 @@ class Program:
         m = re.match(r"^ds_write_(b8|b16|b32|b64|b96|b128)$", base)
         if m:
             return self._mk_dswrite(m.group(1))
-        m = re.match(r"^ds_(read|write)2_(b32|b64)$", base)
+        m = re.match(r"^scratch_(load|store)_(dword|dwordx2|dwordx3|dwordx4)$", base)
         if m:
-            return self._mk_ds2(m.group(1) == "read", 4 if m.group(2) == "b32" else 8)
+            return self._mk_scratch(m.group(1) == "load", {"dword": 1, "dwordx2": 2, "dwordx3": 3, "dwordx4": 4}[m.group(2)])
+        m = re.match(r"^ds_(read|write)2(st64)?_(b32|b64)$", base)
+        if m:
+            return self._mk_ds2(m.group(1) == "read", 4 if m.group(3) == "b32" else 8, 64 if m.group(2) else 1)
         m = re.match(r"^s_load_dword(x2|x4|x8|x16)?$", base)
         if m:
             n = {None: 1, "x2": 2, "x4": 4, "x8": 8, "x16": 16}[m.group(1)]
@@ -893,14 +906,42 @@ class Program:
             w.v[d] = np.where(e, val, w.v[d])
         return run
 
-    def _mk_ds2(self, is_read, n):
-        """ds_read2_b32 / _b64, ds_write2_b32 / _b64: two elements at addr + offset0 * n and addr + offset1 * n"""
-        def run(w, i, is_read=is_read, n=n):
+    def _mk_scratch(self, is_load, k):
+        """scratch_load_dword[xN] vdst, vaddr|off, saddr|off / scratch_store_dword[xN] vaddr|off, vdata, saddr|off: private
+        memory, one copy per lane (4 KiB each here; the kernels of this repo use a few dwords)"""
+        def run(w, i, is_load=is_load, k=k):
+            if not hasattr(w, "scratch"):
+                w.scratch = np.zeros((64, 4096), dtype=np.uint8)
+            va, sa = (i.ops[1], i.ops[2]) if is_load else (i.ops[0], i.ops[2])
+            addr = np.zeros(64, dtype=np.int64) + int(i.mods.get("offset", "0"), 0)
+            if va[0] != "off":
+                addr = addr + w.v[va[1]].astype(np.int64)
+            if sa[0] != "off":
+                addr = addr + w.rs32(sa)
+            e = w.em()
+            if e.any() and (addr[e].min() < 0 or addr[e].max() + 4 * k > w.scratch.shape[1]):
+                raise MemFault("scratch access out of bounds: %s" % i.text)
+            for lane in np.flatnonzero(e):
+                a = int(addr[lane])
+                if is_load:
+                    words = np.ascontiguousarray(w.scratch[lane, a:a + 4 * k]).view("<u4")
+                    for j in range(k):
+                        w.v[i.ops[0][1] + j][lane] = words[j]
+                else:
+                    d = i.ops[1][1]
+                    vals = np.array([w.v[d + j][lane] for j in range(k)], dtype="<u4")
+                    w.scratch[lane, a:a + 4 * k] = vals.view(np.uint8)
+        return run
+
+    def _mk_ds2(self, is_read, n, stride=1):
+        """ds_read2[st64]_b32 / _b64, ds_write2[st64]_b32 / _b64: two elements of n bytes at addr + offset0 * unit and
+        addr + offset1 * unit, unit = n (st64: 64 * n)"""
+        def run(w, i, is_read=is_read, n=n, unit=n * stride):
             e = w.em()
             base = w.v[i.ops[1 if is_read else 0][1]].astype(np.int64)
             k = n // 4
             for which, mod in enumerate(("offset0", "offset1")):
-                addr = (base + int(i.mods.get(mod, "0"), 0) * n) & 0xFFFFFFFF  # (32-bit add: a negative base wraps)
+                addr = (base + int(i.mods.get(mod, "0"), 0) * unit) & 0xFFFFFFFF  # (32-bit add: a negative base wraps)
                 a = np.where(e, addr, 0)
                 if e.any() and (a[e].min() < 0 or a[e].max() + n > w.lds_limit):
                     raise MemFault("LDS access out of bounds: %s" % i.text)
@@ -1228,6 +1269,33 @@ class Program:
             r = _sdwa_dst(w.v[i.ops[0][1]], r, i.mods.get("dst_sel"), i.mods.get("dst_unused"))
         w.wv32(i.ops[0], r)
 
+    def x_s_set_gpr_idx_on(self, w, i):
+        # VGPR indexing mode: until s_set_gpr_idx_off, vector instructions add the index to the VGPR number of the named
+        # operands (the compiler's way to index a small array it keeps in registers)
+        m = re.search(r"gpr_idx\(([A-Z0-9,]+)\)", i.text)
+        w.gpr_idx = (w.rs32(i.ops[0]) & 0xFF, set(m.group(1).split(",")) if m else set())
+
+    def x_s_set_gpr_idx_off(self, w, i):
+        w.gpr_idx = None
+
+    def x_v_bfe_i32(self, w, i):
+        a, off, width = w.rv32(i.ops[1]), w.rv32(i.ops[2]) & np.uint32(31), w.rv32(i.ops[3]) & np.uint32(31)
+        x = (a >> off).astype(np.int64) & ((np.int64(1) << width.astype(np.int64)) - 1)
+        sign = (x >> np.maximum(width.astype(np.int64) - 1, 0)) & 1
+        x = np.where((width > 0) & (sign == 1), x - (np.int64(1) << width.astype(np.int64)), x)
+        w.wv32(i.ops[0], (np.where(width == 0, 0, x) & 0xFFFFFFFF).astype(np.uint32))
+
+    def x_v_bitop3_b16(self, w, i):
+        # as v_bitop3_b32 on the low halves (the high half of the destination is kept)
+        tt = int(i.mods["bitop3"], 0)
+        a, b, c = w.rv32(i.ops[1]), w.rv32(i.ops[2]), w.rv32(i.ops[3])
+        r = np.zeros(64, dtype=np.uint32)
+        for k in range(8):
+            if (tt >> k) & 1:
+                r |= (a if k & 4 else ~a) & (b if k & 2 else ~b) & (c if k & 1 else ~c)
+        old = w.rv32(i.ops[0])
+        w.wv32(i.ops[0], (old & np.uint32(0xFFFF0000)) | (r & np.uint32(0xFFFF)))
+
     def x_v_readlane_b32(self, w, i):
         lane = w.rs32(i.ops[2]) & 63
         w.ws32(i.ops[0], int(w.v[i.ops[1][1]][lane]))
@@ -1348,7 +1416,7 @@ class Program:
         w.wv32(i.ops[0], f.astype(np.uint64).astype(np.uint32))
 
     def x_v_rcp_iflag_f32(self, w, i):
-        with np.errstate(divide="ignore"):
+        with np.errstate(divide="ignore", over="ignore", invalid="ignore"):
             w.wv32(i.ops[0], (np.float32(1.0) / self._f32(w, i.ops[1])).astype(np.float32).view(np.uint32))
 
     x_v_rcp_f32 = x_v_rcp_iflag_f32
@@ -1551,7 +1619,18 @@ def run_wave(prog, w, entry=None, max_inst=50_000_000, profile=None, hooks=None)
             raise EmuError("opcode not modelled (line %d): %s" % (i.line, i.text))
         try:
             scoreboard(w, i)
-            i.fn(w, i)
+            gi = getattr(w, "gpr_idx", None)
+            if gi is not None and k == "valu":  # VGPR indexing mode: shifted operands for this instruction only
+                idx, modes = gi
+                j = copy.copy(i)
+                ops = list(i.ops)
+                for name, pos in (("DST", 0), ("SRC0", 1), ("SRC1", 2), ("SRC2", 3)):
+                    if name in modes and pos < len(ops) and ops[pos][0] == "v":
+                        ops[pos] = ("v", ops[pos][1] + idx) + tuple(ops[pos][2:])
+                j.ops = ops
+                i.fn(w, j)
+            else:
+                i.fn(w, i)
         except EmuError as e:
             raise type(e)("%s   [line %d: %s]" % (e, i.line, i.text)) from None
         pc += 1
@@ -1563,7 +1642,31 @@ def parse_objects(text):
     """data objects of the assembly (`name:` followed by .long / .short / .byte / .quad / .zero) -> {name: bytes}"""
     out, cur, buf = {}, None, None
     fmt = {".long": 4, ".int": 4, ".short": 2, ".byte": 1, ".quad": 8}
+    def unescape(body):  # the assembler's string syntax: \ooo octal, \b \t \n \f \r \" \\
+        b, k = bytearray(), 0
+        simple = {"b": 8, "t": 9, "n": 10, "f": 12, "r": 13, '"': 34, "\\": 92}
+        while k < len(body):
+            ch = body[k]
+            if ch != "\\":
+                b.append(ord(ch))
+                k += 1
+            elif body[k + 1] in "01234567":
+                j = k + 1
+                while j < len(body) and j < k + 4 and body[j] in "01234567":
+                    j += 1
+                b.append(int(body[k + 1:j], 8) & 0xFF)
+                k = j
+            else:
+                b.append(simple[body[k + 1]])
+                k += 2
+        return bytes(b)
+
     for raw in text.splitlines():
+        st = raw.strip()
+        if cur is not None and (st.startswith(".ascii") or st.startswith(".asciz")):
+            q0, q1 = st.index('"'), st.rindex('"')
+            buf += unescape(st[q0 + 1:q1]) + (b"\0" if st.startswith(".asciz") else b"")
+            continue
         line = raw.split(";")[0].strip()
         if not line:
             continue

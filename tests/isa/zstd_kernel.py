@@ -1,0 +1,79 @@
+"""Runs the compiled `zstd_partitions_kernel` (Zstandard decode of the reduce side, zstd_decompress.hip +
+zstd_decode_core.h) on the CPU through tests/isa/gfx950_emu.py (TEST INFRASTRUCTURE).  Both passes of the product: pass 1
+(sizes, literal scratch need) and pass 2 (decode); source, destination and scratch buffers have exactly their declared
+sizes, so any access outside them faults in the interpreter."""
+import os
+import struct
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import gfx950_emu as emu  # noqa: E402
+import lz4_kernel as lk  # noqa: E402
+
+_PROG = None
+
+
+def program():
+    global _PROG
+    if _PROG is None:
+        text = lk.compile_asm("zstd_decompress.hip")
+        entry = lk.find_kernel(text, "zstd_partitions_kernel")
+        lds = 0
+        for line in text.splitlines():
+            if ".amdhsa_group_segment_fixed_size" in line:
+                lds = max(lds, int(line.split()[-1]))
+        _PROG = (emu.Program(text, entry), entry, text, lds)
+    return _PROG
+
+
+def decode_partitions(parts, profile=None):
+    """parts: list of (compressed partition bytes = concatenated frames, decoded size).  Returns (list of decoded bytes or
+    None, list of rc, waves of pass 2)."""
+    prog, entry, text, lds = program()
+    mem = emu.Memory()
+    comp = np.frombuffer(b"".join(p for p, _ in parts) or b"\0", dtype=np.uint8).copy()
+    a_comp = mem.map(comp, "comp", writable=False)
+    total = sum(n for _, n in parts)
+    dst = np.zeros(max(total, 1), dtype=np.uint8)
+    a_dst = mem.map(dst, "dst")
+    n = len(parts)
+    zres = np.zeros(n * 24, dtype=np.uint8)
+    a_res = mem.map(zres, "res")
+    objs = dict(emu.parse_objects(text))  # constant tables of the decoder (predefined FSE distributions, code tables)
+
+    def zparts(lit_offs):
+        b = bytearray()
+        co = do = 0
+        for k, (p, sz) in enumerate(parts):
+            b += struct.pack("<QqQqq", a_comp + co, len(p), a_dst + do, sz, lit_offs[k])
+            co += len(p)
+            do += sz
+        return np.frombuffer(bytes(b), dtype=np.uint8).copy()
+
+    # pass 1: sizes
+    zp = zparts([0] * n)
+    a_parts = mem.map(zp, "parts1", writable=False)
+    kernarg = struct.pack("<QiiQQ", a_parts, n, 0, 0, a_res)
+    emu.launch(prog, entry, mem, kernarg, n, lds, objects=objs)
+    res1 = [struct.unpack("<qqii", bytes(zres[24 * k:24 * k + 24])) for k in range(n)]
+    lit_offs, lit_total = [], 0
+    for (tot, need, rc, _) in res1:
+        lit_offs.append(lit_total)
+        lit_total += (need + 64 + 15) & ~15
+    sizes_ok = [rc == 0 and tot == parts[k][1] for k, (tot, need, rc, _) in enumerate(res1)]
+    lit = np.zeros(lit_total + 64, dtype=np.uint8)
+    a_lit = mem.map(lit, "lit")
+    zp2 = zparts(lit_offs)
+    a_parts2 = mem.map(zp2, "parts2", writable=False)
+    kernarg = struct.pack("<QiiQQ", a_parts2, n, 1, a_lit, a_res)
+    waves = emu.launch(prog, entry, mem, kernarg, n, lds, profile=profile, objects=objs)
+    out, rcs, do = [], [], 0
+    for k, (p, sz) in enumerate(parts):
+        tot, need, rc, _ = struct.unpack("<qqii", bytes(zres[24 * k:24 * k + 24]))
+        rcs.append(rc if sizes_ok[k] or rc else -999)
+        out.append(bytes(dst[do:do + sz]) if rc == 0 and tot == sz else None)
+        do += sz
+    return out, rcs, waves

@@ -267,3 +267,35 @@ def test_compiled_decoder_rejects_malformed_blocks_without_leaving_its_buffers()
     for blk in sbad:
         _, st, _ = dk.decode_blocks([(blk, _preamble_len(blk))], fmt=1)
         assert st == -3
+
+
+# ---- the compiled Zstandard decoder (reduce side, zstd only) under the interpreter -------------------------------------
+def test_compiled_zstd_decoder(oracle):
+    """zstd_partitions_kernel as hipcc compiles it, both passes of the product (sizes, then decode through the literal
+    scratch), on frames written by libzstd the way zstd-jni writes them: TeraSort records and wide rows (Huffman literals,
+    FSE sequence tables, repeat offsets), zeros (RLE blocks), random bytes (raw blocks), two partitions in one launch, a
+    partition of several concatenated frames, an empty partition.  Source, destination and scratch buffers have exactly
+    their sizes: an access outside faults."""
+    import zstd_kernel as zk
+    from oracle import zstd_ref
+    from s3shuffle import datagen
+
+    rng = np.random.default_rng(5)
+    tera, _ = datagen.terasort_map_output(1 << 20, 10, seed=3)
+    wide, _ = datagen.tpcds_wide_map_output(1 << 20, 10, seed=3)
+    pieces = [tera[:9000], wide[:7000], np.zeros(5000, np.uint8), rng.integers(0, 256, 3000).astype(np.uint8),
+              tera[20000:20700]]
+    parts = [(bytes(zstd_ref.compress_stream(p, level=1)), p.size) for p in pieces]
+    # one partition made of three complete frames (a writer that was flushed in pieces), and an empty one
+    multi = b"".join(bytes(zstd_ref.compress_stream(p, level=1)) for p in (tera[:1500], wide[:1200], tera[3000:3300]))
+    parts.append((multi, 1500 + 1200 + 300))
+    parts.append((b"", 0))
+    want = [p.tobytes() for p in pieces] + [tera[:1500].tobytes() + wide[:1200].tobytes() + tera[3000:3300].tobytes(), b""]
+    out, rcs, _ = zk.decode_partitions(parts)
+    assert rcs == [0] * len(parts), rcs
+    assert out == want
+    # a truncated and a corrupted stream end in "bad frame" (or a size that does not match), never outside the buffers
+    good = parts[0][0]
+    for bad in (good[:len(good) // 2], good[:40] + bytes([good[40] ^ 0x5A]) + good[41:]):
+        out, rcs, _ = zk.decode_partitions([(bad, parts[0][1])])
+        assert out[0] is None or out[0] == want[0]
