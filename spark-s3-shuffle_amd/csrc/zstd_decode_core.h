@@ -735,22 +735,61 @@ ZS_HD int decode_frame(Work& w, const uint8_t* src, int64_t size, uint8_t* dst, 
           const uint32_t vl = ZS_UNI32(w.llv[sl]), vm = ZS_UNI32(w.mlv[sm]);
           const int co = (int)(eo >> 24);
           if (co > 31) return ZS_FAIL();
-          // extra bits: offset, match length, literal length
           uint32_t ov;
+          int64_t mlen, llen;
+#ifdef ZS_SEQ_FASTBITS
+          // (experiment for the next round) All fields of a sequence — offset, match-length and literal-length extra bits,
+          // then the three state updates — from ONE window: a refill puts at least 57 bits below the cursor into the
+          // cache, and a sequence of a level-1 stream needs far fewer; the six reads become shifts of one register.
+          const int bm = (int)(vm >> 24), bl = (int)(vl >> 24);
+          const bool more = i + 1 < nseq;
+          const int nl = more ? (int)((el >> 16) & 0xff) : 0, nm = more ? (int)((em >> 16) & 0xff) : 0,
+                    no = more ? (int)((eo >> 16) & 0xff) : 0;
+          const int nb = co + bm + bl + nl + nm + no;
+          if (nb <= 57) {
+            (void)bitr_peek(r, 1);  // make the cache cover the cursor: afterwards cache holds bits [cbase, cbase + 64), cbase <= pos - 57
+            if (!(r.pos - nb >= r.cbase && r.pos <= r.cbase + 64)) {
+              const int32_t top = (r.pos - 1) >> 3;
+              r.cbase = (top - 7) * 8;
+              r.cache = load_bits64(r.p, r.size, top - 7);
+#ifdef S3S_ZSTD_DEVICE
+              r.cache = (uint64_t)ZS_UNI32((uint32_t)r.cache) | ((uint64_t)ZS_UNI32((uint32_t)(r.cache >> 32)) << 32);
+#endif
+            }
+            uint64_t bits = r.cache >> (r.pos - nb - r.cbase);  // the nb bits of this sequence, first field on top
+            int rem = nb;
+            auto take = [&](int n) -> uint32_t {
+              rem -= n;
+              return (uint32_t)((bits >> rem) & ((1ull << n) - 1));
+            };
+            ov = take(co);
+            mlen = (int64_t)(vm & 0xFFFFFFu) + take(bm);
+            llen = (int64_t)(vl & 0xFFFFFFu) + take(bl);
+            if (more) {
+              sl = (el & 0xFFFFu) + take(nl);
+              sm = (em & 0xFFFFu) + take(nm);
+              so = (eo & 0xFFFFu) + take(no);
+            }
+            r.pos -= nb;
+          } else
+#endif
+          {
+          // extra bits: offset, match length, literal length
           if (co > 24) {  // more than 32 bits cannot be peeked at once: two reads
             const uint32_t hi = bitr_read(r, co - 16);
             ov = (hi << 16) | bitr_read(r, 16);
           } else {
             ov = bitr_read(r, co);
           }
-          const uint64_t oval = (1ull << co) + ov;
-          const int64_t mlen = (int64_t)(vm & 0xFFFFFFu) + bitr_read(r, (int)(vm >> 24));
-          const int64_t llen = (int64_t)(vl & 0xFFFFFFu) + bitr_read(r, (int)(vl >> 24));
+          mlen = (int64_t)(vm & 0xFFFFFFu) + bitr_read(r, (int)(vm >> 24));
+          llen = (int64_t)(vl & 0xFFFFFFu) + bitr_read(r, (int)(vl >> 24));
           if (i + 1 < nseq) {  // state updates: LL, ML, OF
             sl = (el & 0xFFFFu) + bitr_read(r, (int)((el >> 16) & 0xff));
             sm = (em & 0xFFFFu) + bitr_read(r, (int)((em >> 16) & 0xff));
             so = (eo & 0xFFFFu) + bitr_read(r, (int)((eo >> 16) & 0xff));
           }
+          }
+          const uint64_t oval = (1ull << co) + ov;
           // Strict (RFC 8878 §3.1.1.3.2.1.2: the stream ends exactly at its first bit): libzstd >= 1.4.5 lets a damaged
           // stream read below its start — what it returns there depends on its 64-bit container's state — and only demands
           // that no bits are left over; such streams are refused here ("Stream is corrupted") instead of decoded to

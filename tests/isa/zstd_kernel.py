@@ -14,12 +14,13 @@ import gfx950_emu as emu  # noqa: E402
 import lz4_kernel as lk  # noqa: E402
 
 _PROG = None
+FLAGS = ()  # extra hipcc flags (build switches kept for measurements, e.g. ("-DZS_SEQ_FASTBITS",)); set before program()
 
 
 def program():
     global _PROG
     if _PROG is None:
-        text = lk.compile_asm("zstd_decompress.hip")
+        text = lk.compile_asm("zstd_decompress.hip", FLAGS)
         entry = lk.find_kernel(text, "zstd_partitions_kernel")
         lds = 0
         for line in text.splitlines():

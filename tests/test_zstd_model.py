@@ -16,13 +16,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
-@pytest.fixture(scope="module")
-def model():
+# the decoder as it ships, and with the build switches that are kept for the next round's measurements (same results demanded)
+@pytest.fixture(scope="module", params=["", "-DZS_SEQ_FASTBITS"], ids=["shipped", "fastbits"])
+def model(request):
     src = os.path.join(HERE, "model", "zstd_decode_model.cpp")
-    so = os.path.join(HERE, "model", "zstd_decode_model.so")
+    so = os.path.join(HERE, "model", "zstd_decode_model%s.so" % ("_" + request.param[3:].lower() if request.param else ""))
     core = os.path.join(ROOT, "spark-s3-shuffle_amd", "csrc", "zstd_decode_core.h")
     if not os.path.exists(so) or max(os.path.getmtime(src), os.path.getmtime(core)) > os.path.getmtime(so):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fPIC", "-shared", src, "-o", so], check=True)
+        subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fPIC", "-shared", *([request.param] if request.param else []),
+                        src, "-o", so], check=True)
     m = ctypes.CDLL(so)
     i64p = ctypes.POINTER(ctypes.c_int64)
     m.zs_decoded_size.argtypes = [ctypes.c_void_p, ctypes.c_int64, i64p]
