@@ -76,7 +76,7 @@ def zstd_main():
     tot = sum(by_src.values())
     print("pass 2: %d instructions with a handler for %d bytes (%d compressed)" % (tot, blk.size, len(comp)))
     srcs = {}
-    for key, c in sorted(((k, v) for k, v in by_src.items()), key=lambda kv: -kv[1])[:60]:
+    for key, c in sorted(((k, v) for k, v in by_src.items()), key=lambda kv: -kv[1])[:int(os.environ.get("SP_TOP", "60"))]:
         if key is None:
             print("%8d %5.1f%%  (no line)" % (c, 100.0 * c / tot))
             continue
