@@ -1107,6 +1107,26 @@ class Program:
         w.ws32(i.ops[0], r)
         w.scc = 1 if r else 0
 
+    def _s_bfe64(self, w, i, signed):
+        spec = w.rs32(i.ops[2])
+        off, width = spec & 0x3F, (spec >> 16) & 0x7F
+        v = _lit64(i.ops[1], w) & M64
+        if width == 0:
+            r = 0
+        else:
+            width = min(width, 64 - off) if off < 64 else 0
+            r = (v >> off) & ((1 << width) - 1) if width else 0
+            if signed and width and width < 64 and (r >> (width - 1)) & 1:
+                r -= 1 << width
+        w.ws64(i.ops[0], r & M64)
+        w.scc = 1 if (r & M64) else 0
+
+    def x_s_bfe_u64(self, w, i):
+        self._s_bfe64(w, i, False)
+
+    def x_s_bfe_i64(self, w, i):
+        self._s_bfe64(w, i, True)
+
     def x_s_bfe_i32(self, w, i):
         spec = w.rs32(i.ops[2])
         width = (spec >> 16) & 0x7F
