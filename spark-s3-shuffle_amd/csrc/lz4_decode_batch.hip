@@ -4,19 +4,21 @@
 // (S3ShuffleReader.scala:108 wraps the range stream with it).  One wavefront per LZ4Block frame.
 //
 // The ring decoder (lz4_decompress.hip, variant 3) spends ~100+ vector instructions per LZ4 sequence
-// and a CU issues one vector instruction per cycle, so it is instruction-issue bound at ~1 sequence
-// per 2000 CU cycles.  A decoder is free to reorganise the work (no bit-exact parse to follow), so
+// and a CU issues one vector (and one scalar) instruction per cycle for all of its wavefronts, so it is
+// instruction-issue bound at ~1 sequence per 2000 CU cycles.  A decoder is free to reorganise the work (no bit-exact parse to follow), so
 // this one makes the lanes work on DIFFERENT sequences:
 //
 //   parse    lane i assumes a token starts at stream byte ip+i and decodes it speculatively (literal
 //            length, offset, match length, position of the next token) from two dword loads; a short
-//            scalar walk over `next` marks the real tokens of the 64-byte window (~7 instructions per
-//            sequence); they are appended to the batch (one record per lane, via LDS)
+//            scalar walk over `next` marks the real tokens of the 64-byte window (5 instructions per
+//            sequence, hand-written); they are appended to the batch (one record per lane, via LDS)
 //   batch    (up to 64 sequences) a prefix sum gives every sequence its output position; ALL literal
-//            runs of the batch are copied at once, one lane per sequence; matches are copied in
-//            dependency rounds: lanes whose source ends before the round's first output byte copy
-//            their (short) matches side by side, a long / overlapping / far match is copied by the
-//            whole wave, 64 bytes per step
+//            runs of the batch are copied at once, one lane per sequence; matches are copied as 16-byte
+//            PIECES, one lane per piece, in dependency rounds — after every match has been pointed at
+//            where it REALLY reads from: a source inside one earlier match's output is that match's
+//            source shifted (chains resolved by pointer doubling), a source inside the batch's literals
+//            is final from the start, periods 1 / 2 / 4 are splats; a match above 64 bytes, an odd
+//            period or a source that straddles the window base is copied by the whole wave
 //   output   is staged in a sliding LDS window (5.4 KiB, 4 KiB of history survive a slide): match
 //            sources are LDS reads, the block leaves in 16-byte coalesced stores; a source older than
 //            the window is read back from L2 (after the flush that wrote it has drained)
