@@ -52,6 +52,23 @@ def test_compiled_kernel_matches_oracle(oracle, windows):
     _check(chunks, oracle, windows=windows)
 
 
+def test_rolling_prefetch_build_is_the_same_compressor(oracle):
+    """-DS3S_X_ROLL_PREFETCH (kept for the next round's measurement: lanes 20..23 of the window block's stream load touch
+    cache lines 3 KiB ahead instead of the whole block being touched up front): same bytes, and the extra lanes stay
+    inside the block — the source buffer ends with the last chunk's last byte."""
+    import lz4_kernel as lk
+    from s3shuffle import datagen
+
+    rng = np.random.default_rng(8)
+    data, _ = datagen.terasort_map_output(1 << 20, 4, seed=2, map_id=1)
+    chunks = [np.asarray(data[:32768]).copy(), corpus.chunk_corpus(6, 9000, rng), corpus.chunk_corpus(2, 3500, rng),
+              np.asarray(data[50000:50000 + 3300]).copy()]
+    out = lk.compress_chunks(chunks, windows=True, flags=("-DS3S_X_ROLL_PREFETCH",))
+    for c, (payload, _, _) in zip(chunks, out):
+        ref = bytes(oracle.lz4_compress_block(c))
+        assert (payload is None and len(ref) >= len(c)) or bytes(payload) == ref
+
+
 def test_lds_race_winner_is_irrelevant(oracle):
     """same-address LDS stores of one instruction: any lane may win (tests/model proves it; here on the real code)"""
     rng = np.random.default_rng(22)
