@@ -67,6 +67,11 @@ def test_rolling_prefetch_build_is_the_same_compressor(oracle):
     for c, (payload, _, _) in zip(chunks, out):
         ref = bytes(oracle.lz4_compress_block(c))
         assert (payload is None and len(ref) >= len(c)) or bytes(payload) == ref
+    import hazards
+
+    text = lk.compile_asm("lz4_compress.hip", ("-DS3S_X_ROLL_PREFETCH",))
+    asm_viol, cc_viol, _, _ = hazards.check_kernel(text, lk.find_kernel(text, "lz4_compress_l2_kernelILb1E"))
+    assert not asm_viol and not cc_viol, (asm_viol[:3], cc_viol[:3])
 
 
 def test_lds_race_winner_is_irrelevant(oracle):
