@@ -16,22 +16,26 @@ import lz4_kernel as lk  # noqa: E402
 _PROGS = {}
 
 
-def program(fmt):
-    if fmt not in _PROGS:
-        text = lk.compile_asm("lz4_decode_batch.hip")
+def program(fmt, flags=()):
+    key = (fmt, tuple(flags))
+    if key not in _PROGS:
+        text = lk.compile_asm("lz4_decode_batch.hip", flags=flags)
         entry = lk.find_kernel(text, "batch_decode_kernelILi%dE" % fmt)
         lds = 0
         for line in text.splitlines():  # the kernel's LDS size from its descriptor block
             if ".amdhsa_group_segment_fixed_size" in line:
                 lds = max(lds, int(line.split()[-1]))
-        _PROGS[fmt] = (emu.Program(text, entry), entry, text, lds or 6144)
-    return _PROGS[fmt]
+        _PROGS[key] = (emu.Program(text, entry), entry, text, lds or 6144)
+    return _PROGS[key]
 
 
-def decode_blocks(blocks, fmt=0, methods=None, profile=None):
+def decode_blocks(blocks, fmt=0, methods=None, profile=None, flags=(), grid=None):
     """blocks: list of (payload bytes, decoded length).  fmt 0 = LZ4 block payloads, 1 = raw Snappy blocks.
-    Returns (list of decoded bytes, status word, waves)."""
-    prog, entry, text, lds = program(fmt)
+    Returns (list of decoded bytes, status word, waves).  flags: extra -D macros of an experiment build; with
+    -DS3S_DEC_PERSIST the kernel takes a frame counter as its last argument and `grid` wavefronts draw frames from it
+    (the interpreter runs them one after the other, so the first one decodes every frame through ONE window buffer
+    and the others find the counter exhausted)."""
+    prog, entry, text, lds = program(fmt, flags)
     mem = emu.Memory()
     comp = b"".join(p for p, _ in blocks)
     frames = bytearray()
@@ -51,8 +55,13 @@ def decode_blocks(blocks, fmt=0, methods=None, profile=None):
     a_dst = mem.map(dst, "dst")
     a_status = mem.map(status, "status")
     kernarg = struct.pack("<QQiiQQQ", a_comp, a_frames, len(blocks), 0, a_fout, a_dst, a_status)
+    work = np.zeros(1, dtype=np.uint32)
+    if "-DS3S_DEC_PERSIST" in flags:
+        kernarg += struct.pack("<Q", mem.map(work, "work"))
     objs = emu.parse_objects(text)
-    waves = emu.launch(prog, entry, mem, kernarg, len(blocks), lds, profile=profile,
+    waves = emu.launch(prog, entry, mem, kernarg, grid or len(blocks), lds, profile=profile,
                        objects={k: v for k, v in objs.items() if k.startswith("_ZN3s3s")})
     res = [bytes(dst[outs[k]:outs[k] + blocks[k][1]]) for k in range(len(blocks))]
+    if "-DS3S_DEC_PERSIST" in flags:
+        assert int(work[0]) == len(blocks) + (grid or len(blocks)), "every wavefront leaves through the counter"
     return res, int(status[0]), waves

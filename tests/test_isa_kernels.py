@@ -258,6 +258,30 @@ def test_compiled_decoder_on_chained_sources(oracle):
         assert st == 0 and res == [w for _, w in cases], fmt
 
 
+def test_persistent_grid_decoder_build_is_the_same_decoder(oracle):
+    """-DS3S_DEC_PERSIST (an experiment kept for the next round's measurement): wavefronts draw
+    frames from a counter and decode them one after the other through the same LDS window.  Valid blocks of both
+    formats decode to the same bytes, a malformed frame between valid ones sets the status and does not stop the
+    frames after it, every wavefront leaves through the counter."""
+    import decode_kernel as dk
+    import framing
+
+    flags = ("-DS3S_DEC_PERSIST",)
+    rng = np.random.default_rng(43)
+    chunks = [corpus.chunk_corpus(k, n, rng) for k, n in [(7, 20000), (3, 5000), (6, 32768), (1, 4000), (7, 13), (2, 3000)]]
+    blocks = [(bytes(oracle.lz4_compress_block(c)), len(c)) for c in chunks]
+    res, st, _ = dk.decode_blocks(blocks, fmt=0, flags=flags, grid=3)
+    assert st == 0 and res == [c.tobytes() for c in chunks]
+    sblocks = [(bytes(oracle.snappy_compress_block(c)), len(c)) for c in chunks]
+    res, st, _ = dk.decode_blocks(sblocks, fmt=1, flags=flags, grid=2)
+    assert st == 0 and res == [c.tobytes() for c in chunks]
+    z = b"abcdefgh"
+    bad = framing.lz4_block([(z, 9, 4)], z)
+    mixed = blocks[:2] + [(bad, len(framing.lz4_decode_py(framing.lz4_block([(z, 8, 4)], z))))] + blocks[2:4]
+    res, st, _ = dk.decode_blocks(mixed, fmt=0, flags=flags, grid=1)
+    assert st == -3 and res[:2] == [c.tobytes() for c in chunks[:2]] and res[3:] == [c.tobytes() for c in chunks[2:4]]
+
+
 def test_compiled_decoder_rejects_malformed_blocks_without_leaving_its_buffers():
     """the payload buffer ends with the block's last byte and the destination has exactly the declared size: any
     access outside either faults in the interpreter (MemFault), whatever the bytes say"""
