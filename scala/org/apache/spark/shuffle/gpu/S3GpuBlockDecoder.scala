@@ -50,7 +50,7 @@ object S3GpuBlockDecoder {
   def decode(blockId: BlockId, stream: InputStream, jvmPath: InputStream => InputStream): InputStream = {
     val dispatcher = S3ShuffleDispatcher.get
     val (shuffleId, mapId, r0, r1) = range(blockId)
-    val ctx = S3SCodec.forThread(S3SCodec.deviceFor(mapId, S3SCodec.deviceCount()))
+    val ctx = S3SCodec.forThread(S3SCodec.deviceFor(mapId, S3SCodec.devices()))
     val codec = S3SCodec.codecId(dispatcher.gpuCodec)
     val algo = S3SCodec.checksumId(dispatcher.checksumEnabled, dispatcher.checksumAlgorithm)
     // cumulative `.index` of the map output, relative to the range
@@ -70,7 +70,9 @@ object S3GpuBlockDecoder {
       }
       val out = S3GpuBuffers.take(outLen(0))
       val bad = Array(-1)
-      val rc = S3SCodec.decompressRange(ctx, codec, algo, comp, compLen, rel, refs, r1 - r0, out, outLen(0), outLen, bad)
+      val rc =
+        try S3SCodec.decompressRange(ctx, codec, algo, comp, compLen, rel, refs, r1 - r0, out, outLen(0), outLen, bad)
+        catch { case t: Throwable => S3GpuBuffers.give(out); throw t }
       if (rc != S3SCodec.OK) S3GpuBuffers.give(out)
       S3SCodec.check(ctx, rc, blockId.name, if (bad(0) >= 0) r0 + bad(0) else -1)
       new S3GpuStreams.DirectBufferInputStream(out, outLen(0)) // gives `out` back to S3GpuBuffers on the first close()
@@ -103,7 +105,9 @@ object S3GpuStreams {
     private def live: Boolean = !closed.get()
     override def read(): Int = if (live && view.hasRemaining) view.get() & 0xff else -1
     override def read(b: Array[Byte], off: Int, len: Int): Int =
-      if (!live || !view.hasRemaining) -1 else { val k = math.min(len, view.remaining()); view.get(b, off, k); k }
+      if (len == 0) 0
+      else if (!live || !view.hasRemaining) -1
+      else { val k = math.min(len, view.remaining()); view.get(b, off, k); k }
     override def available(): Int = if (live) view.remaining() else 0
     override def close(): Unit = if (closed.compareAndSet(false, true)) S3GpuBuffers.give(buf)
   }

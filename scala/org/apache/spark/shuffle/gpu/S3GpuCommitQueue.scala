@@ -31,37 +31,51 @@ object S3GpuCommitQueue {
     private val maxBatch = math.max(S3ShuffleDispatcher.get.gpuCommitBatch, 1)
 
     override def run(): Unit = {
-      val ctx = S3SCodec.forThread(device) // this thread's own context
+      var ctx = 0L // this thread's own context, created with the first request: a failure to create it (no device, no
+      // library) must fail the waiting requests instead of ending the thread and leaving them blocked in `compress`
       val batch = new java.util.ArrayList[Request]()
       while (true) {
         batch.clear()
         batch.add(queue.take())
         queue.drainTo(batch, maxBatch - 1)
-        // one call per (codec, checksum) pair: in practice one pair per application
-        val first = batch.get(0)
-        val same = new scala.collection.mutable.ArrayBuffer[Request]()
-        val it = batch.iterator()
-        while (it.hasNext) { val r = it.next(); if (r.codec == first.codec && r.algo == first.algo) same += r else queue.put(r) }
-        val n = same.length
-        val totals = new Array[Long](n)
-        val status = new Array[Int](n)
-        try {
-          val rc = S3SCodec.compressMapOutputsBatch(ctx, first.codec, first.algo, same.map(_.src).toArray,
-            same.map(_.srcOffsets).toArray, same.map(_.dst).toArray, same.map(_.dstCap).toArray, same.map(_.index).toArray,
-            if (first.algo == S3SCodec.CHECKSUM_NONE) null else same.map(_.sums).toArray, totals, status)
-          val why = if (rc != S3SCodec.OK) S3SCodec.lastError(ctx) else ""
-          var i = 0
-          while (i < n) {
-            same(i).total = totals(i)
-            // a call-level failure (HIP error, bad argument) fails every request of the call; otherwise each has its own status
-            same(i).rc = if (rc != S3SCodec.OK && status(i) == S3SCodec.OK && rc != S3SCodec.E_CAPACITY) rc else status(i)
-            same(i).error = why
-            i += 1
+        if (ctx == 0L) {
+          try ctx = S3SCodec.forThread(device)
+          catch {
+            case t: Throwable =>
+              val it = batch.iterator()
+              while (it.hasNext) { val r = it.next(); r.rc = S3SCodec.E_HIP; r.error = t.toString; r.done.countDown() }
+              batch.clear()
           }
-        } catch {
-          case t: Throwable => same.foreach { r => r.rc = S3SCodec.E_HIP; r.error = t.toString }
-        } finally same.foreach(_.done.countDown())
+        }
+        if (!batch.isEmpty) runBatch(ctx, batch)
       }
+    }
+
+    private def runBatch(ctx: Long, batch: java.util.ArrayList[Request]): Unit = {
+      // one call per (codec, checksum) pair: in practice one pair per application
+      val first = batch.get(0)
+      val same = new scala.collection.mutable.ArrayBuffer[Request]()
+      val it = batch.iterator()
+      while (it.hasNext) { val r = it.next(); if (r.codec == first.codec && r.algo == first.algo) same += r else queue.put(r) }
+      val n = same.length
+      val totals = new Array[Long](n)
+      val status = new Array[Int](n)
+      try {
+        val rc = S3SCodec.compressMapOutputsBatch(ctx, first.codec, first.algo, same.map(_.src).toArray,
+          same.map(_.srcOffsets).toArray, same.map(_.dst).toArray, same.map(_.dstCap).toArray, same.map(_.index).toArray,
+          if (first.algo == S3SCodec.CHECKSUM_NONE) null else same.map(_.sums).toArray, totals, status)
+        val why = if (rc != S3SCodec.OK) S3SCodec.lastError(ctx) else ""
+        var i = 0
+        while (i < n) {
+          same(i).total = totals(i)
+          // a call-level failure (HIP error, bad argument) fails every request of the call; otherwise each has its own status
+          same(i).rc = if (rc != S3SCodec.OK && status(i) == S3SCodec.OK && rc != S3SCodec.E_CAPACITY) rc else status(i)
+          same(i).error = why
+          i += 1
+        }
+      } catch {
+        case t: Throwable => same.foreach { r => r.rc = S3SCodec.E_HIP; r.error = t.toString }
+      } finally same.foreach(_.done.countDown())
     }
   }
 

@@ -32,7 +32,7 @@ import org.apache.spark.shuffle.helper.{S3ShuffleDispatcher, S3ShuffleHelper}
 
 class S3GpuMapOutput(shuffleId: Int, mapId: Long, numPartitions: Int, createBlock: () => OutputStream) {
   private val dispatcher = S3ShuffleDispatcher.get
-  private val device = S3SCodec.deviceFor(mapId, S3SCodec.deviceCount())
+  private val device = S3SCodec.deviceFor(mapId, S3SCodec.devices())
   private val ctx = S3SCodec.forThread(device)
   private val codec = S3SCodec.codecId(dispatcher.gpuCodec)
   private val algo = S3SCodec.checksumId(dispatcher.checksumEnabled, dispatcher.checksumAlgorithm)

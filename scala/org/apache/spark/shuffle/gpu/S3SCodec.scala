@@ -23,6 +23,7 @@ import org.apache.spark.SparkException
 object S3SCodec {
   // ---- constants of include/s3shuffle_codec.h ----------------------------------------------------------------
   val CODEC_NONE = 0; val CODEC_LZ4 = 1; val CODEC_SNAPPY = 2
+  val CODEC_ZSTD = 3 // reduce side only (decompressRange*, decompressedSize); the shipped patch keeps zstd jobs on the JVM, INTEGRATION.md
   val CHECKSUM_NONE = 0; val CHECKSUM_ADLER32 = 1; val CHECKSUM_CRC32 = 2
   val OK = 0; val E_INVALID = -1; val E_CAPACITY = -2; val E_BAD_FRAME = -3; val E_CHECKSUM = -4; val E_HIP = -5
   val OPT_LZ4_BLOCK_SIZE = 1; val OPT_SNAPPY_BLOCK_SIZE = 2
@@ -91,6 +92,13 @@ object S3SCodec {
     }
     h
   })
+
+  /** Number of HIP devices.  `deviceCount` is a native: the library is loaded first (a task's first call into this
+    * object is usually this one — before any context exists). */
+  def devices(): Int = {
+    load(org.apache.spark.shuffle.helper.S3ShuffleDispatcher.get.gpuLibrary)
+    deviceCount()
+  }
 
   /** mapId % nGpu — S3ShuffleDispatcher.getPath shards folder prefixes the same way. */
   def deviceFor(mapId: Long, devices: Int): Int = (mapId % math.max(devices, 1)).toInt
