@@ -145,14 +145,29 @@ JNIEXPORT jint JNICALL FN(decompressRange)(JNIEnv* e, jclass c, jlong h, jint co
 /* ---- batched forms over host buffers: what S3GpuCommitQueue / the prefetcher hand over in ONE call ------------------
  * (s3s_compress_map_outputs_batch / s3s_decompress_ranges_batch pipeline upload, codec and download over the tasks).
  * Object arrays carry one entry per task: direct ByteBuffers and long[] of the same shapes as in the single-task calls. */
+#include <stdarg.h>
 #include <stdlib.h>
+
+/* every per-task array of a batched call has one entry per task (NULL-terminated list; the one optional array of a
+ * call is passed last, so a NULL there just ends the list) */
+static int same_length(JNIEnv* e, jsize n, ...) {
+  va_list ap;
+  va_start(ap, n);
+  int bad = 0;
+  for (jarray a; (a = va_arg(ap, jarray)) != NULL;) bad |= (*e)->GetArrayLength(e, a) != n;
+  va_end(ap);
+  return bad;
+}
 
 JNIEXPORT jint JNICALL FN(compressMapOutputsBatch)(JNIEnv* e, jclass c, jlong h, jint codec, jint algo, jobjectArray src,
                                                    jobjectArray srcOffsets, jobjectArray dst, jlongArray dstCap,
                                                    jobjectArray outIndex, jobjectArray outChecksums, jlongArray outTotal,
                                                    jintArray outStatus) {
   (void)c;
+  if (!src || !srcOffsets || !dst || !dstCap || !outIndex || !outTotal || !outStatus) return S3S_E_INVALID;
   const jsize n = (*e)->GetArrayLength(e, src);
+  if (same_length(e, n, srcOffsets, dst, dstCap, outIndex, outTotal, outStatus, outChecksums, NULL) != 0) return S3S_E_INVALID;
+  if ((*e)->EnsureLocalCapacity(e, 3 * n + 8) != 0) return S3S_E_NOMEM; /* three array references per task stay live over the call */
   s3s_map_task* t = (s3s_map_task*)calloc((size_t)(n > 0 ? n : 1), sizeof *t);
   jlongArray* arrs = (jlongArray*)calloc((size_t)(n > 0 ? n : 1) * 3, sizeof *arrs);
   if (!t || !arrs) {
@@ -175,7 +190,7 @@ JNIEXPORT jint JNICALL FN(compressMapOutputsBatch)(JNIEnv* e, jclass c, jlong h,
     (*e)->DeleteLocalRef(e, sb);
     (*e)->DeleteLocalRef(e, db);
     t[i].src_offsets = (const int64_t*)pin(e, so);
-    t[i].num_partitions = (int32_t)((*e)->GetArrayLength(e, so) - 1);
+    t[i].num_partitions = so ? (int32_t)((*e)->GetArrayLength(e, so) - 1) : -1; /* (a null entry: the library answers S3S_E_INVALID) */
     t[i].dst_capacity = cap[i];
     t[i].out_index = (int64_t*)pin(e, oi);
     t[i].out_checksums = (int64_t*)pin(e, oc);
@@ -204,7 +219,11 @@ JNIEXPORT jint JNICALL FN(decompressRangesBatch)(JNIEnv* e, jclass c, jlong h, j
                                                  jobjectArray dst, jlongArray dstCap, jlongArray outLen,
                                                  jintArray outBadPartition, jintArray outStatus) {
   (void)c;
+  if (!comp || !compLen || !partOffsets || !dst || !dstCap || !outLen || !outBadPartition || !outStatus) return S3S_E_INVALID;
   const jsize n = (*e)->GetArrayLength(e, comp);
+  if (same_length(e, n, compLen, partOffsets, dst, dstCap, outLen, outBadPartition, outStatus, refChecksums, NULL) != 0)
+    return S3S_E_INVALID;
+  if ((*e)->EnsureLocalCapacity(e, 2 * n + 8) != 0) return S3S_E_NOMEM;
   s3s_fetch_range* r = (s3s_fetch_range*)calloc((size_t)(n > 0 ? n : 1), sizeof *r);
   jlongArray* arrs = (jlongArray*)calloc((size_t)(n > 0 ? n : 1) * 2, sizeof *arrs);
   if (!r || !arrs) {
@@ -227,7 +246,7 @@ JNIEXPORT jint JNICALL FN(decompressRangesBatch)(JNIEnv* e, jclass c, jlong h, j
     r[i].comp_len = cl[i];
     r[i].part_offsets = (const int64_t*)pin(e, po);
     r[i].ref_checksums = (const int64_t*)pin(e, rs);
-    r[i].num_partitions = (int32_t)((*e)->GetArrayLength(e, po) - 1);
+    r[i].num_partitions = po ? (int32_t)((*e)->GetArrayLength(e, po) - 1) : -1;
     r[i].dst_capacity = cap[i];
   }
   const int rc = s3s_decompress_ranges_batch(CTX(h), codec, algo, r, (int32_t)n);

@@ -29,5 +29,6 @@ struct JNINativeInterface_ {
   jsize (*GetArrayLength)(JNIEnv*, jarray);
   jobject (*GetObjectArrayElement)(JNIEnv*, jobjectArray, jsize);
   void (*DeleteLocalRef)(JNIEnv*, jobject);
+  jint (*EnsureLocalCapacity)(JNIEnv*, jint);
 };
 #endif
