@@ -756,7 +756,8 @@ ZS_HD int decode_frame(Work& w, const uint8_t* src, int64_t size, uint8_t* dst, 
               r.cache = (uint64_t)ZS_UNI32((uint32_t)r.cache) | ((uint64_t)ZS_UNI32((uint32_t)(r.cache >> 32)) << 32);
 #endif
             }
-            uint64_t bits = r.cache >> (r.pos - nb - r.cbase);  // the nb bits of this sequence, first field on top
+            const int sh = r.pos - nb - r.cbase;  // 0 .. 64 (64 only when nb == 0 and the cursor sits on the cache's top bit)
+            uint64_t bits = sh < 64 ? r.cache >> sh : 0;  // the nb bits of this sequence, first field on top
             int rem = nb;
             auto take = [&](int n) -> uint32_t {
               rem -= n;

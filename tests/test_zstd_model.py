@@ -133,3 +133,21 @@ def test_mutated_streams_behave_like_libzstd(model):
                     # whatever it holds); the product is strict there and reports a corrupt stream
                     strict += 1
     assert agree_fail > 300 and agree_ok > 200 and strict < 0.05 * (agree_ok + strict + 1)
+
+
+@pytest.mark.parametrize("flags", [(), ("-DZS_SEQ_FASTBITS",)], ids=["shipped", "fastbits"])
+def test_mutated_streams_never_leave_their_buffers_under_asan(flags):
+    """the same core under ASan / UBSan, compressed stream and destination in heap blocks of exactly their sizes
+    (tests/model/zstd_asan_fuzz.cpp): 20 000 mutations of libzstd streams — bit flips, truncations, splices, inserted /
+    deleted runs, destinations that are too small — and not one access outside a buffer.  (Reads outside the source are
+    invisible to the guard-byte checks above; on the GPU they would be a memory fault of the executor's process.)
+    Longer campaigns: tests/tools/zstd_asan_fuzz.py."""
+    import sys
+
+    sys.path.insert(0, os.path.join(HERE, "tools"))
+    import zstd_asan_fuzz as zf
+
+    r = zf.run(seed=21, seconds=120, flags=flags, max_mutations=20000)
+    assert r.returncode == 0 and "20000 mutations" in r.stdout, (r.stdout, r.stderr[-3000:])
+    refused, decoded = (int(r.stdout.split(w)[0].split()[-1]) for w in (" refused", " decoded"))
+    assert refused > 5000 and decoded > 500
