@@ -257,6 +257,7 @@ void S3ShuffleMapOutputWriter::write(const void* bytes, size_t len) {
     stage_ = bigger;
     stageCap_ = cap;
   }
+  if (len == 0) return;  // (write(b, off, 0) is legal and `bytes` may then be null)
   memcpy(stage_ + stageLen_, bytes, len);
   stageLen_ += (int64_t)len;
 }
