@@ -16,11 +16,17 @@ import lz4_kernel as lk  # noqa: E402
 _PROGS = {}
 
 
-def program(fmt, flags=()):
-    key = (fmt, tuple(flags))
+def program(fmt, flags=(), kernel="batch"):
+    """kernel: "batch" = batch_decode_kernel<fmt> (the default decoder), "ring" = the ring decoders (decode variant 3, and
+    what LZ4 frames above 32 KiB fall back to): lz4_decompress_valu_kernel / snappy_decompress_valu_kernel."""
+    key = (fmt, tuple(flags), kernel)
     if key not in _PROGS:
-        text = lk.compile_asm("lz4_decode_batch.hip", flags=flags)
-        entry = lk.find_kernel(text, "batch_decode_kernelILi%dE" % fmt)
+        if kernel == "batch":
+            text = lk.compile_asm("lz4_decode_batch.hip", flags=flags)
+            entry = lk.find_kernel(text, "batch_decode_kernelILi%dE" % fmt)
+        else:
+            text = lk.compile_asm("lz4_decompress.hip" if fmt == 0 else "snappy_decompress.hip", flags=flags)
+            entry = lk.find_kernel(text, "lz4_decompress_valu_kernel" if fmt == 0 else "snappy_decompress_valu_kernel")
         lds = 0
         for line in text.splitlines():  # the kernel's LDS size from its descriptor block
             if ".amdhsa_group_segment_fixed_size" in line:
@@ -29,13 +35,14 @@ def program(fmt, flags=()):
     return _PROGS[key]
 
 
-def decode_blocks(blocks, fmt=0, methods=None, profile=None, flags=(), grid=None):
+def decode_blocks(blocks, fmt=0, methods=None, profile=None, flags=(), grid=None, kernel="batch", checks=None):
     """blocks: list of (payload bytes, decoded length).  fmt 0 = LZ4 block payloads, 1 = raw Snappy blocks.
     Returns (list of decoded bytes, status word, waves).  flags: extra -D macros of an experiment build; with
     -DS3S_DEC_PERSIST the kernel takes a frame counter as its last argument and `grid` wavefronts draw frames from it
     (the interpreter runs them one after the other, so the first one decodes every frame through ONE window buffer
-    and the others find the counter exhausted)."""
-    prog, entry, text, lds = program(fmt, flags)
+    and the others find the counter exhausted).  checks: the frames' LZ4Block check fields (the LZ4 ring kernel verifies
+    xxHash32 itself; the batch decoder leaves that to lz4_verify_frames_kernel)."""
+    prog, entry, text, lds = program(fmt, flags, kernel)
     mem = emu.Memory()
     comp = b"".join(p for p, _ in blocks)
     frames = bytearray()
@@ -43,12 +50,17 @@ def decode_blocks(blocks, fmt=0, methods=None, profile=None, flags=(), grid=None
     co = oo = 0
     for k, (p, olen) in enumerate(blocks):
         method = (methods[k] if methods else (0x20 if fmt == 0 else 1))
-        frames += struct.pack("<qiiIi", co, len(p), olen, 0, method)
+        frames += struct.pack("<qiiIi", co, len(p), olen, checks[k] if checks else 0, method)
         outs.append(oo)
         co += len(p)
         oo += olen
     dst = np.zeros(max(oo, 1), dtype=np.uint8)
     status = np.zeros(4, dtype=np.int32)
+    if kernel == "ring":
+        # the ring decoders read the stream in ALIGNED dwords, clamped to the last dword that holds a stream byte: the word
+        # around the buffer's last byte is touched as a whole (never a byte outside it — an allocation is a multiple of 4).
+        # The filler is not zero, so a decoder that USED those bytes would decode wrongly.
+        comp = comp + b"\xEE" * (-len(comp) % 4)
     a_comp = mem.map(np.frombuffer(bytearray(comp) or bytearray(1), dtype=np.uint8), "comp", writable=False)
     a_frames = mem.map(np.frombuffer(frames, dtype=np.uint8), "frames", writable=False)
     a_fout = mem.map(np.array(outs + [oo], dtype=np.int64), "frame_out", writable=False)

@@ -282,6 +282,58 @@ def test_persistent_grid_decoder_build_is_the_same_decoder(oracle):
     assert st == -3 and res[:2] == [c.tobytes() for c in chunks[:2]] and res[3:] == [c.tobytes() for c in chunks[2:4]]
 
 
+def test_compiled_ring_decoders(oracle):
+    """the ring decoders (lz4_decompress_valu_kernel / snappy_decompress_valu_kernel: decode variant 3, and where LZ4 frames
+    above 32 KiB go) as hipcc compiles them, payload buffer and destination of exactly their sizes (the payload rounded up to
+    the dword its last byte sits in: these kernels read aligned dwords): oracle-compressed corpora, chained / periodic sources,
+    a 100 000-byte frame of a foreign writer (far matches beyond the LDS ring), a wrong frame check, malformed blocks"""
+    import decode_kernel as dk
+    import framing
+    import test_batch_decode_model as tm
+    import xxhash
+
+    def chk(b):
+        return xxhash.xxh32(bytes(b), seed=0x9747B28C).intdigest() & 0x0FFFFFFF
+
+    rng = np.random.default_rng(45)
+    chunks = [corpus.chunk_corpus(k, n, rng) for k, n in [(7, 20000), (6, 9000), (3, 5000), (1, 4000), (2, 32768), (7, 13)]]
+    blocks = [(bytes(oracle.lz4_compress_block(c)), len(c)) for c in chunks]
+    res, st, _ = dk.decode_blocks(blocks, fmt=0, kernel="ring", checks=[chk(c) for c in chunks])
+    assert st == 0 and res == [c.tobytes() for c in chunks]
+    sblocks = [(bytes(oracle.snappy_compress_block(c)), len(c)) for c in chunks]
+    res, st, _ = dk.decode_blocks(sblocks, fmt=1, kernel="ring")
+    assert st == 0 and res == [c.tobytes() for c in chunks]
+    # a frame above 32 KiB (lz4.blockSize = 128k on the writer): TeraSort-like records match far behind the ring
+    from s3shuffle import datagen
+
+    big = datagen.terasort_map_output(100_000, 1, seed=5)[0]
+    blk = framing.lz4_hc(big, 9)
+    res, st, _ = dk.decode_blocks([(blk, big.size)], fmt=0, kernel="ring", checks=[chk(big)])
+    assert st == 0 and res[0] == big.tobytes()
+    # chained sources
+    cases = []
+    for _ in range(4):
+        seqs = tm._chain_sequences(rng, int(rng.integers(50, 300)))
+        b = framing.lz4_block([(rng.integers(0, 256, l).astype(np.uint8).tobytes(), o, m) for l, o, m in seqs], b"abcdefg")
+        cases.append((b, framing.lz4_decode_py(b)))
+    res, st, _ = dk.decode_blocks([(b, len(w)) for b, w in cases], fmt=0, kernel="ring", checks=[chk(w) for _, w in cases])
+    assert st == 0 and res == [w for _, w in cases]
+    # the LZ4 ring kernel verifies the frame check itself; malformed payloads end in S3S_E_BAD_FRAME inside the buffers
+    _, st, _ = dk.decode_blocks(blocks[:1], fmt=0, kernel="ring", checks=[chk(chunks[0]) ^ 1])
+    assert st == -3
+    z = b"abcdefgh"
+    good = framing.lz4_block([(z, 8, 40)], z)
+    orig = framing.lz4_decode_py(good)
+    for bad in (framing.lz4_block([(z, 9, 4)], z), framing.lz4_block([(z, 8, 4)], z)[:-3], bytes([0xF0]) + b"\xff" * 40,
+                framing.lz4_block([(z * 4, 8, 30000)], z)):
+        _, st, _ = dk.decode_blocks([(bad, len(orig))], fmt=0, kernel="ring", checks=[chk(orig)])
+        assert st == -3
+    for bad in (framing.snappy_block([("lit", z), ("copy", 9, 4, 2)]), framing.snappy_block([("lit", z * 10)])[:-5],
+                framing.snappy_block([("lit", z), ("copy", 4, 64, 2)] * 3, ulen=100)):
+        _, st, _ = dk.decode_blocks([(bad, _preamble_len(bad))], fmt=1, kernel="ring")
+        assert st == -3
+
+
 def test_compiled_decoder_rejects_malformed_blocks_without_leaving_its_buffers():
     """the payload buffer ends with the block's last byte and the destination has exactly the declared size: any
     access outside either faults in the interpreter (MemFault), whatever the bytes say"""

@@ -1,6 +1,6 @@
 """Fuzz of the COMPILED batch decoder in the gfx950 interpreter (TEST INFRASTRUCTURE).
 
-    python tests/tools/isa_decode_fuzz.py --seed 5 --minutes 20 [--fmt lz4|snappy|both]
+    python tests/tools/isa_decode_fuzz.py --seed 5 --minutes 20 [--fmt lz4|snappy|both] [--kernel batch|ring]
 
 Valid blocks (sequence lists with chained / periodic / literal sources, oracle-compressed corpora) must decode to the
 reference decoder's bytes; mutated blocks must be refused or decode to exactly what the reference decoder produces — and the
@@ -27,11 +27,20 @@ import test_batch_decode_model as tm  # noqa: E402
 from oracle import binding as oracle  # noqa: E402
 
 
+def _check(data):
+    """the LZ4Block frame's check field (the LZ4 ring kernel verifies it; the other kernels ignore the field)"""
+    import xxhash
+
+    return xxhash.xxh32(bytes(data), seed=0x9747B28C).intdigest() & 0x0FFFFFFF
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--minutes", type=float, default=10)
     ap.add_argument("--fmt", default="both")
+    ap.add_argument("--kernel", default="batch", choices=["batch", "ring"],
+                    help="ring = lz4_decompress_valu_kernel / snappy_decompress_valu_kernel (decode variant 3, the fallback for big frames)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     fmts = [0, 1] if args.fmt == "both" else [0 if args.fmt == "lz4" else 1]
@@ -67,7 +76,8 @@ def main():
             if not cases:
                 continue
             try:
-                res, st, _ = dk.decode_blocks([(b, len(w)) for b, w in cases], fmt=fmt)
+                res, st, _ = dk.decode_blocks([(b, len(w)) for b, w in cases], fmt=fmt, kernel=args.kernel,
+                                              checks=[_check(w) for _, w in cases])
                 n_valid += len(cases)
                 if st != 0 or res != [w for _, w in cases]:
                     bad += 1
@@ -84,7 +94,8 @@ def main():
                 if fmt == 1:  # a Snappy block declares its length: the frame record must agree or the kernel refuses
                     pass
                 try:
-                    res, st, _ = dk.decode_blocks([(bytes(p), olen)], fmt=fmt)
+                    res, st, _ = dk.decode_blocks([(bytes(p), olen)], fmt=fmt, kernel=args.kernel,
+                                                  checks=[_check(ref if ref is not None and len(ref) == olen else want)])
                     n_mut += 1
                     if st == 0 and ref is not None and len(ref) == olen and res[0] != ref:
                         bad += 1
