@@ -367,6 +367,77 @@ def test_compiled_decoder_rejects_malformed_blocks_without_leaving_its_buffers()
         assert st == -3
 
 
+# ---- the compiled LZ4Block frame discovery (reduce side) under the interpreter ------------------------------------------------
+def _lz4block_stream(oracle, rng, n_chunks, fake_at=()):
+    """LZ4Block frames of 32 KiB chunks (compressible ones and random ones that are stored RAW), one end mark; `fake_at` = chunk
+    numbers whose RAW payload carries a complete, plausible frame header (what the tile speculation must not believe)"""
+    import framing
+
+    out = bytearray()
+    for i in range(n_chunks):
+        if i % 3 == 0:
+            c = corpus.chunk_corpus(7, 32768, rng).tobytes()
+        else:
+            c = bytearray(rng.integers(0, 256, 32768, dtype=np.uint8).tobytes())
+            if i in fake_at:  # a header that passes every field check and whose chain stays inside the range
+                for at in (5, 9000, 20000):
+                    c[at:at + 21] = b"LZ4Block" + bytes([0x25]) + (700).to_bytes(4, "little") + (900).to_bytes(4, "little") + bytes(4)
+            c = bytes(c)
+        pay = bytes(oracle.lz4_compress_block(np.frombuffer(c, np.uint8)))
+        raw = len(pay) >= len(c)
+        out += framing.lz4_frame(c if raw else pay, c, raw=raw)
+    out += framing.lz4_end_frame()
+    return bytes(out)
+
+
+def test_compiled_frame_discovery(oracle):
+    """tile_speculate -> tile_resolve -> scan -> tile_emit -> scan as hipcc compiles them, every buffer of exactly its size
+    (tests/isa/discover_kernel.py): multi-tile streams, concatenated streams, fake headers inside stored payloads right behind
+    tile boundaries, and every way a range can end early — the answer is LZ4BlockInputStream.refill()'s, frame by frame, or
+    S3S_E_BAD_FRAME, and no access leaves a buffer."""
+    import discover_kernel as dsc
+    import framing
+
+    rng = np.random.default_rng(47)
+    s1 = _lz4block_stream(oracle, rng, 9, fake_at=(1, 2, 4, 5, 7))  # 3.4 tiles; tiles 1..3 start inside chunks 2, 4 / 5, 7
+    s2 = _lz4block_stream(oracle, rng, 2)
+    for stream in (s1, s1 + s2 + s2, framing.lz4_end_frame(), framing.lz4_end_frame() * 3, s2[:21 + 5] and s2):
+        st, recs, outs = dsc.discover(stream)
+        want = dsc.reference_frames(stream)
+        assert want is not None and st == 0 and recs == want
+        assert outs == list(np.concatenate([[0], np.cumsum([r[2] for r in want])]))
+    # a range that ends early: inside the last header, inside a payload, one byte short, inside the magic, at tile boundaries
+    cuts = [len(s1) - k for k in (1, 2, 8, 20, 21, 22, 30, 42, 43)] + [65536 + d for d in (-1, 0, 1, 8, 20, 21)] + [1, 7, 8, 20]
+    for cut in cuts:
+        stream = s1[:cut]
+        st, recs, _ = dsc.discover(stream)
+        want = dsc.reference_frames(stream)
+        if want is None:
+            assert st == -3, cut
+        else:
+            assert st == 0 and recs == want, cut
+    # "LZ4Block" in the last bytes of the range (a header that cannot be complete) and damaged header fields
+    tail = s2 + b"LZ4Block"[: 8]
+    assert dsc.discover(tail)[0] == -3
+    assert dsc.discover(s2 + b"LZ4Block" + bytes(12))[0] == -3
+    for at, val in ((8, 0x35), (8, 0x2F), (9 + 3, 0x7F), (13 + 3, 0x80), (0, 0x4D)):
+        m = bytearray(s1)
+        m[at] = val
+        st, recs, _ = dsc.discover(bytes(m))
+        want = dsc.reference_frames(bytes(m))
+        assert (st == -3) if want is None else (st == 0 and recs == want), (at, val)
+    # random damage: the reference's verdict, never a fault
+    for _ in range(25):
+        m = bytearray(s1 if rng.integers(0, 2) else s2)
+        for _ in range(int(rng.integers(1, 4))):
+            m[int(rng.integers(0, len(m)))] = int(rng.integers(0, 256))
+        if rng.integers(0, 3) == 0:
+            m = m[: int(rng.integers(1, len(m)))]
+        st, recs, _ = dsc.discover(bytes(m))
+        want = dsc.reference_frames(bytes(m))
+        assert (st == -3) if want is None else (st == 0 and recs == want)
+
+
 # ---- the compiled Zstandard decoder (reduce side, zstd only) under the interpreter -------------------------------------
 def test_compiled_zstd_decoder(oracle):
     """zstd_partitions_kernel as hipcc compiles it, both passes of the product (sizes, then decode through the literal
