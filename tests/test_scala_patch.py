@@ -88,3 +88,63 @@ def test_shim_positions_are_long_and_close_is_idempotent():
     dec = _read(SHIM, "S3GpuBlockDecoder.scala")
     assert "compareAndSet(false, true)" in dec
     assert "hostFree" in out_cls  # the pool gives surplus buffers back
+
+
+def _strip_scala(src):
+    """comments, string / char literals and interpolations out of the way (enough of a lexer for a bracket check)"""
+    out, i, n = [], 0, len(src)
+    while i < n:
+        two = src[i:i + 2]
+        if two == "//":
+            i = src.find("\n", i) if src.find("\n", i) >= 0 else n
+        elif two == "/*":
+            depth, i = 1, i + 2  # Scala block comments nest
+            while i < n and depth:
+                if src[i:i + 2] == "/*":
+                    depth, i = depth + 1, i + 2
+                elif src[i:i + 2] == "*/":
+                    depth, i = depth - 1, i + 2
+                else:
+                    i += 1
+        elif src[i:i + 3] == '"""':
+            i = src.find('"""', i + 3) + 3
+        elif src[i] == '"':
+            i += 1
+            while i < n and src[i] != '"':
+                i += 2 if src[i] == "\\" else 1
+            i += 1
+        elif src[i] == "'" and i + 2 < n and (src[i + 2] == "'" or (src[i + 1] == "\\" and src[i + 3] == "'")):
+            i += 3 if src[i + 2] == "'" else 4
+        else:
+            out.append(src[i])
+            i += 1
+    return "".join(out)
+
+
+def _brackets_balance(src):
+    stack, pairs = [], {")": "(", "]": "[", "}": "{"}
+    for ln, line in enumerate(_strip_scala(src).splitlines(), 1):
+        for ch in line:
+            if ch in "([{":
+                stack.append((ch, ln))
+            elif ch in pairs:
+                if not stack or stack[-1][0] != pairs[ch]:
+                    return "unexpected %r in line %d (open: %r)" % (ch, ln, stack[-1:] or None)
+                stack.pop()
+    return "unclosed %r" % stack[-1:] if stack else None
+
+
+def test_scala_sources_are_structurally_sound(patched_tree):
+    """no scalac here: at least every bracket of the shim sources and of the four PATCHED reference files closes where it
+    should (comments and string literals lexed away) — an edit that drops a brace does not survive the CPU suite"""
+    files = [os.path.join(SHIM, f) for f in sorted(os.listdir(SHIM)) if f.endswith(".scala")]
+    assert len(files) == 4
+    base = os.path.join(patched_tree, "src", "main", "scala", "org", "apache", "spark")
+    files += [os.path.join(base, "shuffle", "S3ShuffleMapOutputWriter.scala"),
+              os.path.join(base, "shuffle", "S3SingleSpillShuffleMapOutputWriter.scala"),
+              os.path.join(base, "shuffle", "helper", "S3ShuffleDispatcher.scala"),
+              os.path.join(base, "storage", "S3ShuffleReader.scala")]
+    for f in files:
+        assert _brackets_balance(_read(f)) is None, (f, _brackets_balance(_read(f)))
+    assert _brackets_balance("object A { def f(x: Int) = { x + 1 }") is not None  # (the check sees a dropped brace)
+    assert _brackets_balance('object A { val s = "}" /* } */ }') is None
