@@ -74,6 +74,33 @@ def test_rolling_prefetch_build_is_the_same_compressor(oracle):
     assert not asm_viol and not cc_viol, (asm_viol[:3], cc_viol[:3])
 
 
+def test_issue_priority_build_is_the_same_compressor(oracle):
+    """-DS3S_X_SETPRIO (kept for the next round's measurement: raised issue priority from the window's entry to its candidate
+    gather): same bytes, wait states intact, and the priority is back to 0 wherever the block is left"""
+    import hazards
+    import lz4_kernel as lk
+
+    rng = np.random.default_rng(9)
+    chunks = [corpus.chunk_corpus(7, 32768, rng), corpus.chunk_corpus(6, 9000, rng), corpus.chunk_corpus(3, 20000, rng)]
+    out = lk.compress_chunks(chunks, windows=True, flags=("-DS3S_X_SETPRIO",))
+    for c, (payload, _, _) in zip(chunks, out):
+        ref = bytes(oracle.lz4_compress_block(c))
+        assert (payload is None and len(ref) >= len(c)) or bytes(payload) == ref
+    text = lk.compile_asm("lz4_compress.hip", ("-DS3S_X_SETPRIO",))
+    entry = lk.find_kernel(text, "lz4_compress_l2_kernelILb1E")
+    asm_viol, cc_viol, _, _ = hazards.check_kernel(text, entry)
+    assert not asm_viol and not cc_viol, (asm_viol[:3], cc_viol[:3])
+    # between a raise and the next lowering there is no branch and no label: straight-line code
+    lines = [ln.split(";")[0].strip() for ln in text.splitlines()]
+    raised = 0
+    for ln in lines:
+        if ln.startswith("s_setprio"):
+            raised = int(ln.split()[1]) > 0
+        elif raised:
+            assert not ln.startswith(("s_branch", "s_cbranch", "s_endpgm", "s_setpc")) and not ln.endswith(":"), ln
+    assert sum(ln.startswith("s_setprio 2") for ln in lines) == 3 and not raised  # (three copies of the window body)
+
+
 def test_lds_race_winner_is_irrelevant(oracle):
     """same-address LDS stores of one instruction: any lane may win (tests/model proves it; here on the real code)"""
     rng = np.random.default_rng(22)

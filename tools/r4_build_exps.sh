@@ -4,6 +4,7 @@
 # (tests/test_isa_kernels.py: rolling_prefetch, persistent_grid_decoder; tests/test_zstd_model.py for the zstd macro).
 #   rollpf    -DS3S_X_ROLL_PREFETCH     LZ4 compressor: rolling prefetch through spare lanes of the stream load
 #   storent   -DS3S_X_STORE_NT          LZ4 compressor: non-temporal sequence stores (was +-0 before the block prefetch)
+#   setprio   -DS3S_X_SETPRIO          LZ4 compressor: raised issue priority from a window's entry to its candidate gather
 #   decpers   -DS3S_DEC_PERSIST         batch decoder as a persistent grid (S3S_DEC_GRID wavefronts, default 26 per CU)
 #   zsfast    -DZS_SEQ_FASTBITS         zstd decoder: one 64-bit bit window per sequence
 set -e
@@ -12,6 +13,7 @@ make exp EXPNAME=rollpf EXPFLAGS=-DS3S_X_ROLL_PREFETCH &
 make exp EXPNAME=storent EXPFLAGS=-DS3S_X_STORE_NT &
 wait
 make exp EXPNAME=decpers EXPFLAGS=-DS3S_DEC_PERSIST &
+make exp EXPNAME=setprio EXPFLAGS=-DS3S_X_SETPRIO &
 make exp EXPNAME=zsfast EXPFLAGS=-DZS_SEQ_FASTBITS &
 wait
 ls -la ../lib/

@@ -9,10 +9,11 @@ O=gpurun_out/$tag; mkdir -p $O
 L=$R/spark-s3-shuffle_amd/lib
 head1() { timeout 90 python bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 5 "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['roofline'].get('avg_launch_ms'))" || echo FAILED; }
 {
-echo "== compress headline (GB/s, ms per launch): shipped / rollpf / storent / grid 1536 / shipped"
+echo "== compress headline (GB/s, ms per launch): shipped / rollpf / storent / setprio / grid 1536 / shipped"
 unset S3S_CODEC_LIB;                                   echo "shipped  $(head1)"
 export S3S_CODEC_LIB=$L/libs3shuffle_codec_exp_rollpf.so;  echo "rollpf   $(head1 --verify)"
 export S3S_CODEC_LIB=$L/libs3shuffle_codec_exp_storent.so; echo "storent  $(head1 --verify)"
+export S3S_CODEC_LIB=$L/libs3shuffle_codec_exp_setprio.so; echo "setprio  $(head1 --verify)"
 unset S3S_CODEC_LIB; echo "grid1536 $(S3S_LZ4_GRID=1536 head1)"
 echo "shipped  $(head1)"
 echo "== wide rows LZ4: shipped / rollpf"
