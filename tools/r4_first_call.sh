@@ -14,6 +14,8 @@ unset S3S_CODEC_LIB;                                   echo "shipped  $(head1)"
 export S3S_CODEC_LIB=$L/libs3shuffle_codec_exp_rollpf.so;  echo "rollpf   $(head1 --verify)"
 export S3S_CODEC_LIB=$L/libs3shuffle_codec_exp_storent.so; echo "storent  $(head1 --verify)"
 export S3S_CODEC_LIB=$L/libs3shuffle_codec_exp_setprio.so; echo "setprio  $(head1 --verify)"
+export S3S_CODEC_LIB=$L/libs3shuffle_codec_exp_rollpf6k.so; echo "rollpf6k $(head1 --verify)"
+export S3S_CODEC_LIB=$L/libs3shuffle_codec_exp_rollpfprio.so; echo "rollpf+prio $(head1 --verify)"
 unset S3S_CODEC_LIB; echo "grid1536 $(S3S_LZ4_GRID=1536 head1)"
 echo "shipped  $(head1)"
 echo "== wide rows LZ4: shipped / rollpf"
