@@ -507,6 +507,9 @@ V2 = {  # name -> f(src0, src1) on uint32 arrays
     "v_mul_lo_u32": lambda a, b: (a.astype(np.uint64) * b.astype(np.uint64)).astype(np.uint32),
     "v_mul_hi_u32": lambda a, b: ((a.astype(np.uint64) * b.astype(np.uint64)) >> np.uint64(32)).astype(np.uint32),
     "v_mul_u32_u24": lambda a, b: ((a & np.uint32(0xFFFFFF)).astype(np.uint64) * (b & np.uint32(0xFFFFFF)).astype(np.uint64)).astype(np.uint32),
+    "v_mul_i32_i24": lambda a, b: (_sx24(a) * _sx24(b)).astype(np.uint64).astype(np.uint32),
+    "v_mul_hi_i32_i24": lambda a, b: ((_sx24(a) * _sx24(b)) >> np.int64(32)).astype(np.uint64).astype(np.uint32),
+    "v_mul_hi_u32_u24": lambda a, b: (((a & np.uint32(0xFFFFFF)).astype(np.uint64) * (b & np.uint32(0xFFFFFF)).astype(np.uint64)) >> np.uint64(32)).astype(np.uint32),
     "v_lshlrev_b16": lambda a, b: (b << (a & np.uint32(15))) & np.uint32(0xFFFF),
     "v_lshrrev_b16": lambda a, b: (b & np.uint32(0xFFFF)) >> (a & np.uint32(15)),
     "v_add_u16": lambda a, b: (a + b) & np.uint32(0xFFFF),
@@ -515,6 +518,12 @@ V2 = {  # name -> f(src0, src1) on uint32 arrays
     "v_or_b16": lambda a, b: (a | b) & np.uint32(0xFFFF),
     "v_bcnt_u32_b32": lambda a, b: np.array([bin(int(x)).count("1") for x in a], dtype=np.uint32) + b,
 }
+
+
+def _sx24(a):
+    """low 24 bits, sign-extended, as int64"""
+    v = (a & np.uint32(0xFFFFFF)).astype(np.int64)
+    return np.where(v & 0x800000, v - 0x1000000, v)
 
 
 def _ffbl(a):
@@ -1254,7 +1263,10 @@ class Program:
         pass
 
     x_s_waitcnt = x_s_nop
-    x_s_barrier = x_s_nop
+    def x_s_barrier(self, w, i):
+        if getattr(w, "multi_wave_group", False):
+            raise EmuError("s_barrier in a multi-wavefront workgroup: the interpreter runs its wavefronts one after the other")
+
     x_s_sleep = x_s_nop
     x_s_setprio = x_s_nop
     x_s_waitcnt_vscnt = x_s_nop
@@ -1474,6 +1486,21 @@ class Program:
             old = w.mem.load(addrs, one, 4).view("<u4")[lane, 0]
             new = np.zeros((64, 4), dtype=np.uint8)
             new[lane] = np.array([(int(old) + int(w.v[vdata[1]][lane])) & 0xFFFFFFFF], dtype="<u4").view(np.uint8)
+            w.mem.store(addrs, one, new)
+            if ret:
+                w.v[i.ops[0][1]][lane] = old
+
+    def x_global_atomic_xor(self, w, i):
+        # global_atomic_xor [vdst,] vaddr, vdata, saddr — as x_global_atomic_add
+        ret = len(i.ops) == 4
+        vaddr, vdata, saddr = (i.ops[1], i.ops[2], i.ops[3]) if ret else (i.ops[0], i.ops[1], i.ops[2])
+        addrs = self._gaddr(w, i, vaddr, saddr)
+        for lane in np.flatnonzero(w.em()):
+            one = np.zeros(64, dtype=bool)
+            one[lane] = True
+            old = w.mem.load(addrs, one, 4).view("<u4")[lane, 0]
+            new = np.zeros((64, 4), dtype=np.uint8)
+            new[lane] = np.array([(int(old) ^ int(w.v[vdata[1]][lane])) & 0xFFFFFFFF], dtype="<u4").view(np.uint8)
             w.mem.store(addrs, one, new)
             if ret:
                 w.v[i.ops[0][1]][lane] = old
@@ -1729,20 +1756,24 @@ def launch(prog, entry, mem, kernarg, grid_x, lds_bytes, user_sgprs=2, block_x=6
            on_wave=None, hooks=None, objects=None):
     """One 64-thread workgroup per block id (the kernels here use single-wave workgroups).  ABI as hipcc emits it
     for these kernels: s[0:1] = kernarg segment, s2 = workgroup id x, v0 = thread id x."""
-    if block_x != 64:
-        raise EmuError("only single-wave workgroups are modelled")
+    if block_x % 64 != 0:
+        raise EmuError("workgroups are whole wavefronts")
+    # block_x > 64: the workgroup's wavefronts run one after the other, each with its own LDS image — only right for kernels
+    # whose wavefronts do not talk to each other (no s_barrier, no shared LDS): run_wave refuses s_barrier then
     kbase = mem.map(np.frombuffer(bytearray(kernarg), dtype=np.uint8), "kernarg", writable=False)
     symbols = {name: mem.map(np.frombuffer(bytearray(data), dtype=np.uint8), name, writable=False)
                for name, data in (objects or {}).items()}
     stats = []
     for bx in (grid_x if not isinstance(grid_x, int) else range(grid_x)):
-        w = new_wave(mem, lds_bytes, lds_order)
-        w.symbols = symbols
-        w.s[0], w.s[1] = kbase & M32, kbase >> 32
-        w.s[user_sgprs] = bx
-        w.v[0] = np.arange(64, dtype=np.uint32)
-        run_wave(prog, w, entry, profile=profile, hooks=hooks)
-        stats.append(w)
-        if on_wave:
-            on_wave(bx, w)
+        for wv in range(block_x // 64):
+            w = new_wave(mem, lds_bytes, lds_order)
+            w.symbols = symbols
+            w.multi_wave_group = block_x > 64
+            w.s[0], w.s[1] = kbase & M32, kbase >> 32
+            w.s[user_sgprs] = bx
+            w.v[0] = np.arange(64, dtype=np.uint32) + np.uint32(64 * wv)  # work-item id x (y = z = 0 in the packed register)
+            run_wave(prog, w, entry, profile=profile, hooks=hooks)
+            stats.append(w)
+            if on_wave:
+                on_wave(bx, w)
     return stats

@@ -394,6 +394,35 @@ def test_compiled_decoder_rejects_malformed_blocks_without_leaving_its_buffers()
         assert st == -3
 
 
+# ---- the compiled checksum kernels under the interpreter ----------------------------------------------------------------------
+@pytest.mark.parametrize("algo", [1, 2], ids=["adler32", "crc32"])
+def test_compiled_checksum_kernels(algo):
+    """checksum_segments_kernel (256-thread workgroups, four wavefronts that do not talk to each other) + checksum_combine_kernel
+    as hipcc compiles them, against zlib: ragged ranges at every alignment, empty ranges, ranges of several 16 KiB segments,
+    one-byte ranges — the data buffer ends with its last byte.  And the capacity-overflow rule: offsets that point behind
+    `data_len` are not followed (tests/isa/checksum_kernel.py maps exactly data_len bytes)."""
+    import zlib
+
+    import checksum_kernel as ck
+
+    f = zlib.adler32 if algo == 1 else zlib.crc32
+    rng = np.random.default_rng(50 + algo)
+    data = rng.integers(0, 256, 120_000, dtype=np.uint8).tobytes()
+    cuts = sorted({0, 0, 1, 2, 63, 64, 65, 127, 4096, 16383, 16384, 16385, 16384 * 3 + 7, 70_001, 70_001, 119_999, 120_000})
+    offs = [0] + cuts + [120_000]
+    assert ck.checksum_ranges(algo, data, offs) == [f(data[a:b]) for a, b in zip(offs, offs[1:])]
+    offs = sorted(int(x) for x in rng.integers(0, 120_001, 40)) + [120_000]
+    offs = [0] + offs
+    assert ck.checksum_ranges(algo, data, offs) == [f(data[a:b]) for a, b in zip(offs, offs[1:])]
+    zeros = bytes(40_000)  # Adler32's worst case for the modulus is 0xff bytes, CRC's for leading zeros is zeros
+    assert ck.checksum_ranges(algo, zeros, [0, 40_000]) == [f(zeros)]
+    ff = b"\xff" * 100_000
+    assert ck.checksum_ranges(algo, ff, [0, 100_000]) == [f(ff)]
+    # offsets computed on the device after a capacity overflow exceed the caller's buffer: those ranges are skipped, not read
+    got = ck.checksum_ranges(algo, data[:50_000], [0, 20_000, 50_000, 90_000, 120_000], data_len=50_000)
+    assert got[:2] == [f(data[:20_000]), f(data[20_000:50_000])]
+
+
 # ---- the compiled LZ4Block frame discovery (reduce side) under the interpreter ------------------------------------------------
 def _lz4block_stream(oracle, rng, n_chunks, fake_at=()):
     """LZ4Block frames of 32 KiB chunks (compressible ones and random ones that are stored RAW), one end mark; `fake_at` = chunk
