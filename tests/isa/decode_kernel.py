@@ -77,3 +77,32 @@ def decode_blocks(blocks, fmt=0, methods=None, profile=None, flags=(), grid=None
     if "-DS3S_DEC_PERSIST" in flags:
         assert int(work[0]) == len(blocks) + (grid or len(blocks)), "every wavefront leaves through the counter"
     return res, int(status[0]), waves
+
+
+def decode_range(comp: bytes, recs, outs, verify=True):
+    """The decode launches of one fetched range: `recs` / `outs` = the frame records and output offsets the compiled frame
+    discovery produced (tests/isa/discover_kernel.py), batch_decode_kernel<LZ4> over them, then lz4_verify_frames_kernel
+    (xxHash32 of every decoded block against the frame's check field).  Buffers of exactly their sizes.
+    -> (status, decoded bytes)"""
+    prog, entry, text, lds = program(0)
+    n = len(recs)
+    total = outs[-1]
+    mem = emu.Memory()
+    frames = bytearray()
+    for r in recs:
+        frames += struct.pack("<qiiIi", *r)
+    dst = np.zeros(max(total, 1), dtype=np.uint8)[:total]
+    status = np.zeros(4, dtype=np.int32)
+    a_comp = mem.map(np.frombuffer(bytearray(comp), dtype=np.uint8), "comp", writable=False)
+    a_frames = mem.map(np.frombuffer(frames or bytearray(24), dtype=np.uint8), "frames", writable=False)
+    a_fout = mem.map(np.array(outs, dtype=np.int64), "frame_out", writable=False)
+    a_dst = mem.map(dst if total else np.zeros(1, np.uint8), "dst")
+    a_status = mem.map(status, "status")
+    objs = {k: v for k, v in emu.parse_objects(text).items() if k.startswith("_ZN3s3s")}
+    if n:
+        emu.launch(prog, entry, mem, struct.pack("<QQiiQQQ", a_comp, a_frames, n, 0, a_fout, a_dst, a_status), n, lds, objects=objs)
+        if verify:
+            ventry = lk.find_kernel(text, "lz4_verify_frames_kernel")
+            emu.launch(emu.Program(text, ventry), ventry, mem, struct.pack("<QiiQQQ", a_frames, n, 0, a_fout, a_dst, a_status),
+                       (n + 15) // 16, lds, objects=objs)
+    return int(status[0]), dst.tobytes()

@@ -1,0 +1,91 @@
+"""One whole map-side call (LZ4 + checksum) through the compiled kernels on the CPU (TEST INFRASTRUCTURE): the launches of
+compress_core in csrc/codec_api.hip in their order —
+
+    xxh32_items_wave_kernel   (frame checks)          csrc/lz4_compress.hip
+    lz4_compress_l2_kernel    (blocks + end frames)   csrc/lz4_compress.hip   (persistent grid: one wavefront draws every item)
+    scan_items_kernel         (item offsets + index)  csrc/assemble.hip
+    gather_items_kernel       (.data image)           csrc/assemble.hip       (256-thread workgroups)
+    checksum_segments / checksum_combine              csrc/checksum.hip       (tests/isa/checksum_kernel.py)
+
+with the item plan built the way the host code builds it.  Every buffer has exactly its size: the source ends with the last
+partition's last byte, the destination has exactly the image's size (dst_capacity = that), the slot / item arrays exactly
+n_chunks / n_items entries."""
+import os
+import struct
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import checksum_kernel as ck  # noqa: E402
+import gfx950_emu as emu  # noqa: E402
+import lz4_kernel as lk  # noqa: E402
+
+BLOCK = 32768
+LEVEL = 5  # log2(32 KiB) - 10
+SEED = 0x9747B28C
+_P = {}
+
+
+def _prog(src, needle):
+    if src not in _P:
+        text = lk.compile_asm(src)
+        _P[src] = (text, {k: v for k, v in emu.parse_objects(text).items() if k.startswith("_ZN3s3s")})
+    if (src, needle) not in _P:
+        entry = lk.find_kernel(_P[src][0], needle)
+        _P[(src, needle)] = (emu.Program(_P[src][0], entry), entry)
+    return _P[(src, needle)] + (_P[src][1],)
+
+
+def compress_map_output(parts, algo, dst_bytes):
+    """parts: list of bytes (one per partition, may be empty); dst_bytes: size of the destination (= dst_capacity).
+    -> (status, image bytes, index list [n + 1], checksums list [n] or None)"""
+    n = len(parts)
+    src = np.frombuffer(b"".join(parts), dtype=np.uint8)
+    items = bytearray()
+    part_first = []
+    off = ch = 0
+    for p, b in enumerate(parts):
+        part_first.append(len(items) // 24)
+        for pos in range(0, len(b), BLOCK):
+            items += struct.pack("<qiiii", off + pos, min(BLOCK, len(b) - pos), 0 | (LEVEL << 8), ch, p)
+            ch += 1
+        if b:
+            items += struct.pack("<qiiii", 0, 0, 1 | (LEVEL << 8), -1, p)
+        off += len(b)
+    n_items = len(items) // 24
+    part_first.append(n_items)
+    mem = emu.Memory()
+    a_src = mem.map(src.copy() if src.size else np.zeros(1, np.uint8), "src", writable=False)
+    a_items = mem.map(np.frombuffer(items or bytearray(24), dtype=np.uint8), "items", writable=False)
+    check = np.zeros(max(n_items, 1), np.uint32)
+    size = np.zeros(max(n_items, 1), np.uint32)
+    item_off = np.full(n_items + 1, -7, np.int64)
+    index = np.full(n + 1, -7, np.int64)
+    slots = np.zeros(max(ch, 1) * lk.K_SLOT_BYTES, np.uint8)
+    work = np.zeros(1, np.uint32)
+    status = np.zeros(1, np.int32)
+    dst = np.full(max(dst_bytes, 1), 0xA5, np.uint8)[:dst_bytes]
+    a_check, a_size, a_off, a_index = mem.map(check, "item_check"), mem.map(size, "item_size"), mem.map(item_off, "item_off"), mem.map(index, "index")
+    a_slots, a_work, a_status = mem.map(slots, "slots"), mem.map(work, "work"), mem.map(status, "status")
+    a_pf = mem.map(np.array(part_first, np.int32), "part_first", writable=False)
+    a_dst = mem.map(dst if dst_bytes else np.zeros(1, np.uint8), "dst")
+    if n_items:
+        prog, entry, objs = _prog("lz4_compress.hip", "xxh32_items_wave_kernel")
+        emu.launch(prog, entry, mem, struct.pack("<QQiIQ", a_src, a_items, n_items, SEED, a_check), n_items, 0, objects=objs)
+        prog, entry, objs = _prog("lz4_compress.hip", "lz4_compress_l2_kernelILb1E")
+        emu.launch(prog, entry, mem, struct.pack("<QQiiQQQQ", a_src, a_items, n_items, 0, a_check, a_slots, a_size, a_work), 1, 16384,
+                   objects=objs)
+        assert int(work[0]) == n_items + 1
+    prog, entry, objs = _prog("assemble.hip", "scan_items_kernel")
+    emu.launch(prog, entry, mem, struct.pack("<QiiQQiiQ", a_size, n_items, 0, a_off, a_pf, n, 0, a_index), 1, 0, objects=objs)
+    if n_items:
+        prog, entry, objs = _prog("assemble.hip", "gather_items_kernel")
+        emu.launch(prog, entry, mem, struct.pack("<QQiiQqQQQqQ", a_src, a_items, n_items, 0, a_slots, lk.K_SLOT_BYTES, a_size, a_off,
+                                                 a_dst, dst_bytes, a_status), n_items, 0, block_x=256, objects=objs)
+    idx = [int(x) for x in index]
+    sums = None
+    if algo and int(status[0]) == 0:
+        sums = ck.checksum_ranges(algo, dst.tobytes(), idx, data_len=dst_bytes)
+    return int(status[0]), dst.tobytes(), idx, sums

@@ -394,6 +394,67 @@ def test_compiled_decoder_rejects_malformed_blocks_without_leaving_its_buffers()
         assert st == -3
 
 
+# ---- one whole map-side call through the compiled kernels ------------------------------------------------------------------
+def test_whole_map_side_call_through_the_compiled_kernels(oracle):
+    """tests/isa/map_side.py: frame-check pre-pass, LZ4 blocks and end frames (persistent grid), item scan, gather into the
+    .data image, per-partition checksums — the kernels of compress_core in its order, the item plan built like the host code
+    builds it, every buffer of exactly its size.  Image, index and checksums equal the oracle's; a destination that is one
+    byte short is S3S_E_CAPACITY and nothing is written behind it (the buffer ends there)."""
+    import map_side as ms
+
+    rng = np.random.default_rng(52)
+    parts = [corpus.chunk_corpus(7, 70_000, rng).tobytes(), b"", corpus.chunk_corpus(3, 5, rng).tobytes(),
+             rng.integers(0, 256, 33_000, dtype=np.uint8).tobytes(),  # incompressible: RAW frames, payload gathered from the source
+             corpus.chunk_corpus(6, 9000, rng).tobytes(), b"", corpus.chunk_corpus(2, 32768, rng).tobytes()]
+    data = np.frombuffer(b"".join(parts), np.uint8)
+    offs = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int64)
+    for algo in (1, 2):
+        img, idx, sums = oracle.compress_map_output(1, algo, data, offs)
+        st, got, gi, gs = ms.compress_map_output(parts, algo, img.size)
+        assert st == 0 and got == img.tobytes() and gi == list(idx) and gs == [int(x) for x in sums]
+    st, got, gi, _ = ms.compress_map_output(parts, 0, img.size - 1)
+    assert st == -2 and gi == list(idx)  # (the index says what it would have taken)
+    st, got, gi, gs = ms.compress_map_output([b"", b"", b""], 1, 0)
+    assert st == 0 and gi == [0, 0, 0, 0] and gs == [1, 1, 1]
+    one = [bytes([7])]
+    img, idx, sums = oracle.compress_map_output(1, 1, np.frombuffer(one[0], np.uint8), np.array([0, 1], np.int64))
+    st, got, gi, gs = ms.compress_map_output(one, 1, img.size)
+    assert st == 0 and got == img.tobytes() and gs == [int(sums[0])]
+
+
+def test_whole_reduce_side_call_through_the_compiled_kernels(oracle):
+    """the other direction: the .data image of a map output (written by the oracle) as one fetched batch range — per-partition
+    checksums (compiled checksum kernels) equal the stored ones, the compiled frame discovery finds every LZ4Block frame, the
+    compiled batch decoder + frame-check kernel turn them back into the partitions.  One flipped payload byte: the partition's
+    checksum differs; with the checksum left aside, the frame check refuses the block."""
+    import checksum_kernel as ck
+    import decode_kernel as dk
+    import discover_kernel as dsc
+
+    rng = np.random.default_rng(53)
+    parts = [corpus.chunk_corpus(7, 50_000, rng).tobytes(), b"", rng.integers(0, 256, 33_000, dtype=np.uint8).tobytes(),
+             corpus.chunk_corpus(6, 9000, rng).tobytes(), corpus.chunk_corpus(3, 11, rng).tobytes()]
+    data = np.frombuffer(b"".join(parts), np.uint8)
+    offs = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int64)
+    img, idx, sums = oracle.compress_map_output(1, 1, data, offs)
+    image = img.tobytes()
+    assert ck.checksum_ranges(1, image, [int(x) for x in idx]) == [int(x) for x in sums]
+    st, recs, outs = dsc.discover(image)
+    assert st == 0 and outs[-1] == data.size
+    st, back = dk.decode_range(image, recs, outs)
+    assert st == 0 and back == data.tobytes()
+    bad = bytearray(image)
+    victim = next(r for r in recs if r[1] > 100 and r[4] == 0x20)  # an LZ4-coded block: damage a byte in its literals / tokens
+    bad[victim[0] + 40] ^= 0x04
+    p = max(k for k in range(len(parts)) if idx[k] <= victim[0])
+    got = ck.checksum_ranges(1, bytes(bad), [int(x) for x in idx])
+    assert [k for k in range(len(parts)) if got[k] != int(sums[k])] == [p]
+    st, recs2, outs2 = dsc.discover(bytes(bad))
+    assert st == 0 and recs2 == recs  # (the headers are intact)
+    st, _ = dk.decode_range(bytes(bad), recs2, outs2)
+    assert st == -3
+
+
 # ---- the compiled checksum kernels under the interpreter ----------------------------------------------------------------------
 @pytest.mark.parametrize("algo", [1, 2], ids=["adler32", "crc32"])
 def test_compiled_checksum_kernels(algo):
