@@ -38,21 +38,27 @@ def _prog(src, needle):
     return _P[(src, needle)] + (_P[src][1],)
 
 
-def compress_map_output(parts, algo, dst_bytes):
-    """parts: list of bytes (one per partition, may be empty); dst_bytes: size of the destination (= dst_capacity).
+def compress_map_output(parts, algo, dst_bytes, codec=1):
+    """parts: list of bytes (one per partition, may be empty); dst_bytes: size of the destination (= dst_capacity);
+    codec 1 = LZ4 (LZ4Block frames), 2 = Snappy (SnappyOutputStream chunks; snappy_compress_kernel, one workgroup per item).
     -> (status, image bytes, index list [n + 1], checksums list [n] or None)"""
     n = len(parts)
+    snappy = codec == 2
+    # a slot holds one chunk's codec output (codec_api.hip): kSlotBytes for LZ4, kSlotHeader + MaxCompressedLength rounded for Snappy
+    stride = 32 + ((32 + BLOCK + BLOCK // 6 + 15) & ~15) if snappy else lk.K_SLOT_BYTES
     src = np.frombuffer(b"".join(parts), dtype=np.uint8)
     items = bytearray()
     part_first = []
     off = ch = 0
     for p, b in enumerate(parts):
         part_first.append(len(items) // 24)
+        if b and snappy:
+            items += struct.pack("<qiiii", 0, 0, 2, -1, p)  # kItemSnappyHeader
         for pos in range(0, len(b), BLOCK):
-            items += struct.pack("<qiiii", off + pos, min(BLOCK, len(b) - pos), 0 | (LEVEL << 8), ch, p)
+            items += struct.pack("<qiiii", off + pos, min(BLOCK, len(b) - pos), 3 if snappy else 0 | (LEVEL << 8), ch, p)
             ch += 1
-        if b:
-            items += struct.pack("<qiiii", 0, 0, 1 | (LEVEL << 8), -1, p)
+        if b and not snappy:
+            items += struct.pack("<qiiii", 0, 0, 1 | (LEVEL << 8), -1, p)  # kItemLz4End
         off += len(b)
     n_items = len(items) // 24
     part_first.append(n_items)
@@ -63,7 +69,7 @@ def compress_map_output(parts, algo, dst_bytes):
     size = np.zeros(max(n_items, 1), np.uint32)
     item_off = np.full(n_items + 1, -7, np.int64)
     index = np.full(n + 1, -7, np.int64)
-    slots = np.zeros(max(ch, 1) * lk.K_SLOT_BYTES, np.uint8)
+    slots = np.zeros(max(ch, 1) * stride, np.uint8)
     work = np.zeros(1, np.uint32)
     status = np.zeros(1, np.int32)
     dst = np.full(max(dst_bytes, 1), 0xA5, np.uint8)[:dst_bytes]
@@ -71,7 +77,12 @@ def compress_map_output(parts, algo, dst_bytes):
     a_slots, a_work, a_status = mem.map(slots, "slots"), mem.map(work, "work"), mem.map(status, "status")
     a_pf = mem.map(np.array(part_first, np.int32), "part_first", writable=False)
     a_dst = mem.map(dst if dst_bytes else np.zeros(1, np.uint8), "dst")
-    if n_items:
+    if n_items and snappy:
+        prog, entry, objs = _prog("snappy_compress.hip", "snappy_compress_kernelILb1E")
+        objs = {k: v for k, v in emu.parse_objects(_P["snappy_compress.hip"][0]).items() if "g_sn_sched" in k or k.startswith("_ZN3s3s")}
+        emu.launch(prog, entry, mem, struct.pack("<QQiiQqQ", a_src, a_items, n_items, 0, a_slots, stride, a_size), n_items, 32768,
+                   objects=objs)
+    elif n_items:
         prog, entry, objs = _prog("lz4_compress.hip", "xxh32_items_wave_kernel")
         emu.launch(prog, entry, mem, struct.pack("<QQiIQ", a_src, a_items, n_items, SEED, a_check), n_items, 0, objects=objs)
         prog, entry, objs = _prog("lz4_compress.hip", "lz4_compress_l2_kernelILb1E")
@@ -82,7 +93,7 @@ def compress_map_output(parts, algo, dst_bytes):
     emu.launch(prog, entry, mem, struct.pack("<QiiQQiiQ", a_size, n_items, 0, a_off, a_pf, n, 0, a_index), 1, 0, objects=objs)
     if n_items:
         prog, entry, objs = _prog("assemble.hip", "gather_items_kernel")
-        emu.launch(prog, entry, mem, struct.pack("<QQiiQqQQQqQ", a_src, a_items, n_items, 0, a_slots, lk.K_SLOT_BYTES, a_size, a_off,
+        emu.launch(prog, entry, mem, struct.pack("<QQiiQqQQQqQ", a_src, a_items, n_items, 0, a_slots, stride, a_size, a_off,
                                                  a_dst, dst_bytes, a_status), n_items, 0, block_x=256, objects=objs)
     idx = [int(x) for x in index]
     sums = None

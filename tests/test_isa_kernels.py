@@ -396,8 +396,8 @@ def test_compiled_decoder_rejects_malformed_blocks_without_leaving_its_buffers()
 
 # ---- one whole map-side call through the compiled kernels ------------------------------------------------------------------
 def test_whole_map_side_call_through_the_compiled_kernels(oracle):
-    """tests/isa/map_side.py: frame-check pre-pass, LZ4 blocks and end frames (persistent grid), item scan, gather into the
-    .data image, per-partition checksums — the kernels of compress_core in its order, the item plan built like the host code
+    """tests/isa/map_side.py: frame-check pre-pass, LZ4 blocks and end frames (persistent grid) — or the Snappy kernel —, item
+    scan, gather into the .data image, per-partition checksums — the kernels of compress_core in its order, the item plan built like the host code
     builds it, every buffer of exactly its size.  Image, index and checksums equal the oracle's; a destination that is one
     byte short is S3S_E_CAPACITY and nothing is written behind it (the buffer ends there)."""
     import map_side as ms
@@ -408,10 +408,11 @@ def test_whole_map_side_call_through_the_compiled_kernels(oracle):
              corpus.chunk_corpus(6, 9000, rng).tobytes(), b"", corpus.chunk_corpus(2, 32768, rng).tobytes()]
     data = np.frombuffer(b"".join(parts), np.uint8)
     offs = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int64)
-    for algo in (1, 2):
-        img, idx, sums = oracle.compress_map_output(1, algo, data, offs)
-        st, got, gi, gs = ms.compress_map_output(parts, algo, img.size)
-        assert st == 0 and got == img.tobytes() and gi == list(idx) and gs == [int(x) for x in sums]
+    for codec, algo in ((1, 1), (1, 2), (2, 2)):  # LZ4 + Adler32, LZ4 + CRC32, Snappy (own slot stride: a raw block may grow) + CRC32
+        img, idx, sums = oracle.compress_map_output(codec, algo, data, offs)
+        st, got, gi, gs = ms.compress_map_output(parts, algo, img.size, codec=codec)
+        assert st == 0 and got == img.tobytes() and gi == list(idx) and gs == [int(x) for x in sums], (codec, algo)
+    img, idx, sums = oracle.compress_map_output(1, 0, data, offs)
     st, got, gi, _ = ms.compress_map_output(parts, 0, img.size - 1)
     assert st == -2 and gi == list(idx)  # (the index says what it would have taken)
     st, got, gi, gs = ms.compress_map_output([b"", b"", b""], 1, 0)
