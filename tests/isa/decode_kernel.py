@@ -79,12 +79,13 @@ def decode_blocks(blocks, fmt=0, methods=None, profile=None, flags=(), grid=None
     return res, int(status[0]), waves
 
 
-def decode_range(comp: bytes, recs, outs, verify=True):
+def decode_range(comp: bytes, recs, outs, verify=True, fmt=0):
     """The decode launches of one fetched range: `recs` / `outs` = the frame records and output offsets the compiled frame
     discovery produced (tests/isa/discover_kernel.py), batch_decode_kernel<LZ4> over them, then lz4_verify_frames_kernel
     (xxHash32 of every decoded block against the frame's check field).  Buffers of exactly their sizes.
     -> (status, decoded bytes)"""
-    prog, entry, text, lds = program(0)
+    prog, entry, text, lds = program(fmt)
+    verify = verify and fmt == 0  # (Snappy chunks carry no check field: the partition checksum is their guard)
     n = len(recs)
     total = outs[-1]
     mem = emu.Memory()

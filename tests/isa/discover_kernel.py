@@ -88,3 +88,45 @@ def reference_frames(stream: bytes):
         out.append((pos + 21, clen, olen, check, method))
         pos += 21 + clen
     return out
+
+
+def discover_snappy(stream: bytes, part_offsets):
+    """SnappyOutputStream images of several partitions in one range (csrc/snappy_decompress.hip: snappy_count_kernel ->
+    scan_u32_kernel -> snappy_emit_kernel -> scan_u32_kernel, as decode_api.hip launches them).
+    -> (status, frames [(payload offset, payload bytes, decoded bytes, 0, 1)], output offsets)"""
+    offs = np.asarray(part_offsets, np.int64)
+    n_parts = len(offs) - 1
+    if "sn" not in _PROG:
+        text = lk.compile_asm("snappy_decompress.hip")
+        _PROG["sn"] = (text, {k: v for k, v in emu.parse_objects(text).items() if k.startswith("_ZN3s3s")})
+    text, objs = _PROG["sn"]
+
+    def run(needle, kernarg, grid):
+        # these two kernels read blockDim.x: the implicit arguments follow the explicit ones (code object v5: block counts
+        # x / y / z as u32, then group sizes x / y / z as u16, then the remainders)
+        kernarg += b"\0" * (-len(kernarg) % 8) + struct.pack("<IIIHHHHHH", grid, 1, 1, 64, 1, 1, 0, 0, 0) + bytes(200)
+        entry = lk.find_kernel(text, needle)
+        emu.launch(emu.Program(text, entry), entry, mem, kernarg, grid, 0, objects=objs)
+
+    mem = emu.Memory()
+    a_comp = mem.map(np.frombuffer(bytearray(stream) or bytearray(1), dtype=np.uint8), "comp", writable=False)
+    a_off = mem.map(offs, "part_off", writable=False)
+    cnt = np.full(n_parts, 0xFFFFFFFF, np.uint32)
+    base = np.full(n_parts + 1, -7, np.int64)
+    status = np.zeros(1, np.int32)
+    a_cnt, a_base, a_st = mem.map(cnt, "part_nframes"), mem.map(base, "frame_base"), mem.map(status, "status")
+    run("snappy_count_kernel", struct.pack("<QQiiQQ", a_comp, a_off, n_parts, 0, a_cnt, a_st), (n_parts + 63) // 64)
+    if int(status[0]) != 0:
+        return int(status[0]), [], [0]  # (the host stops here: "Stream is corrupted (snappy chunk chain)")
+    _launch("scan_u32_kernel", mem, struct.pack("<QqQ", a_cnt, n_parts, a_base), 1)
+    n_frames = int(base[n_parts])
+    frames = np.zeros(max(n_frames, 1) * 24, np.uint8)[: n_frames * 24]
+    orig = np.zeros(n_frames, np.uint32)
+    fout = np.full(n_frames + 1, -7, np.int64)
+    a_fr = mem.map(frames if n_frames else np.zeros(1, np.uint8), "frames")
+    a_or = mem.map(orig if n_frames else np.zeros(1, np.uint32), "frame_orig")
+    a_fo = mem.map(fout, "frame_out")
+    run("snappy_emit_kernel", struct.pack("<QQiiQQQQ", a_comp, a_off, n_parts, 0, a_base, a_fr, a_or, a_st), (n_parts + 63) // 64)
+    _launch("scan_u32_kernel", mem, struct.pack("<QqQ", a_or, n_frames, a_fo), 1)
+    recs = [struct.unpack_from("<qiiIi", frames, 24 * k) for k in range(n_frames)]
+    return int(status[0]), recs, [int(x) for x in fout]

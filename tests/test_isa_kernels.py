@@ -456,6 +456,37 @@ def test_whole_reduce_side_call_through_the_compiled_kernels(oracle):
     assert st == -3
 
 
+def test_whole_snappy_reduce_side_call_through_the_compiled_kernels(oracle):
+    """SnappyOutputStream images: snappy_count / snappy_emit (chunk chains of every partition, concatenated streams) feed the
+    compiled batch decoder; chains that end early or run over their partition are S3S_E_BAD_FRAME without leaving the range"""
+    import decode_kernel as dk
+    import discover_kernel as dsc
+
+    rng = np.random.default_rng(54)
+    parts = [corpus.chunk_corpus(7, 50_000, rng).tobytes(), b"", rng.integers(0, 256, 33_000, dtype=np.uint8).tobytes(),
+             corpus.chunk_corpus(6, 9000, rng).tobytes(), corpus.chunk_corpus(3, 11, rng).tobytes()]
+    data = np.frombuffer(b"".join(parts), np.uint8)
+    offs = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int64)
+    img, idx, _ = oracle.compress_map_output(2, 0, data, offs)
+    image = img.tobytes()
+    st, recs, outs = dsc.discover_snappy(image, idx)
+    assert st == 0 and outs[-1] == data.size and len(recs) == 2 + 2 + 1 + 1
+    st, back = dk.decode_range(image, recs, outs, fmt=1)
+    assert st == 0 and back == data.tobytes()
+    # two streams in one partition (a multi-spill merge): the second header is stepped over
+    twice = image[: int(idx[1])] * 2
+    st, recs, outs = dsc.discover_snappy(twice, [0, len(twice)])
+    assert st == 0 and len(recs) == 4 and outs[-1] == 2 * len(parts[0])
+    for cut in (1, 3, 4, 5, 17, 100, int(idx[1]) - 1):  # ends inside the header / a length word / a chunk
+        assert dsc.discover_snappy(image[:cut], [0, cut])[0] == -3, cut
+    bad = bytearray(image)
+    bad[16:20] = (1 << 30).to_bytes(4, "big")  # a chunk length that runs over the partition
+    assert dsc.discover_snappy(bytes(bad), idx)[0] == -3
+    bad = bytearray(image)
+    bad[3] ^= 1  # header magic
+    assert dsc.discover_snappy(bytes(bad), idx)[0] == -3
+
+
 # ---- the compiled checksum kernels under the interpreter ----------------------------------------------------------------------
 @pytest.mark.parametrize("algo", [1, 2], ids=["adler32", "crc32"])
 def test_compiled_checksum_kernels(algo):
