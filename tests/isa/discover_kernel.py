@@ -130,3 +130,98 @@ def discover_snappy(stream: bytes, part_offsets):
     _launch("scan_u32_kernel", mem, struct.pack("<QqQ", a_or, n_frames, a_fo), 1)
     recs = [struct.unpack_from("<qiiIi", frames, 24 * k) for k in range(n_frames)]
     return int(status[0]), recs, [int(x) for x in fout]
+
+
+def decode_ranges_batch(ranges, capacities, skip=()):
+    """The batched reduce-side call for LZ4 (s3s_decompress_ranges_batch_device, csrc/decode_api.hip) through the compiled
+    kernels: tile_speculate_batch -> tile_resolve_batch | host: frame counts -> tile_emit_batch -> frames_finish_batch ->
+    ONE batch_decode_kernel launch over the frames of every range (comp = dst = nullptr: the records carry absolute
+    addresses) -> lz4_verify_frames_kernel.  ranges: list of LZ4Block streams (bytes); capacities: destination bytes per range
+    (the destination buffer of a range has exactly that size); skip: ranges the host marks as failed (checksum) beforehand.
+    -> list of (status, decoded bytes or None) per range, and the decode launch's own status word"""
+    import decode_kernel as dk
+
+    n_ranges = len(ranges)
+    mem = emu.Memory()
+    desc, bufs = [], []
+    tile_range = []
+    status = np.zeros(n_ranges + 1, np.int32)
+    a_status = mem.map(status, "status")
+    result = np.full(2 * n_ranges, -7, np.int64)
+    a_result = mem.map(result, "result")
+    for r, stream in enumerate(ranges):
+        n = len(stream)
+        nt = (n + TILE - 1) // TILE
+        b = {"comp": np.frombuffer(bytearray(stream) or bytearray(1), dtype=np.uint8),
+             "se": np.full(max(nt, 1), -7, np.int64)[:nt], "sx": np.full(max(nt, 1), -7, np.int64)[:nt],
+             "te": np.full(max(nt, 1), -7, np.int64)[:nt], "fb": np.full(nt + 1, -7, np.int64),
+             "sc": np.full(max(nt, 1), -7, np.int32)[:nt], "dst": np.full(max(capacities[r], 1), 0xA5, np.uint8)[:capacities[r]]}
+        a = {k: mem.map(v if v.size else np.zeros(1, v.dtype), "%s%d" % (k, r), writable=(k != "comp")) for k, v in b.items()}
+        d = dict(comp=a["comp"], comp_len=n, n_tiles=nt, tile0=len(tile_range), se=a["se"], sx=a["sx"], te=a["te"], fb=a["fb"],
+                 sc=a["sc"], status=a_status + 4 * r, result=a_result + 16 * r, frames=0, forig=0, fout=0, oabs=0, n_frames=0,
+                 dst_base=a["dst"], cap=capacities[r], skip=1 if r in skip else 0)
+        tile_range += [r] * nt
+        desc.append(d)
+        bufs.append((b, a))
+
+    def pack():
+        out = bytearray()
+        for d in desc:
+            out += struct.pack("<QqiiQQQQQQQQQQQqqqii", d["comp"], d["comp_len"], d["n_tiles"], d["tile0"], d["se"], d["sx"], d["te"],
+                               d["fb"], d["sc"], d["status"], d["result"], d["frames"], d["forig"], d["fout"], d["oabs"],
+                               d["n_frames"], d["dst_base"], d["cap"], d["skip"], 0)
+        return np.frombuffer(out, dtype=np.uint8).copy()
+
+    total_tiles = len(tile_range)
+    a_tr = mem.map(np.array(tile_range or [0], np.int32), "tile_range", writable=False)
+    d_ranges = pack()
+    a_rg = mem.map(d_ranges, "ranges")
+    if total_tiles:
+        _launch("tile_speculate_batch_kernel", mem, struct.pack("<QQi", a_rg, a_tr, total_tiles), total_tiles)
+    _launch("tile_resolve_batch_kernel", mem, struct.pack("<Qi", a_rg, n_ranges), n_ranges)
+    # host: frame counts; a range whose chain is broken (or that was marked) takes no part in what follows
+    total_frames = 0
+    first = []
+    for r, d in enumerate(desc):
+        nf = int(result[2 * r]) if d["n_tiles"] > 0 else 0
+        if status[r] != 0 or d["skip"]:
+            nf, d["skip"] = 0, 1
+        d["n_frames"] = nf
+        first.append(total_frames)
+        total_frames += nf
+    frames = np.zeros(max(total_frames, 1) * 24, np.uint8)[: total_frames * 24]
+    out_abs = np.full(max(total_frames, 1), -7, np.int64)[:total_frames]
+    a_frames = mem.map(frames if total_frames else np.zeros(1, np.uint8), "frames")
+    a_oabs = mem.map(out_abs if total_frames else np.zeros(1, np.int64), "out_abs")
+    for r, d in enumerate(desc):
+        nf = d["n_frames"]
+        fo = np.zeros(max(nf, 1), np.uint32)[:nf]
+        fout = np.full(nf + 1, -7, np.int64)
+        bufs[r][0]["forig"], bufs[r][0]["fout"] = fo, fout
+        d["forig"] = mem.map(fo if nf else np.zeros(1, np.uint32), "frame_orig%d" % r)
+        d["fout"] = mem.map(fout, "frame_out%d" % r)
+        d["frames"] = a_frames + 24 * first[r]
+        d["oabs"] = a_oabs + 8 * first[r]
+    d_ranges[:] = pack()
+    if total_tiles:
+        _launch("tile_emit_batch_kernel", mem, struct.pack("<QQi", a_rg, a_tr, total_tiles), (total_tiles + 63) // 64)
+    _launch("frames_finish_batch_kernel", mem, struct.pack("<Qi", a_rg, n_ranges), n_ranges)
+    if total_frames:
+        prog, entry, text, lds = dk.program(0)
+        objs = {k: v for k, v in emu.parse_objects(text).items() if k.startswith("_ZN3s3s")}
+        a_dec = a_status + 4 * n_ranges
+        emu.launch(prog, entry, mem, struct.pack("<QQiiQQQ", 0, a_frames, total_frames, 0, a_oabs, 0, a_dec), total_frames, lds,
+                   objects=objs)
+        ventry = lk.find_kernel(text, "lz4_verify_frames_kernel")
+        emu.launch(emu.Program(text, ventry), ventry, mem, struct.pack("<QiiQQQ", a_frames, total_frames, 0, a_oabs, 0, a_dec),
+                   (total_frames + 15) // 16, lds, objects=objs)
+    out = []
+    for r, d in enumerate(desc):
+        st = int(status[r])
+        if st == 0 and d["skip"]:
+            st = -4  # (the host's own mark: a checksum mismatch found before the decode)
+        total = int(result[2 * r + 1]) if d["n_frames"] > 0 else 0
+        if st == 0 and total > d["cap"]:
+            st = -2
+        out.append((st, bufs[r][0]["dst"][:total].tobytes() if st == 0 else None))
+    return out, int(status[n_ranges])

@@ -74,24 +74,42 @@ class Memory:
                 bad, n, "store" if write else "load", name, int(offs[bad]), arr.size))
         return arr, np.where(active, offs, 0)
 
+    def _groups(self, addrs, active):
+        """the active lanes grouped by the region their address falls into (one group in nearly every access: the fast path
+        of _locate; kernels that follow per-lane descriptors — the batched frame discovery — touch several regions at once)"""
+        idx = np.flatnonzero(active)
+        if idx.size == 0:
+            return
+        base, arr, _, _ = self.find(int(addrs[idx[0]]))
+        a = addrs.astype(np.int64)[idx] - base
+        if a.min() >= 0 and a.max() < max(arr.size, 1):
+            yield active
+            return
+        left = active.copy()
+        while left.any():
+            first = int(np.flatnonzero(left)[0])
+            base, arr, _, _ = self.find(int(addrs[first]))
+            o = addrs.astype(np.int64) - base
+            grp = left & (o >= 0) & (o < max(arr.size, 1))
+            yield grp
+            left = left & ~grp
+
     def load(self, addrs, active, n):
         """-> uint8[64, n] (zeros for inactive lanes)"""
-        arr, offs = self._locate(addrs, active, n, False)
         out = np.zeros((64, n), dtype=np.uint8)
-        if arr is None:
-            return out
-        got = arr[offs[:, None] + np.arange(n)]
-        out[active] = got[active]
+        for grp in self._groups(addrs, active):
+            arr, offs = self._locate(addrs, grp, n, False)
+            got = arr[offs[:, None] + np.arange(n)]
+            out[grp] = got[grp]
         return out
 
     def store(self, addrs, active, data):
         n = data.shape[1]
-        arr, offs = self._locate(addrs, active, n, True)
-        if arr is None:
-            return
-        for lane in np.flatnonzero(active):  # lane order: the highest lane wins a same-address race
-            o = int(offs[lane])
-            arr[o:o + n] = data[lane]
+        for grp in self._groups(addrs, active):
+            arr, offs = self._locate(addrs, grp, n, True)
+            for lane in np.flatnonzero(grp):  # lane order: the highest lane wins a same-address race
+                o = int(offs[lane])
+                arr[o:o + n] = data[lane]
 
     def load_scalar(self, addr, n):
         base, arr, name, wr = self.find(addr)
@@ -1471,6 +1489,12 @@ class Program:
     def x_global_atomic_swap(self, w, i):
         # (no return value used here): global_atomic_swap vaddr, vdata, saddr
         addrs = self._gaddr(w, i, i.ops[0], i.ops[2])
+        data = w.v[i.ops[1][1]].astype("<u4").view(np.uint8).reshape(64, 4)
+        w.mem.store(addrs, w.em(), np.ascontiguousarray(data))
+
+    def x_flat_atomic_swap(self, w, i):
+        # (no return value used here): flat_atomic_swap vaddr(64), vdata
+        addrs = self._gaddr(w, i, i.ops[0], ("off",))
         data = w.v[i.ops[1][1]].astype("<u4").view(np.uint8).reshape(64, 4)
         w.mem.store(addrs, w.em(), np.ascontiguousarray(data))
 

@@ -456,6 +456,29 @@ def test_whole_reduce_side_call_through_the_compiled_kernels(oracle):
     assert st == -3
 
 
+def test_batched_reduce_side_call_through_the_compiled_kernels(oracle):
+    """s3s_decompress_ranges_batch_device's launches for LZ4 (tests/isa/discover_kernel.py: decode_ranges_batch): several fetched
+    ranges in one call — the batched discovery kernels walk their LzRange descriptors, frames_finish_batch rebases the records to
+    absolute addresses, ONE decode launch (comp = dst = nullptr) and one frame-check launch cover every range.  A range with a
+    broken chain, one whose destination is too small and one the host marked beforehand leave the others untouched; their
+    frames become empty records and nothing is written to their destinations."""
+    import discover_kernel as dsc
+
+    rng = np.random.default_rng(55)
+    srcs = [corpus.chunk_corpus(7, 90_000, rng).tobytes(), corpus.chunk_corpus(6, 9000, rng).tobytes(), b"",
+            rng.integers(0, 256, 70_000, dtype=np.uint8).tobytes(), corpus.chunk_corpus(2, 40_000, rng).tobytes()]
+    streams = [oracle.compress_stream(1, np.frombuffer(b, np.uint8)).tobytes() if b else b"" for b in srcs]
+    res, dec_status = dsc.decode_ranges_batch(streams, [len(b) for b in srcs])
+    assert dec_status == 0 and [st for st, _ in res] == [0] * 5 and [out for _, out in res] == srcs
+    broken = bytearray(streams[3])
+    broken[21 + 32768 + 9] ^= 0x40  # the second frame's compressedLen: the chain leaves the range
+    res, dec_status = dsc.decode_ranges_batch([streams[0], bytes(broken), streams[4], streams[1], streams[1]],
+                                              [len(srcs[0]), len(srcs[3]), len(srcs[4]) - 1, len(srcs[1]), len(srcs[1])], skip=(4,))
+    assert dec_status == 0
+    assert [st for st, _ in res] == [0, -3, -2, 0, -4]
+    assert res[0][1] == srcs[0] and res[3][1] == srcs[1]
+
+
 def test_whole_snappy_reduce_side_call_through_the_compiled_kernels(oracle):
     """SnappyOutputStream images: snappy_count / snappy_emit (chunk chains of every partition, concatenated streams) feed the
     compiled batch decoder; chains that end early or run over their partition are S3S_E_BAD_FRAME without leaving the range"""
