@@ -148,3 +148,18 @@ def test_scala_sources_are_structurally_sound(patched_tree):
         assert _brackets_balance(_read(f)) is None, (f, _brackets_balance(_read(f)))
     assert _brackets_balance("object A { def f(x: Int) = { x + 1 }") is not None  # (the check sees a dropped brace)
     assert _brackets_balance('object A { val s = "}" /* } */ }') is None
+
+
+def test_documented_keys_exist_where_the_document_says():
+    """every spark.shuffle.s3.gpu.* key of the table is defined by the patch's dispatcher, or the row says
+    that only the C++ host mirror has it (and then the host mirror's Conf names it)"""
+    doc = _read(ROOT, "INTEGRATION.md")
+    patch = _read(PATCH)
+    host = _read(ROOT, "spark-s3-shuffle_amd", "host", "s3shuffle_host.h")
+    rows = re.findall(r"^\| `(spark\.shuffle\.s3\.gpu\.[A-Za-z]+)` \|[^|]*\|([^\n]*)$", doc, flags=re.M)
+    assert len(rows) >= 9
+    for key, text in rows:
+        if "C++ host mirror" in text:
+            assert key in host and key not in patch, key
+        else:
+            assert '"%s"' % key in patch, key
