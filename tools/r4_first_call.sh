@@ -7,6 +7,10 @@ tag=${1:-r04a}
 R=$GRAFT_REPO_ROOT; cd $R; export TMPDIR=/tmp
 O=gpurun_out/$tag; mkdir -p $O
 L=$R/spark-s3-shuffle_amd/lib
+# the state the round starts from: the whole GPU suite (incl. the tests added without a GPU at the end of round 3) and the driver's bench line
+timeout 400 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 | tee $O/pytest_gpu.txt
+timeout 200 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | grep '^{' > $O/bench_full.json
+python -c "import json; d=json.loads(open('$O/bench_full.json').read()); print('driver-style headline', d['value'], 'GB/s;', {k: v.get('value') for k, v in d.get('secondary', {}).items() if isinstance(v, dict) and 'value' in v})" | tee $O/bench_full.txt
 head1() { timeout 90 python bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 5 "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['roofline'].get('avg_launch_ms'))" || echo FAILED; }
 {
 echo "== compress headline (GB/s, ms per launch): shipped / rollpf / storent / setprio / grid 1536 / shipped"
