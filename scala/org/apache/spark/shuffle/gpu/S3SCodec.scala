@@ -68,7 +68,10 @@ object S3SCodec {
 
   def load(libraryPath: String): Unit = synchronized {
     if (!loaded) {
-      System.load(libraryPath) // spark.shuffle.s3.gpu.library
+      // spark.shuffle.s3.gpu.library: an absolute path, or a bare name (libs3shuffle_jni.so / s3shuffle_jni) that is looked up
+      // on java.library.path — System.load refuses anything that is not absolute
+      if (libraryPath.contains(java.io.File.separator)) System.load(new java.io.File(libraryPath).getAbsolutePath)
+      else System.loadLibrary(libraryPath.stripPrefix("lib").stripSuffix(".so"))
       require(abiVersion() == ABI_VERSION, s"libs3shuffle_codec ABI ${abiVersion()} != $ABI_VERSION")
       loaded = true
     }
