@@ -24,7 +24,10 @@
 #include "s3shuffle_codec.h"
 
 #define CTX(h) ((s3s_ctx*)(intptr_t)(h))
-#define FN(name) Java_org_apache_spark_shuffle_gpu_S3SCodec_##name
+/* S3SCodec is a Scala `object`: scalac puts its @native methods on the module class S3SCodec$ as INSTANCE methods (the static
+ * forwarders in class S3SCodec are ordinary bytecode), so the JVM looks the natives up under the mangled name of S3SCodec$
+ * ('$' is _00024) and passes the module instance where a static native would get the class. */
+#define FN(name) Java_org_apache_spark_shuffle_gpu_S3SCodec_00024_##name
 
 static jlong* pin(JNIEnv* e, jlongArray a) { return a ? (*e)->GetLongArrayElements(e, a, NULL) : NULL; }
 static void unpin(JNIEnv* e, jlongArray a, jlong* p, jint mode) {

@@ -10,7 +10,7 @@
 #include "mock_jvm.h"
 #include "s3shuffle_codec.h"
 
-#define FN(name) Java_org_apache_spark_shuffle_gpu_S3SCodec_##name
+#define FN(name) Java_org_apache_spark_shuffle_gpu_S3SCodec_00024_##name /* (natives of the Scala object's module class S3SCodec$) */
 #define CHECK(x)                                                         \
   do {                                                                   \
     if (!(x)) {                                                          \

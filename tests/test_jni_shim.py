@@ -17,7 +17,9 @@ def test_jni_translation_unit_type_checks_against_the_header(tmp_path):
                     "-I", os.path.join(ROOT, "tests", "mock_jni"), "-I", os.path.join(ROOT, "include"),
                     JNI_C, "-o", str(obj)], check=True)
     syms = subprocess.run(["nm", "--defined-only", str(obj)], check=True, capture_output=True, text=True).stdout
-    exported = set(re.findall(r"Java_org_apache_spark_shuffle_gpu_S3SCodec_(\w+)", syms))
+    # S3SCodec is a Scala object: its natives live on the module class S3SCodec$ ("$" = _00024 in JNI's name mangling)
+    assert not re.search(r"Java_org_apache_spark_shuffle_gpu_S3SCodec_(?!00024_)", syms)
+    exported = set(re.findall(r"Java_org_apache_spark_shuffle_gpu_S3SCodec_00024_(\w+)", syms))
     assert {"create", "destroy", "compressMapOutput", "compressMapOutputSegments", "decompressRange",
             "checksumRanges", "maxCompressedSize", "decompressedSize", "hostAlloc", "hostFree", "lastError",
             "compressMapOutputsBatch", "decompressRangesBatch"} <= exported
