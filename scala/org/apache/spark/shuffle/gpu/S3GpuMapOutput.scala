@@ -51,6 +51,7 @@ class S3GpuMapOutput(shuffleId: Int, mapId: Long, numPartitions: Int, createBloc
   private var running: Checksum = null // non-null <=> partition groupFirst already has bytes in the object
   private var stream: OutputStream = null // the data block, opened lazily like initStream() (:43-49)
   private var uncompressedTotal = 0L
+  private var flushedOnce = false // something of this map output already went through the library
 
   def bytesStaged: Long = uncompressedTotal
 
@@ -109,6 +110,7 @@ class S3GpuMapOutput(shuffleId: Int, mapId: Long, numPartitions: Int, createBloc
   private def flush(endOfPartition: Boolean): Unit = {
     val n = groupOffsets.length - 1 // staged partitions groupFirst .. current (the last one possibly partial)
     if (n <= 0) return
+    flushedOnce = true
     val offs = groupOffsets.toArray
     val cap = S3SCodec.maxCompressedSize(ctx, codec, offs, n)
     val out = S3GpuBuffers.take(cap)
@@ -154,11 +156,41 @@ class S3GpuMapOutput(shuffleId: Int, mapId: Long, numPartitions: Int, createBloc
     staging.clear()
   }
 
+  /** A map output below spark.shuffle.s3.gpu.minBytes is not worth a library call (one 32 KiB block is a ~1 ms serial chain
+    * on a wavefront: the call has that floor): the same partition streams come from the JVM codec — LZ4 objects are
+    * byte-identical either way, Snappy objects decode the same.  Only for an output that was never flushed before. */
+  private def flushOnJvm(): Unit = {
+    val jvmCodec = org.apache.spark.io.CompressionCodec.createCodec(org.apache.spark.SparkEnv.get.conf, dispatcher.gpuCodec)
+    val n = groupOffsets.length - 1
+    var i = 0
+    while (i < n) {
+      val p = groupFirst + i
+      val from = groupOffsets(i)
+      val len = groupOffsets(i + 1) - from
+      val sum: Checksum =
+        if (algo == S3SCodec.CHECKSUM_CRC32) new CRC32() else if (algo == S3SCodec.CHECKSUM_ADLER32) new Adler32() else null
+      if (len > 0) { // (an empty partition is 0 bytes in the object, like S3ShuffleMapOutputWriter's untouched partition writer)
+        if (stream == null) stream = createBlock()
+        val counted = new S3GpuBuffers.CountingStream(stream, sum) // (close() stops at it: the data block stays open)
+        val out = jvmCodec.compressedOutputStream(counted)
+        S3GpuBuffers.writeTo(out, staging, from, len, null)
+        out.close()
+        partitionLengths(p) = counted.count
+      }
+      if (sum != null) checksums(p) = sum.getValue // (of no bytes for an empty partition: Adler32 1, CRC32 0 — as the library answers)
+      i += 1
+    }
+    groupFirst = current + 1
+    groupOffsets.clear(); groupOffsets += 0L
+    staging.clear()
+  }
+
   /** commitAllPartitions: compress + checksum on the GPU, then the reference's own store writes. */
   def commit(): MapOutputCommitMessage = {
     try {
       if (current < numPartitions - 1) openPartition(numPartitions - 1)
-      flush(endOfPartition = true)
+      if (!flushedOnce && uncompressedTotal < dispatcher.gpuMinBytes) flushOnJvm()
+      else flush(endOfPartition = true)
       if (stream != null) { stream.close(); stream = null }
       // emission rule and order of commitAllPartitions (:111-115): index, then checksum, iff bytes or alwaysCreateIndex
       if (partitionLengths.sum > 0 || dispatcher.alwaysCreateIndex) {
@@ -214,6 +246,18 @@ object S3GpuBuffers {
   def grow(b: ByteBuffer, atLeast: Long): ByteBuffer = {
     val n = take(atLeast)
     b.flip(); n.put(b); give(b); n
+  }
+
+  /** Counts (and optionally checksums) what passes through; close() flushes and stops here — the codec streams close
+    * what they wrap, the data block must stay open for the next partition. */
+  final class CountingStream(under: OutputStream, sum: Checksum) extends OutputStream {
+    var count = 0L
+    override def write(b: Int): Unit = { under.write(b); if (sum != null) sum.update(b); count += 1 }
+    override def write(b: Array[Byte], off: Int, len: Int): Unit = {
+      under.write(b, off, len); if (sum != null) sum.update(b, off, len); count += len
+    }
+    override def flush(): Unit = under.flush()
+    override def close(): Unit = under.flush()
   }
 
   /** out[from, from+len) -> s in 1 MiB pieces; `sum` (optional) sees the same bytes in the same order. */

@@ -30,6 +30,7 @@ class StagedMapOutput:
         self.running = None  # zlib-style running value of the split partition (None = not split)
         self.obj = bytearray()
         self.num_partitions = num_partitions
+        self.flushed_once = False
 
     def _open_partition(self, reduce_id):  # openPartition
         assert reduce_id >= self.current
@@ -59,6 +60,7 @@ class StagedMapOutput:
         n = len(self.group_offsets) - 1
         if n <= 0:
             return
+        self.flushed_once = True
         offs = np.array(self.group_offsets, np.int64)
         img, index, sums = self.o.compress_map_output(self.codec, self.algo, np.frombuffer(bytes(self.staging), np.uint8), offs)
         for i in range(n):
@@ -84,10 +86,31 @@ class StagedMapOutput:
         self.group_offsets = [0] if end_of_partition else [0, 0]
         self.staging = bytearray()
 
-    def commit(self):
+    def _flush_on_jvm(self):  # flushOnJvm: the same partition streams from the JVM codec (here: the oracle's stream writer)
+        n = len(self.group_offsets) - 1
+        for i in range(n):
+            p = self.group_first + i
+            data = bytes(self.staging[self.group_offsets[i]:self.group_offsets[i + 1]])
+            v = self._sum_new() if self.algo != NONE else None
+            if data:
+                stored = self.o.compress_stream(self.codec, np.frombuffer(data, np.uint8)).tobytes()
+                self.obj += stored
+                self.partition_lengths[p] = len(stored)
+                if v is not None:
+                    v = self._sum_update(v, stored)
+            if v is not None:
+                self.checksums[p] = v
+        self.group_first = self.current + 1
+        self.group_offsets = [0]
+        self.staging = bytearray()
+
+    def commit(self, min_bytes=0):
         if self.current < self.num_partitions - 1:
             self._open_partition(self.num_partitions - 1)
-        self._flush(end_of_partition=True)
+        if not self.flushed_once and len(self.staging) < min_bytes and sum(self.partition_lengths) == 0:
+            self._flush_on_jvm()
+        else:
+            self._flush(end_of_partition=True)
         return self.partition_lengths, self.checksums, bytes(self.obj)
 
 
@@ -137,3 +160,24 @@ def test_a_flush_exactly_at_a_partition_boundary(oracle):
     rc, back, bad = oracle.decompress_range(LZ4, ADLER, np.frombuffer(obj, np.uint8), index, np.array(sums, np.int64), len(a) + len(b))
     assert rc == 0 and back.tobytes() == a + b and lengths[2] == 0 and sums[2] == 1
     assert [sums[p] for p in (0, 1)] == [oracle.checksum(ADLER, np.frombuffer(obj[int(index[p]):int(index[p + 1])], np.uint8)) for p in (0, 1)]
+
+
+@pytest.mark.parametrize("codec,algo", [(LZ4, ADLER), (SNAPPY, CRC), (LZ4, NONE)])
+def test_small_map_outputs_take_the_jvm_codec_and_produce_the_same_object(oracle, codec, algo):
+    """spark.shuffle.s3.gpu.minBytes: a map output below it is compressed by the JVM codec partition by partition (flushOnJvm) —
+    the object, the lengths and the checksums are those of the library call (the oracle's single-call image)"""
+    import corpus
+
+    rng = np.random.default_rng(23)
+    parts = [corpus.chunk_corpus(7, 9000, rng).tobytes(), b"", corpus.chunk_corpus(3, 40_000, rng).tobytes(), b"x", b""]
+    m = StagedMapOutput(oracle, codec, algo, len(parts), 1 << 20)
+    for p, b in enumerate(parts):
+        if b or p == 1:
+            m.append(p, b)
+    lengths, sums, obj = m.commit(min_bytes=2 << 20)
+    assert not m.flushed_once
+    offs = np.concatenate([[0], np.cumsum([len(b) for b in parts])]).astype(np.int64)
+    img, idx, s1 = oracle.compress_map_output(codec, algo, np.frombuffer(b"".join(parts), np.uint8), offs)
+    assert obj == img.tobytes() and list(np.cumsum([0] + lengths)) == list(idx)
+    if algo != NONE:
+        assert sums == [int(x) for x in s1]
