@@ -66,3 +66,28 @@ def test_scala_constants_match_the_header():
         hv = int(re.search(r"%s\s*=\s*(-?\d+)" % name, header).group(1))
         sv = int(re.search(r"val %s = (-?\d+)" % sc, scala).group(1))
         assert hv == sv, name
+
+
+_SCALA_TO_JNI = {"Int": "jint", "Long": "jlong", "ByteBuffer": "jobject", "String": "jstring", "Unit": "void",
+                 "Array[Long]": "jlongArray", "Array[Int]": "jintArray", "Array[ByteBuffer]": "jobjectArray",
+                 "Array[Array[Long]]": "jobjectArray"}
+
+
+def test_scala_native_types_match_the_c_side():
+    """not only the number of parameters: every parameter's and the result's JNI type (Int -> jint, Array[Long] -> jlongArray,
+    Array[Array[Long]] -> jobjectArray, ...) is what the C wrapper declares — an Int passed where the C side reads a jlong
+    would only show up as garbage at run time"""
+    c_src = re.sub(r"/\*.*?\*/", "", open(JNI_C).read(), flags=re.S)
+    c = {}
+    for m in re.finditer(r"JNIEXPORT\s+(\w+)\s+JNICALL\s+FN\((\w+)\)\s*\(([^)]*)\)", c_src):
+        params = [p.strip() for p in m.group(3).split(",") if p.strip()][2:]  # (JNIEnv*, jclass)
+        c[m.group(2)] = (m.group(1), [p.split()[0] for p in params])
+    s_src = open(SCALA).read()
+    seen = 0
+    for m in re.finditer(r"@native def (\w+)\(([^)]*)\)\s*:\s*([\w\[\]]+)", s_src, flags=re.S):
+        name, params, ret = m.group(1), m.group(2), m.group(3)
+        types = [p.split(":", 1)[1].strip() for p in re.split(r",(?![^\[]*\])", params) if p.strip()]
+        want = (_SCALA_TO_JNI[ret], [_SCALA_TO_JNI[t] for t in types])
+        assert c[name] == want, (name, c[name], want)
+        seen += 1
+    assert seen == len(c) >= 17
