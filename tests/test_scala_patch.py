@@ -163,3 +163,19 @@ def test_documented_keys_exist_where_the_document_says():
             assert key in host and key not in patch, key
         else:
             assert '"%s"' % key in patch, key
+
+
+def test_reference_members_the_shim_uses_exist(patched_tree):
+    """the other direction: every S3ShuffleHelper.<member> and dispatcher.<member> the shim sources call is defined in the
+    (patched) reference — a renamed helper would otherwise only fail at scalac time, which nobody can run here"""
+    base = os.path.join(patched_tree, "src", "main", "scala", "org", "apache", "spark")
+    helper = _read(base, "shuffle", "helper", "S3ShuffleHelper.scala")
+    disp = _read(base, "shuffle", "helper", "S3ShuffleDispatcher.scala")
+    shim = "".join(_strip_scala(_read(SHIM, f)) for f in sorted(os.listdir(SHIM)) if f.endswith(".scala"))
+    used_helper = set(re.findall(r"S3ShuffleHelper\.(\w+)", shim))
+    used_disp = set(re.findall(r"\b(?:dispatcher|d|S3ShuffleDispatcher\.get)\.(\w+)", shim)) - {"get"}
+    assert used_helper and used_disp
+    for name in used_helper:
+        assert re.search(r"\bdef %s\b" % name, helper), name
+    for name in used_disp:
+        assert re.search(r"\b(?:val|def|lazy val)\s+%s\b" % name, disp), name
