@@ -179,3 +179,40 @@ def test_reference_members_the_shim_uses_exist(patched_tree):
         assert re.search(r"\bdef %s\b" % name, helper), name
     for name in used_disp:
         assert re.search(r"\b(?:val|def|lazy val)\s+%s\b" % name, disp), name
+
+
+def _call_args(src, start):
+    """number of top-level arguments of the call whose '(' is at src[start]"""
+    depth, args, i, any_tok = 0, 0, start, False
+    while i < len(src):
+        ch = src[i]
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+            if depth == 0:
+                return args + (1 if any_tok else 0)
+        elif ch == "," and depth == 1:
+            args += 1
+        elif depth == 1 and not ch.isspace():
+            any_tok = True
+        i += 1
+    raise AssertionError("unbalanced call")
+
+
+def test_calls_of_the_natives_pass_as_many_arguments_as_they_declare():
+    """every S3SCodec.<native>(...) call in the shim sources against the @native declaration's parameter count"""
+    decl = {}
+    codec = _strip_scala(_read(SHIM, "S3SCodec.scala"))
+    for m in re.finditer(r"@native def (\w+)\(([^)]*)\)", codec, flags=re.S):
+        decl[m.group(1)] = len([p for p in re.split(r",(?![^\[]*\])", m.group(2)) if p.strip()])
+    calls = 0
+    for f in sorted(os.listdir(SHIM)):
+        src = _strip_scala(_read(SHIM, f))
+        for m in re.finditer(r"(?:S3SCodec\.|(?<![\w.]))(%s)\(" % "|".join(decl), src):
+            if f == "S3SCodec.scala" and src[max(0, m.start() - 12):m.start()].rstrip().endswith("def"):
+                continue  # the declaration itself
+            n = _call_args(src, m.end() - 1)
+            assert n == decl[m.group(1)], (f, m.group(1), n, decl[m.group(1)])
+            calls += 1
+    assert calls >= 15
