@@ -11,7 +11,8 @@
  *   reduce side  S3ShuffleReader.read (validation + wrapStream)    storage/S3ShuffleReader.scala:98-110
  *
  * Build (with a JDK):  cc -O2 -fPIC -shared -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -Iinclude \
- *                         jni/s3s_jni.c -Lspark-s3-shuffle_amd/lib -ls3shuffle_codec -o libs3s_jni.so
+ *                         jni/s3s_jni.c -Lspark-s3-shuffle_amd/lib -ls3shuffle_codec -Wl,-rpath,'$ORIGIN' -o libs3shuffle_jni.so
+ *                      (the name spark.shuffle.s3.gpu.library defaults to; libs3shuffle_codec.so next to it)
  * This image has no JDK: tests/test_jni_shim.py compiles the file against tests/mock_jni/jni.h instead, so the
  * signatures stay in step with the header.
  *
