@@ -310,6 +310,29 @@ __global__ __launch_bounds__(kWave) void frames_finish_batch_kernel(LzRange* __r
   }
   if (lane == 0) r.result[1] = total;
   const int64_t comp_base = (int64_t)reinterpret_cast<uintptr_t>(r.comp);
+#ifdef S3S_X_FINISH_WIDE
+  // (experiment for the next round) the rebase is one wavefront per range on the critical path in front of the decode launch
+  // (50 us for four 128 MiB ranges, 3 % of the reduce-side step): four records per lane and iteration, their loads issued
+  // together, instead of one load -> store round trip per record
+  if (!skip) {
+    for (int64_t i0 = 4 * (int64_t)lane; i0 < r.n_frames; i0 += 4 * kWave) {
+      int64_t co[4], fo[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int64_t i = i0 + k < r.n_frames ? i0 + k : r.n_frames - 1;
+        co[k] = r.frames[i].comp_off;
+        fo[k] = __builtin_nontemporal_load(&r.frame_out[i]);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (i0 + k < r.n_frames) {
+          r.frames[i0 + k].comp_off = co[k] + comp_base;
+          r.out_abs[i0 + k] = fo[k] + r.dst_base;
+        }
+    }
+    return;
+  }
+#endif
   for (int64_t i = lane; i < r.n_frames; i += kWave) {
     if (skip) {
       r.frames[i] = Frame{0, 0, 0, 0u, 0x10};

@@ -20,9 +20,20 @@ TILE = 65536
 _PROG = {}
 
 
+FLAGS = ()  # extra hipcc flags of an experiment build (set before the first launch; e.g. ("-DS3S_X_FINISH_WIDE",))
+
+
+def use_flags(flags):
+    """switch to another build of lz4_decompress.hip (drops the cached programs)"""
+    global FLAGS
+    FLAGS = tuple(flags)
+    for k in [k for k in _PROG if k != "sn"]:
+        del _PROG[k]
+
+
 def _program(needle):
     if "text" not in _PROG:
-        _PROG["text"] = lk.compile_asm("lz4_decompress.hip")
+        _PROG["text"] = lk.compile_asm("lz4_decompress.hip", flags=FLAGS)
         _PROG["objs"] = {k: v for k, v in emu.parse_objects(_PROG["text"]).items() if k.startswith("_ZN3s3s")}
     if needle not in _PROG:
         entry = lk.find_kernel(_PROG["text"], needle)

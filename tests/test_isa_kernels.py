@@ -479,6 +479,26 @@ def test_batched_reduce_side_call_through_the_compiled_kernels(oracle):
     assert res[0][1] == srcs[0] and res[3][1] == srcs[1]
 
 
+def test_wide_finish_build_is_the_same_reduce_side(oracle):
+    """-DS3S_X_FINISH_WIDE (kept for the next round's measurement: frames_finish_batch_kernel rebases four records per lane
+    and iteration): the batched reduce-side call gives the same bytes and the same verdicts, frame counts that are not a
+    multiple of four included"""
+    import discover_kernel as dsc
+
+    rng = np.random.default_rng(56)
+    srcs = [corpus.chunk_corpus(7, 300_000, rng).tobytes(), corpus.chunk_corpus(6, 9000, rng).tobytes(), b"",
+            corpus.chunk_corpus(2, 40_000, rng).tobytes()]
+    streams = [oracle.compress_stream(1, np.frombuffer(b, np.uint8)).tobytes() if b else b"" for b in srcs]
+    dsc.use_flags(("-DS3S_X_FINISH_WIDE",))
+    try:
+        res, dec_status = dsc.decode_ranges_batch(streams, [len(b) for b in srcs])
+        assert dec_status == 0 and [st for st, _ in res] == [0] * 4 and [out for _, out in res] == srcs
+        res, _ = dsc.decode_ranges_batch([streams[0], streams[3], streams[1]], [len(srcs[0]), len(srcs[3]) - 1, len(srcs[1])], skip=(2,))
+        assert [st for st, _ in res] == [0, -2, -4] and res[0][1] == srcs[0]
+    finally:
+        dsc.use_flags(())
+
+
 def test_whole_snappy_reduce_side_call_through_the_compiled_kernels(oracle):
     """SnappyOutputStream images: snappy_count / snappy_emit (chunk chains of every partition, concatenated streams) feed the
     compiled batch decoder; chains that end early or run over their partition are S3S_E_BAD_FRAME without leaving the range"""

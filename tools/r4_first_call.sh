@@ -31,7 +31,9 @@ for g in 5120 4096; do
   export S3S_CODEC_LIB=$L/libs3shuffle_codec_exp_decpers.so S3S_DEC_GRID=$g
   echo "decpers grid=$g $(head1 --direction decompress --steps 10 --warmup 3)"
 done
-unset S3S_CODEC_LIB S3S_DEC_GRID
+unset S3S_DEC_GRID
+export S3S_CODEC_LIB=$L/libs3shuffle_codec_exp_finwide.so; echo "finwide  $(head1 --direction decompress --steps 10 --warmup 3)"
+unset S3S_CODEC_LIB
 echo "shipped  $(head1 --direction decompress --steps 10 --warmup 3)"
 echo "== zstd decode: shipped / one bit window per sequence / shipped"
 echo "shipped  $(head1 --workload terasort-10g-200p-zstd --direction decompress --steps 5 --warmup 2)"
