@@ -104,6 +104,31 @@ __device__ __forceinline__ void speculate_tile(const uint8_t* __restrict__ comp,
   if (k == 0) {
     entry = 0;
   } else {
+#ifdef S3S_X_SPEC_UNROLL
+    // (experiment for the next round) 256 positions per step: the four loads of a step are in flight together instead of one
+    // load -> ballot round trip per 64 positions (a tile's first header is ~8 KiB in: ~130 of those round trips today)
+    for (int64_t p0 = t0; p0 < t1 && entry < 0; p0 += 4 * kWave) {
+      uint64_t w[4];
+      bool in[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int64_t p = p0 + u * kWave + lane;
+        in[u] = p < t1 && comp_len - p >= kLz4FrameHeader;
+        w[u] = in[u] ? ld64u(comp + p) : 0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int64_t p = p0 + u * kWave + lane;
+        bool hit = false;
+        if (in[u] && w[u] == kMagic) {
+          const Header hd = parse_header(comp + p);
+          hit = hd.ok && p + kLz4FrameHeader + hd.comp_len <= comp_len;
+        }
+        const uint64_t m = __ballot(hit);
+        if (m && entry < 0) entry = p0 + u * kWave + __builtin_ctzll(m);
+      }
+    }
+#else
     // first plausible header in the tile: 64 positions per step
     for (int64_t p0 = t0; p0 < t1 && entry < 0; p0 += kWave) {
       const int64_t p = p0 + lane;
@@ -115,6 +140,7 @@ __device__ __forceinline__ void speculate_tile(const uint8_t* __restrict__ comp,
       const uint64_t m = __ballot(hit);
       if (m) entry = p0 + __builtin_ctzll(m);
     }
+#endif
   }
   if (lane == 0) {
     int32_t cnt = 0;

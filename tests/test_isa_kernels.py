@@ -479,6 +479,20 @@ def test_batched_reduce_side_call_through_the_compiled_kernels(oracle):
     assert res[0][1] == srcs[0] and res[3][1] == srcs[1]
 
 
+def test_unrolled_speculation_build_is_the_same_discovery(oracle):
+    """-DS3S_X_SPEC_UNROLL (kept for the next round's measurement: the tile speculation looks at 256 positions per step, four
+    loads in flight): every case of the frame-discovery test and of the batched reduce-side test, same answers, no access
+    outside a buffer (the range ends with its last byte: a step's fourth load must not look past it)"""
+    import discover_kernel as dsc
+
+    dsc.use_flags(("-DS3S_X_SPEC_UNROLL",))
+    try:
+        test_compiled_frame_discovery(oracle)
+        test_batched_reduce_side_call_through_the_compiled_kernels(oracle)
+    finally:
+        dsc.use_flags(())
+
+
 def test_wide_finish_build_is_the_same_reduce_side(oracle):
     """-DS3S_X_FINISH_WIDE (kept for the next round's measurement: frames_finish_batch_kernel rebases four records per lane
     and iteration): the batched reduce-side call gives the same bytes and the same verdicts, frame counts that are not a

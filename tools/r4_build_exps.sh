@@ -7,7 +7,7 @@
 #   storent   -DS3S_X_STORE_NT          LZ4 compressor: non-temporal sequence stores (was +-0 before the block prefetch)
 #   setprio   -DS3S_X_SETPRIO          LZ4 compressor: raised issue priority from a window's entry to its candidate gather
 #   decpers   -DS3S_DEC_PERSIST         batch decoder as a persistent grid (S3S_DEC_GRID wavefronts, default 26 per CU)
-#   finwide   -DS3S_X_FINISH_WIDE       batched LZ4 discovery: the rebase in front of the decode launch with four records per lane
+#   finwide   -DS3S_X_FINISH_WIDE -DS3S_X_SPEC_UNROLL   LZ4 frame discovery: rebase with four records per lane, speculation with 256 positions per step
 #   zsfast    -DZS_SEQ_FASTBITS         zstd decoder: one 64-bit bit window per sequence
 set -e
 cd "$(dirname "$0")/../spark-s3-shuffle_amd/csrc"
@@ -21,6 +21,6 @@ make exp EXPNAME=rollpf6k EXPFLAGS='-DS3S_X_ROLL_PREFETCH -DS3S_X_ROLL_DIST=6144
 make exp EXPNAME=rollpfprio EXPFLAGS='-DS3S_X_ROLL_PREFETCH -DS3S_X_SETPRIO' &
 make exp EXPNAME=zsfast EXPFLAGS=-DZS_SEQ_FASTBITS &
 wait
-make exp EXPNAME=finwide EXPFLAGS=-DS3S_X_FINISH_WIDE &
+make exp EXPNAME=finwide EXPFLAGS='-DS3S_X_FINISH_WIDE -DS3S_X_SPEC_UNROLL' &
 wait
 ls -la ../lib/
