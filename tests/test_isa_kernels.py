@@ -99,6 +99,14 @@ def test_issue_priority_build_is_the_same_compressor(oracle):
         elif raised:
             assert not ln.startswith(("s_branch", "s_cbranch", "s_endpgm", "s_setpc")) and not ln.endswith(":"), ln
     assert sum(ln.startswith("s_setprio 2") for ln in lines) == 3 and not raised  # (three copies of the window body)
+    # the same switch in the Snappy block
+    import snappy_kernel as sk
+
+    for c, (slot, sz, w) in zip(chunks, sk.compress_chunks(chunks, flags=("-DS3S_X_SETPRIO",))):
+        assert bytes(slot[32:32 + sz - 4]) == bytes(oracle.snappy_compress_block(c))
+    text = lk.compile_asm("snappy_compress.hip", ("-DS3S_X_SETPRIO",))
+    asm_viol, cc_viol, _, _ = hazards.check_kernel(text, lk.find_kernel(text, "snappy_compress_kernelILb1E"))
+    assert not asm_viol and not cc_viol and sum(ln.strip().startswith("s_setprio 2") for ln in text.splitlines()) == 3
 
 
 def test_lds_race_winner_is_irrelevant(oracle):

@@ -25,6 +25,9 @@ echo "shipped  $(head1)"
 echo "== wide rows LZ4: shipped / rollpf"
 echo "shipped  $(head1 --workload tpcds-wide-100g-200p-lz4)"
 export S3S_CODEC_LIB=$L/libs3shuffle_codec_exp_rollpf.so; echo "rollpf   $(head1 --workload tpcds-wide-100g-200p-lz4)"; unset S3S_CODEC_LIB
+echo "== Snappy wide rows: shipped / setprio"
+echo "shipped  $(head1 --workload tpcds-wide-100g-200p-snappy)"
+export S3S_CODEC_LIB=$L/libs3shuffle_codec_exp_setprio.so; echo "setprio  $(head1 --workload tpcds-wide-100g-200p-snappy --verify)"; unset S3S_CODEC_LIB
 echo "== decoder: shipped / persistent grid (26, 20, 16 wavefronts per CU) / shipped"
 LIBS="decpers" bash tools/r3_dec_quick.sh
 for g in 5120 4096; do
