@@ -197,6 +197,9 @@ def parse_args():
 _GEN_CACHE = {}  # (generator, partitions, map id, bytes) -> host arrays: the secondary passes reuse the headline's inputs
 
 
+_SKEW_CACHE = {}
+
+
 def make_map_output(workload: str, map_id: int, n_bytes: int):
     from s3shuffle import datagen
 
@@ -209,10 +212,26 @@ def make_map_output(workload: str, map_id: int, n_bytes: int):
     elif gen == "tpcds":
         r = datagen.tpcds_wide_map_output(n_bytes, nparts, seed=3, map_id=map_id)
     else:
-        r = datagen.skew_block(n_bytes, "terasort", seed=5, map_id=map_id)
+        # single-partition blocks are a prefix of the same record stream (records are generated by index): the block-size
+        # sweep slices the largest block generated so far for this map task instead of regenerating it
+        big = _SKEW_CACHE.get(map_id)
+        if big is None or big.size < n_bytes:
+            big = datagen.skew_block(n_bytes, "terasort", seed=5, map_id=map_id)[0]
+            _SKEW_CACHE[map_id] = big
+        return big[:n_bytes], np.array([0, n_bytes], dtype=np.int64)
     if n_bytes <= (256 << 20):
         _GEN_CACHE[key] = r
     return r
+
+
+def _kernel_stamp():
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from src_stamp import kernel_sources_sha256
+
+        return kernel_sources_sha256(ROOT)
+    except Exception:
+        return None
 
 
 def usable_cores() -> int:
@@ -231,6 +250,18 @@ def usable_cores() -> int:
     return n
 
 
+_LIB_NAMES = {
+    "lz4": ("liblz4 1.9.3 LZ4_compress_default (the code lz4-java JNI binds)", "liblz4 1.9.3 LZ4_decompress_safe (the code lz4-java JNI binds)"),
+    "snappy": ("libsnappy 1.1.8 snappy_compress (the C++ code snappy-java binds, there in version 1.1.10)",
+               "libsnappy 1.1.8 snappy_uncompress (the C++ code snappy-java binds, there in version 1.1.10)"),
+}
+
+
+def _simd_names(simd: int) -> str:
+    return ("CRC32 by PCLMULQDQ folding" if simd & 1 else "CRC32 slice-by-8") + " / " + \
+           ("Adler32 by SSSE3 PSADBW+PMADDUBSW" if simd & 2 else "Adler32 byte loop") + " (the JVM runs both as intrinsics)"
+
+
 def cpu_baseline(workload: str, target_s: float, map_mib: int = 128):
     """The CPU path timed beside the GPU one: one map task per host thread (how Spark runs the
     reference: one task per executor core), each doing LZ4Block framing around liblz4 1.9.3's
@@ -244,7 +275,8 @@ def cpu_baseline(workload: str, target_s: float, map_mib: int = 128):
     data, offs = make_map_output(workload, 0, sample_mib << 20)
     algo_id = {"adler32": oracle.CHECKSUM_ADLER32, "crc32": oracle.CHECKSUM_CRC32}[algo]
     codec_o = oracle.CODEC_LZ4 if codec == "lz4" else oracle.CODEC_SNAPPY
-    have_liblz4 = bool(oracle.lib().s3o_mt_have_liblz4()) and codec == "lz4"
+    have_lib = bool(oracle.lib().s3o_mt_have_liblz4()) if codec == "lz4" else bool(oracle.lib().s3o_mt_have_libsnappy())
+    simd = int(oracle.lib().s3o_simd_available())
     # calibrate with one rep, then size the run to ~target_s
     s1, _ = oracle.mt_compress_bench(codec_o, algo_id, data, offs, cores, reps=1)
     reps = max(1, min(400, int(target_s / max(s1, 1e-3))))
@@ -253,10 +285,11 @@ def cpu_baseline(workload: str, target_s: float, map_mib: int = 128):
     t1, _ = oracle.mt_compress_bench(codec_o, algo_id, data, offs, 1, reps=2)
     one = data.size * 2 / t1 / 1e9
     return {
-        "value": round(value, 3), "unit": "GB/s", "cores": cores, "kind": "port",
+        "value": round(value, 3), "unit": "GB/s", "cores": cores, "kind": "reference-lib" if have_lib else "port",
         "sample": f"{cores} threads x {reps} reps x one whole {sample_mib} MiB map task of the workload "
                   f"({parts} partitions), {codec}+{algo}, map-side compress+checksum; block compressor = "
-                  f"{'liblz4 1.9.3 LZ4_compress_default (the code lz4-java JNI binds)' if have_liblz4 else 'oracle restatement'}; "
+                  f"{_LIB_NAMES[codec][0] if have_lib else 'oracle restatement'}; checksums = {_simd_names(simd)}; "
+                  f"framing / index by oracle/s3s_oracle_mt.c; "
                   f"JVM/JNI overheads not included (upper bound on the reference path); "
                   f"os.cpu_count()={os.cpu_count()}, cgroup/affinity limit={cores}",
         "single_thread_GBps": round(one, 3), "wall_s": round(s, 2),
@@ -278,6 +311,8 @@ def cpu_baseline_decompress(workload: str, target_s: float, map_mib: int = 128):
     algo_id = {"adler32": oracle.CHECKSUM_ADLER32, "crc32": oracle.CHECKSUM_CRC32}[algo]
     codec_o = oracle.CODEC_LZ4 if codec == "lz4" else oracle.CODEC_SNAPPY
     img, index, sums = oracle.compress_map_output(codec_o, algo_id, data, offs)
+    have_lib = bool(oracle.lib().s3o_mt_have_liblz4()) if codec == "lz4" else bool(oracle.lib().s3o_mt_have_libsnappy())
+    simd = int(oracle.lib().s3o_simd_available())
     s1, n = oracle.mt_decompress_bench(codec_o, algo_id, img, index, sums, data.size, cores, reps=1)
     if s1 < 0 or n != data.size:
         return None
@@ -285,10 +320,10 @@ def cpu_baseline_decompress(workload: str, target_s: float, map_mib: int = 128):
     s, _ = oracle.mt_decompress_bench(codec_o, algo_id, img, index, sums, data.size, cores, reps=reps)
     t1, _ = oracle.mt_decompress_bench(codec_o, algo_id, img, index, sums, data.size, 1, reps=4)
     return {
-        "value": round(data.size * cores * reps / s / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
+        "value": round(data.size * cores * reps / s / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "reference-lib" if have_lib else "port",
         "sample": f"{cores} threads x {reps} reps x one whole {sample_mib} MiB map task of the workload ({parts} partitions), "
                   f"{codec}+{algo}, reduce-side verify+decompress; block decoder = "
-                  f"{'liblz4 1.9.3 LZ4_decompress_safe (the code lz4-java JNI binds)' if codec == 'lz4' else 'oracle restatement'}; "
+                  f"{_LIB_NAMES[codec][1] if have_lib else 'oracle restatement'}; checksums = {_simd_names(simd)}; "
                   f"JVM/JNI overheads not included; os.cpu_count()={os.cpu_count()}, cgroup/affinity limit={cores}",
         "single_thread_GBps": round(data.size * 4 / t1 / 1e9, 3), "wall_s": round(s, 2),
     }
@@ -513,6 +548,20 @@ def run_workload(args, rank: int, local_rank: int, world: int, dist):
 
     u_rank = sum(t["u"] for t in tasks)
     c_rank = sum(comp_bytes)
+    elapsed_rank = elapsed
+    per_rank = [{"rank": rank, "device": local_rank, "elapsed_s": round(elapsed_rank, 5),
+                 "GBps": round(u_rank * args.steps / elapsed_rank / 1e9, 3), "map_tasks": len(tasks)}]
+    rccl_ranks = 1
+    if dist:
+        rccl_ranks = int(dist.get_world_size())
+        # per-rank balance for the scaling record: every rank's own elapsed time and bytes, gathered with
+        # one all_gather of three doubles per rank — after the timed region, so it costs the measurement nothing
+        mine = torch.tensor([float(elapsed_rank), float(u_rank), float(len(tasks))], dtype=torch.float64, device=dev)
+        allr = [torch.zeros(3, dtype=torch.float64, device=dev) for _ in range(rccl_ranks)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": r, "device": r % max(torch.cuda.device_count(), 1), "elapsed_s": round(float(v[0]), 5),
+                     "GBps": round(float(v[1]) * args.steps / max(float(v[0]), 1e-9) / 1e9, 3), "map_tasks": int(v[2])}
+                    for r, v in enumerate(allr)]
     if dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -547,6 +596,8 @@ def run_workload(args, rank: int, local_rank: int, world: int, dist):
             "value": round(value, 3),
             "unit": "GB/s",
             "n_gpus": world,
+            "rccl_ranks": rccl_ranks if dist else 0,  # ranks the RCCL process group saw (0 = plain `python bench.py`, no group)
+            "per_rank": per_rank,                      # each rank's own clock over its own map tasks (value uses the MAX)
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -609,8 +660,13 @@ def run_workload(args, rank: int, local_rank: int, world: int, dist):
                 out["speedup_vs_cpu_1_core"] = round(value / cb["single_thread_GBps"], 3)
         else:
             out["cpu_baseline"] = None
-        # roofline.traffic is HBM bytes per launch from PMC counters — only when THIS run was the profiled one (the
-        # profiling script passes the figure in); otherwise null, with a pointer to the tracked PMC pass
+        # roofline.traffic = HBM bytes per launch of the dominant kernel from the PMC counters (2 x FETCH_SIZE + WRITE_SIZE KB,
+        # gfx950 correction as in tools/r3_report.py).  Counters cannot be collected inside a timed run (rocprofv3 serialises
+        # the kernels), so the figure comes from the tracked PMC pass of the SAME kernels: profiles/traffic_latest.json names
+        # the sha256 of the kernel sources each entry was taken with, and it is used only when that equals the stamp of the
+        # sources this library was built from (tools/src_stamp.py); otherwise traffic stays null and the entry is only cited.
+        stamp = _kernel_stamp()
+        out["kernel_sources_sha256"] = stamp
         if os.environ.get("S3S_BENCH_TRAFFIC_BYTES"):
             out["roofline"]["traffic"] = int(os.environ["S3S_BENCH_TRAFFIC_BYTES"])
             out["roofline"]["traffic_source"] = os.environ.get("S3S_BENCH_TRAFFIC_SOURCE", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command")
@@ -621,7 +677,15 @@ def run_workload(args, rank: int, local_rank: int, world: int, dist):
                     ref = json.load(open(traffic_file))
                     key = f"{args.workload}:{args.direction}"
                     if key in ref:
-                        out["roofline"]["traffic_reference"] = dict(ref[key], note="PMC pass of an earlier profiled run of this workload (tracked under profiles/); not measured by this run")
+                        e = ref[key]
+                        if stamp and e.get("kernel_sources_sha256") == stamp and e.get("map_tasks_per_launch"):
+                            out["roofline"]["traffic"] = int(e["hbm_bytes_per_launch"] * tasks_per_launch / e["map_tasks_per_launch"])
+                            out["roofline"]["traffic_over_algorithmic"] = round(out["roofline"]["traffic"] / max(alg_bytes, 1.0), 3)
+                            out["roofline"]["traffic_source"] = (
+                                f"{e.get('source')}; PMC pass of the same kernel sources (sha256 {stamp[:12]}), "
+                                f"{e['map_tasks_per_launch']} map task(s) per profiled launch scaled to {tasks_per_launch}")
+                        else:
+                            out["roofline"]["traffic_reference"] = dict(e, note="PMC pass of OTHER kernel sources than this run's (tracked under profiles/); not used as traffic")
                 except Exception:
                     pass
     for c in codecs:
@@ -675,7 +739,13 @@ def run_secondaries(args, rank: int, local_rank: int):
             "speedup_vs_cpu_all_cores": o.get("speedup_vs_cpu_all_cores"),
             "wall_s": round(time.perf_counter() - t0, 2),
         }
-        _GEN_CACHE.pop(("skew", 1, 0, mib << 20), None)
+    t0 = time.perf_counter()
+    try:
+        res["block_size_sweep"] = run_block_size_sweep(args, rank, local_rank, res)
+        res["block_size_sweep"]["wall_s"] = round(time.perf_counter() - t0, 2)
+    except Exception as e:
+        res["block_size_sweep"] = {"error": repr(e)}
+    _SKEW_CACHE.clear()
     t0 = time.perf_counter()
     try:
         res["host_path"] = run_host_path(args, local_rank)
@@ -683,6 +753,39 @@ def run_secondaries(args, rank: int, local_rank: int):
     except Exception as e:
         res["host_path"] = {"error": repr(e)}
     res["wall_s_total"] = round(time.perf_counter() - t_all, 2)
+    return res
+
+
+SWEEP = [(8, 8), (32, 8), (128, 8), (512, 2), (1024, 1)]  # (MiB per single-partition block, blocks per step)
+
+
+def run_block_size_sweep(args, rank: int, local_rank: int, have: dict):
+    """north_star: "GB/s on synthetic 8 MiB-1 GiB shuffle blocks" (sweep 8 / 32 / 128 / 512 / 1024 MiB).  Single-
+    partition TeraSort blocks resident in HBM, both directions, the batched entry points, 3 timed steps after 1 warmup, no
+    CPU leg.  8 MiB is the reference's default write buffer (S3ShuffleDispatcher.scala:55): the common case is the small end.
+    `have`: results of the secondary passes that already ran one of these points (the 1 GiB block)."""
+    import copy
+
+    res = {"what": "single-partition TeraSort blocks in HBM, LZ4 + Adler32; GB/s of uncompressed bytes; 3 timed steps, 1 warmup",
+           "unit": "GB/s", "points": []}
+    for mib, maps in SWEEP:
+        point = {"block_MiB": mib, "blocks_per_step": maps}
+        for direction in ("compress", "decompress"):
+            prior = have.get(f"skew-1gib-lz4:{direction}") if mib == 1024 else None
+            if prior and "value" in prior:
+                point[direction], point[direction + "_ms_per_step"] = prior["value"], prior["ms_per_step"]
+                continue
+            a = copy.copy(args)
+            a.workload, a.direction, a.map_mib, a.maps_per_gpu = "skew-1part-lz4", direction, mib, maps
+            a.steps, a.warmup, a.task_threads, a.batch, a.verify, a.no_cpu_baseline = 3, 1, 0, -1, False, True
+            try:
+                o = run_workload(a, rank, local_rank, 1, None)
+                point[direction], point[direction + "_ms_per_step"] = o["value"], o["ms_per_step"]
+                point[direction + "_task_threads"] = o["config"]["task_threads_per_gpu"]
+            except Exception as e:
+                point[direction] = None
+                point[direction + "_error"] = repr(e)
+        res["points"].append(point)
     return res
 
 

@@ -66,11 +66,13 @@
 extern "C" {
 #endif
 
-#define S3S_ABI_VERSION 5 /* 2: + segments entry points, page-locked staging, tuning options 6, 7;
+#define S3S_ABI_VERSION 6 /* 2: + segments entry points, page-locked staging, tuning options 6, 7;
                              3: + s3s_compress_map_outputs_batch_device;
                              4: + s3s_decompress_ranges_batch_device; decode variants {3, 4}, LZ4 parses {1, 9, 10};
                              5: + s3s_compress_map_outputs_batch / s3s_decompress_ranges_batch (host buffers),
-                                S3S_CODEC_ZSTD on the reduce side */
+                                S3S_CODEC_ZSTD on the reduce side;
+                             6: S3S_STATUS_NOT_RUN in the per-entry status of the batched calls (a call-level failure is told
+                                apart from an entry's own verdict) */
 
 /* spark.io.compression.codec (only when spark.shuffle.compress=true) */
 enum { S3S_CODEC_NONE = 0, S3S_CODEC_LZ4 = 1, S3S_CODEC_SNAPPY = 2,
@@ -88,7 +90,11 @@ enum {
   S3S_E_CHECKSUM = -4,    /* SparkException("Invalid checksum detected for ...") */
   S3S_E_HIP = -5,         /* HIP runtime / device failure */
   S3S_E_UNSUPPORTED = -6, /* e.g. block size outside the supported range */
-  S3S_E_NOMEM = -7
+  S3S_E_NOMEM = -7,
+  S3S_STATUS_NOT_RUN = -100 /* only ever in s3s_map_task.status / s3s_fetch_range.status: every entry of a batch is stamped
+                               with it on entry to the call, so that after a CALL-level failure (bad argument, HIP error
+                               before or between the tasks) the entries the library never finished are told apart from the
+                               ones that have their own verdict; the call's return code applies to exactly these */
 };
 
 /* option keys for s3s_set_option / s3s_get_option */
@@ -175,7 +181,8 @@ int s3s_compress_map_output_device(s3s_ctx* ctx, int codec, int checksum_algo,
  * synchronisation for the batch.  Every task gets exactly the bytes, index and checksums
  * s3s_compress_map_output_device would have produced for it alone.  One codec stream per
  * non-empty partition (no multi-spill pieces in the batched form).
- * Returns S3S_OK, or the first failing task's error; each task's own result is in .status.   */
+ * Returns S3S_OK, or the first failing task's error; each task's own result is in .status
+ * (S3S_STATUS_NOT_RUN = the call failed before this task had a result: the return code is its error). */
 typedef struct s3s_map_task {
   const uint8_t* d_src;         /* in: device memory holding this task's partitions */
   const int64_t* src_offsets;   /* in: host array [num_partitions + 1], offsets into d_src */
@@ -185,7 +192,7 @@ typedef struct s3s_map_task {
   int64_t* out_index;           /* out: host array [num_partitions + 1] */
   int64_t* out_checksums;       /* out: host array [num_partitions] (may be NULL iff checksum NONE) */
   int64_t out_total;            /* out: bytes of the .data image */
-  int32_t status;               /* out: S3S_OK / S3S_E_CAPACITY for this task */
+  int32_t status;               /* out: S3S_OK / S3S_E_CAPACITY for this task; S3S_STATUS_NOT_RUN: see the enum */
 } s3s_map_task;
 int s3s_compress_map_outputs_batch_device(s3s_ctx* ctx, int codec, int checksum_algo,
                                           s3s_map_task* tasks, int32_t n_tasks);
@@ -240,7 +247,7 @@ typedef struct s3s_fetch_range {
   int64_t dst_capacity;          /* in */
   int64_t out_len;               /* out: decoded bytes */
   int32_t bad_partition;         /* out: first partition with a wrong checksum, or -1 */
-  int32_t status;                /* out: S3S_OK / S3S_E_CHECKSUM / S3S_E_BAD_FRAME / S3S_E_CAPACITY / ... */
+  int32_t status;                /* out: S3S_OK / S3S_E_CHECKSUM / S3S_E_BAD_FRAME / S3S_E_CAPACITY / ...; S3S_STATUS_NOT_RUN: see the enum */
 } s3s_fetch_range;
 int s3s_decompress_ranges_batch_device(s3s_ctx* ctx, int codec, int checksum_algo,
                                        s3s_fetch_range* ranges, int32_t n_ranges);

@@ -172,6 +172,20 @@ JNIEXPORT jint JNICALL FN(compressMapOutputsBatch)(JNIEnv* e, jclass c, jlong h,
   const jsize n = (*e)->GetArrayLength(e, src);
   if (same_length(e, n, srcOffsets, dst, dstCap, outIndex, outTotal, outStatus, outChecksums, NULL) != 0) return S3S_E_INVALID;
   if ((*e)->EnsureLocalCapacity(e, 3 * n + 8) != 0) return S3S_E_NOMEM; /* three array references per task stay live over the call */
+  /* the inner arrays against the partition count srcOffsets[i] implies (advisor r3: a short outIndex[i] / outChecksums[i]
+   * would let the library write past a pinned JVM array) - checked before anything is pinned */
+  for (jsize i = 0; i < n; i++) {
+    jlongArray so = (jlongArray)(*e)->GetObjectArrayElement(e, srcOffsets, i);
+    jlongArray oi = (jlongArray)(*e)->GetObjectArrayElement(e, outIndex, i);
+    jlongArray oc = outChecksums ? (jlongArray)(*e)->GetObjectArrayElement(e, outChecksums, i) : NULL;
+    const jsize np1 = so ? (*e)->GetArrayLength(e, so) : 0;
+    const int bad = so && (np1 < 1 || !oi || (*e)->GetArrayLength(e, oi) < np1 ||
+                           (outChecksums && algo != S3S_CHECKSUM_NONE && np1 > 1 && (!oc || (*e)->GetArrayLength(e, oc) < np1 - 1)));
+    if (so) (*e)->DeleteLocalRef(e, so);
+    if (oi) (*e)->DeleteLocalRef(e, oi);
+    if (oc) (*e)->DeleteLocalRef(e, oc);
+    if (bad) return S3S_E_INVALID;
+  }
   s3s_map_task* t = (s3s_map_task*)calloc((size_t)(n > 0 ? n : 1), sizeof *t);
   jlongArray* arrs = (jlongArray*)calloc((size_t)(n > 0 ? n : 1) * 3, sizeof *arrs);
   if (!t || !arrs) {
@@ -199,6 +213,7 @@ JNIEXPORT jint JNICALL FN(compressMapOutputsBatch)(JNIEnv* e, jclass c, jlong h,
     t[i].out_index = (int64_t*)pin(e, oi);
     t[i].out_checksums = (int64_t*)pin(e, oc);
   }
+  for (jsize i = 0; i < n; i++) t[i].status = S3S_STATUS_NOT_RUN; /* (a return before the library's own stamp must not read as S3S_OK) */
   const int rc = s3s_compress_map_outputs_batch(CTX(h), codec, algo, t, (int32_t)n);
   for (jsize i = 0; i < n; i++) {
     tot[i] = t[i].out_total;
@@ -228,6 +243,15 @@ JNIEXPORT jint JNICALL FN(decompressRangesBatch)(JNIEnv* e, jclass c, jlong h, j
   if (same_length(e, n, compLen, partOffsets, dst, dstCap, outLen, outBadPartition, outStatus, refChecksums, NULL) != 0)
     return S3S_E_INVALID;
   if ((*e)->EnsureLocalCapacity(e, 2 * n + 8) != 0) return S3S_E_NOMEM;
+  for (jsize i = 0; i < n; i++) { /* refChecksums[i] must cover the partitions partOffsets[i] names */
+    jlongArray po = (jlongArray)(*e)->GetObjectArrayElement(e, partOffsets, i);
+    jlongArray rs = refChecksums ? (jlongArray)(*e)->GetObjectArrayElement(e, refChecksums, i) : NULL;
+    const jsize np1 = po ? (*e)->GetArrayLength(e, po) : 0;
+    const int bad = po && (np1 < 1 || (refChecksums && algo != S3S_CHECKSUM_NONE && np1 > 1 && (!rs || (*e)->GetArrayLength(e, rs) < np1 - 1)));
+    if (po) (*e)->DeleteLocalRef(e, po);
+    if (rs) (*e)->DeleteLocalRef(e, rs);
+    if (bad) return S3S_E_INVALID;
+  }
   s3s_fetch_range* r = (s3s_fetch_range*)calloc((size_t)(n > 0 ? n : 1), sizeof *r);
   jlongArray* arrs = (jlongArray*)calloc((size_t)(n > 0 ? n : 1) * 2, sizeof *arrs);
   if (!r || !arrs) {
@@ -253,6 +277,7 @@ JNIEXPORT jint JNICALL FN(decompressRangesBatch)(JNIEnv* e, jclass c, jlong h, j
     r[i].num_partitions = po ? (int32_t)((*e)->GetArrayLength(e, po) - 1) : -1;
     r[i].dst_capacity = cap[i];
   }
+  for (jsize i = 0; i < n; i++) r[i].status = S3S_STATUS_NOT_RUN;
   const int rc = s3s_decompress_ranges_batch(CTX(h), codec, algo, r, (int32_t)n);
   for (jsize i = 0; i < n; i++) {
     ol[i] = r[i].out_len;

@@ -72,6 +72,19 @@ def lib() -> ctypes.CDLL:
     L.s3o_mt_decompress_bench.argtypes = [i32, i32, i32, vp, i64, vp, vp, ctypes.c_int32, i64, i32, i32, vp]
     L.s3o_mt_stream_liblz4.restype = i64
     L.s3o_mt_stream_liblz4.argtypes = [vp, i64, i32, vp]
+    L.s3o_mt_have_libsnappy.restype = i32
+    L.s3o_mt_stream_libsnappy.restype = i64
+    L.s3o_mt_stream_libsnappy.argtypes = [vp, i64, i32, vp]
+    L.s3o_mt_decode_libsnappy.restype = i64
+    L.s3o_mt_decode_libsnappy.argtypes = [vp, i64, vp, i64]
+    L.s3o_crc32_fast.restype = u32
+    L.s3o_crc32_fast.argtypes = [u32, vp, ctypes.c_size_t]
+    L.s3o_adler32_fast.restype = u32
+    L.s3o_adler32_fast.argtypes = [u32, vp, ctypes.c_size_t]
+    L.s3o_checksum_fast.restype = i64
+    L.s3o_checksum_fast.argtypes = [i32, vp, ctypes.c_size_t]
+    L.s3o_simd_available.restype = i32
+    L.s3o_simd_crc_constants.argtypes = [vp]
     _LIB = L
     return L
 
@@ -92,6 +105,21 @@ def xxh32(data, seed: int = 0x9747B28C) -> int:
 def checksum(algo: int, data) -> int:
     d = _u8(data)
     return int(lib().s3o_checksum(algo, d.ctypes.data, d.size))
+
+
+def checksum_fast(algo: int, data, init: Optional[int] = None) -> int:
+    """the cpu_baseline's checksums (s3s_oracle_simd.c: PCLMULQDQ CRC32 / SSSE3 Adler32); init = running value"""
+    d = _u8(data)
+    if init is None:
+        return int(lib().s3o_checksum_fast(algo, d.ctypes.data, d.size))
+    f = lib().s3o_adler32_fast if algo == CHECKSUM_ADLER32 else lib().s3o_crc32_fast
+    return int(f(init, d.ctypes.data, d.size))
+
+
+def simd_crc_constants():
+    k = (ctypes.c_uint64 * 7)()
+    lib().s3o_simd_crc_constants(k)
+    return [int(x) for x in k]
 
 
 def lz4_compress_block(data) -> np.ndarray:

@@ -63,6 +63,12 @@ uint32_t s3o_crc32(uint32_t crc, const void* data, size_t len);
 uint32_t s3o_adler32(uint32_t adler, const void* data, size_t len);
 /* the value java.util.zip.{Adler32,CRC32}.getValue() would return over data[0,len) */
 int64_t s3o_checksum(int algo, const void* data, size_t len);
+/* s3s_oracle_simd.c: the same three functions at the speed of the JVM's intrinsics (carry-less-multiply CRC32, SSSE3 Adler32);
+ * used by the cpu_baseline driver only, pinned against the restatement and zlib by tests/test_oracle_pins.py */
+uint32_t s3o_crc32_fast(uint32_t crc, const void* data, size_t len);
+uint32_t s3o_adler32_fast(uint32_t adler, const void* data, size_t len);
+int64_t s3o_checksum_fast(int algo, const void* data, size_t len);
+int s3o_simd_available(void); /* bit 0: PCLMULQDQ CRC32 in use, bit 1: SSSE3 Adler32 in use */
 
 /* ---- raw LZ4 block ------------------------------------------------------------------ */
 /* LZ4_compressBound */

@@ -68,8 +68,10 @@ object S3GpuCommitQueue {
         var i = 0
         while (i < n) {
           same(i).total = totals(i)
-          // a call-level failure (HIP error, bad argument) fails every request of the call; otherwise each has its own status
-          same(i).rc = if (rc != S3SCodec.OK && status(i) == S3SCodec.OK && rc != S3SCodec.E_CAPACITY) rc else status(i)
+          // every task has its own verdict; the call's return code belongs to exactly the tasks the library never finished
+          // (S3S_STATUS_NOT_RUN: a call-level failure - HIP error, bad argument - before or between the tasks), so one task's
+          // corrupt input or short buffer never fails its neighbours (advisor r3)
+          same(i).rc = if (status(i) == S3SCodec.STATUS_NOT_RUN) (if (rc != S3SCodec.OK) rc else S3SCodec.E_HIP) else status(i)
           same(i).error = why
           i += 1
         }
@@ -91,10 +93,22 @@ object S3GpuCommitQueue {
     w
   }
 
-  /** Blocks the task thread until its request has been compressed (possibly together with other tasks' requests). */
+  /** Blocks the task thread until its request has been compressed (possibly together with other tasks' requests).
+   *  The wait is UNINTERRUPTIBLE on purpose (advisor r3): Spark interrupts task threads on kill and on speculation, and an
+   *  InterruptedException here would unwind S3GpuMapOutput.flush, whose `finally` hands `dst` back to the buffer pool (and
+   *  commit / abort releases `src`) while the worker thread is still inside s3s_compress_map_outputs_batch - DMA-reading
+   *  `src` and writing `dst`.  Another task could then be given those page-locked buffers and have them overwritten by the
+   *  late download.  So the buffers stay owned by this call until the native call has returned; the interrupt is remembered
+   *  and re-raised on the thread afterwards, where the task's own cancellation checks see it. */
   def compress(device: Int, r: Request): Request = {
     worker(device).queue.put(r)
-    r.done.await()
+    var interrupted = false
+    var finished = false
+    while (!finished) {
+      try { r.done.await(); finished = true }
+      catch { case _: InterruptedException => interrupted = true }
+    }
+    if (interrupted) Thread.currentThread().interrupt()
     r
   }
 }

@@ -26,8 +26,9 @@ object S3SCodec {
   val CODEC_ZSTD = 3 // reduce side only (decompressRange*, decompressedSize); the shipped patch keeps zstd jobs on the JVM, INTEGRATION.md
   val CHECKSUM_NONE = 0; val CHECKSUM_ADLER32 = 1; val CHECKSUM_CRC32 = 2
   val OK = 0; val E_INVALID = -1; val E_CAPACITY = -2; val E_BAD_FRAME = -3; val E_CHECKSUM = -4; val E_HIP = -5
+  val STATUS_NOT_RUN = -100 // per-entry status of a batch call that failed before this entry had a verdict: the call's return code is its error
   val OPT_LZ4_BLOCK_SIZE = 1; val OPT_SNAPPY_BLOCK_SIZE = 2
-  val ABI_VERSION = 5
+  val ABI_VERSION = 6
 
   // ---- native entry points (jni/s3s_jni.c, one line each) -------------------------------------------------------
   @native def abiVersion(): Int
@@ -77,14 +78,37 @@ object S3SCodec {
     }
   }
 
-  /** A context is not thread-safe: one per task thread and device, kept for the life of the executor. */
+  /** A context is not thread-safe: one per task thread and device.  Executor task threads come from a cached pool and die
+    * after idling, so every context is registered with its owning thread and destroyed once that thread is gone (advisor r3:
+    * a leaked context keeps device workspace, pinned staging and four 64-128 MiB pipeline buffers).  The reaping runs on the
+    * thread that is about to create a context — never concurrently with the dead owner, so no native call is in flight. */
   private val contexts = new ThreadLocal[scala.collection.mutable.Map[Int, Long]] {
     override def initialValue() = scala.collection.mutable.Map.empty[Int, Long]
   }
+  private val owners = new java.util.concurrent.ConcurrentHashMap[java.lang.Long, java.lang.ref.WeakReference[Thread]]()
+
+  /** destroys the contexts of task threads that no longer exist; returns how many went */
+  def reapDeadThreads(): Int = {
+    var n = 0
+    val it = owners.entrySet().iterator()
+    while (it.hasNext) {
+      val e = it.next()
+      val t = e.getValue.get()
+      if ((t == null || !t.isAlive) && owners.remove(e.getKey, e.getValue)) { destroy(e.getKey); n += 1 }
+    }
+    n
+  }
+
+  /** live contexts (all devices): what spark.shuffle.s3.gpu.maxContexts bounds */
+  def liveContexts: Int = owners.size()
 
   def forThread(device: Int): Long = contexts.get().getOrElseUpdate(device, {
     val d = org.apache.spark.shuffle.helper.S3ShuffleDispatcher.get
     load(d.gpuLibrary)
+    reapDeadThreads()
+    if (owners.size() >= d.gpuMaxContexts)
+      throw new IOException(s"more than ${d.gpuMaxContexts} GPU codec contexts alive (spark.shuffle.s3.gpu.maxContexts): " +
+        "task threads x devices; raise the key or lower spark.executor.cores")
     val h = create(device, 0L)
     if (h == 0L) throw new IOException(s"s3s_create($device) failed: no HIP device (there is no CPU fallback)")
     // the JVM codecs' chunk sizes (spark.io.compression.{lz4,snappy}.blockSize): the objects must look like theirs
@@ -93,6 +117,7 @@ object S3SCodec {
       destroy(h)
       throw new IllegalArgumentException(s"codec block size not supported by the GPU path: $why")
     }
+    owners.put(h, new java.lang.ref.WeakReference[Thread](Thread.currentThread()))
     h
   })
 

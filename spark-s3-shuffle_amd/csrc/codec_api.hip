@@ -489,6 +489,7 @@ int s3s_compress_map_outputs_batch_device(s3s_ctx* ctx, int codec, int checksum_
   if (codec == S3S_CODEC_SNAPPY && !snappy_compress_available())
     return fail(ctx, S3S_E_UNSUPPORTED, "snappy compression is not available in this build");
   if (n_tasks == 0) return S3S_OK;
+  BatchVerdict<s3s_map_task> verdict(tasks, n_tasks);
   if (codec == S3S_CODEC_NONE) {  // nothing to batch: plain copies
     int worst = S3S_OK;
     for (int32_t t = 0; t < n_tasks; t++) {
@@ -497,7 +498,7 @@ int s3s_compress_map_outputs_batch_device(s3s_ctx* ctx, int codec, int checksum_
                                                 k.d_dst, k.dst_capacity, k.out_index, k.out_checksums, &k.out_total);
       if (k.status != S3S_OK && worst == S3S_OK) worst = k.status;
     }
-    return worst;
+    return verdict.finish(worst);
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int64_t bs = effective_block(ctx, codec);
@@ -679,7 +680,7 @@ int s3s_compress_map_outputs_batch_device(s3s_ctx* ctx, int codec, int checksum_
     if (checksum_algo != S3S_CHECKSUM_NONE && k.num_partitions > 0)
       memcpy(k.out_checksums, h_sums + first_part[(size_t)t], sizeof(int64_t) * (size_t)k.num_partitions);
   }
-  return worst;
+  return verdict.finish(worst);
 }
 
 int64_t s3s_max_compressed_size_segments(const s3s_ctx* ctx, int codec, const int64_t* seg_offsets, int32_t n_segs) {

@@ -426,9 +426,10 @@ extern "C" int s3s_decompress_ranges_batch_device(s3s_ctx* ctx, int codec, int c
     return S3S_OK;
   };
   if (n_ranges == 0) return S3S_OK;
+  BatchVerdict<s3s_fetch_range> verdict(R, n_ranges);
   if (codec == S3S_CODEC_NONE || n_ranges == 1) {  // nothing to batch
     for (int32_t r = 0; r < n_ranges; r++) single(R[r]);
-    return first_error();
+    return verdict.finish(first_error());
   }
   // ---- validate, count ------------------------------------------------------------------------------------------
   int64_t n_parts = 0, n_segs = 0;
@@ -709,5 +710,5 @@ extern "C" int s3s_decompress_ranges_batch_device(s3s_ctx* ctx, int codec, int c
     for (int32_t r = 0; r < n_ranges; r++)
       if (R[r].status == S3S_OK) single(R[r]);
   }
-  return first_error();
+  return verdict.finish(first_error());
 }

@@ -70,6 +70,8 @@ int s3s_compress_map_outputs_batch(s3s_ctx* ctx, int codec, int checksum_algo, s
   ctx->err[0] = 0;
   if (n_tasks < 0 || (n_tasks > 0 && !tasks)) return fail(ctx, S3S_E_INVALID, "null task array or negative count");
   if (n_tasks == 0) return S3S_OK;
+  BatchVerdict<s3s_map_task> verdict(tasks, n_tasks);  // (a call-level failure leaves NOT_RUN marks: the return code is theirs)
+  for (int32_t t = 0; t < n_tasks; t++) tasks[t].out_total = 0;
   std::vector<int64_t> u((size_t)n_tasks), cap((size_t)n_tasks);
   for (int32_t t = 0; t < n_tasks; t++) {
     const s3s_map_task& k = tasks[t];
@@ -87,7 +89,7 @@ int s3s_compress_map_outputs_batch(s3s_ctx* ctx, int codec, int checksum_algo, s
     s3s_map_task& k = tasks[0];
     k.status = s3s_compress_map_output(ctx, codec, checksum_algo, k.d_src, k.src_offsets, k.num_partitions, k.d_dst,
                                        k.dst_capacity, k.out_index, k.out_checksums, &k.out_total);
-    return k.status;
+    return verdict.finish(k.status);
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   int rc;
@@ -177,7 +179,7 @@ int s3s_compress_map_outputs_batch(s3s_ctx* ctx, int codec, int checksum_algo, s
   HIP_TRY(ctx, hipStreamSynchronize(ctx->hb_out));
   if (ctx->profile)
     for (int s = 0; s < S3S_STAGE_COUNT; s++) ctx->stage_ms[s] = stage_acc[s];  // summed over the groups
-  return worst;
+  return verdict.finish(worst);
 }
 
 int s3s_decompress_ranges_batch(s3s_ctx* ctx, int codec, int checksum_algo, s3s_fetch_range* ranges, int32_t n_ranges) {
@@ -185,6 +187,11 @@ int s3s_decompress_ranges_batch(s3s_ctx* ctx, int codec, int checksum_algo, s3s_
   ctx->err[0] = 0;
   if (n_ranges < 0 || (n_ranges > 0 && !ranges)) return fail(ctx, S3S_E_INVALID, "null range array or negative count");
   if (n_ranges == 0) return S3S_OK;
+  BatchVerdict<s3s_fetch_range> verdict(ranges, n_ranges);
+  for (int32_t r = 0; r < n_ranges; r++) {
+    ranges[r].out_len = 0;
+    ranges[r].bad_partition = -1;
+  }
   for (int32_t r = 0; r < n_ranges; r++) {
     const s3s_fetch_range& k = ranges[r];
     if (k.comp_len < 0 || k.dst_capacity < 0 || k.num_partitions < 0 || !k.part_offsets)
@@ -196,7 +203,7 @@ int s3s_decompress_ranges_batch(s3s_ctx* ctx, int codec, int checksum_algo, s3s_
     k.bad_partition = -1;
     k.status = s3s_decompress_range(ctx, codec, checksum_algo, k.d_comp, k.comp_len, k.part_offsets, k.ref_checksums,
                                     k.num_partitions, k.d_dst, k.dst_capacity, &k.out_len, &k.bad_partition);
-    return k.status;
+    return verdict.finish(k.status);
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   int rc;
@@ -276,7 +283,7 @@ int s3s_decompress_ranges_batch(s3s_ctx* ctx, int codec, int checksum_algo, s3s_
   HIP_TRY(ctx, hipStreamSynchronize(ctx->hb_out));
   if (ctx->profile)
     for (int s = 0; s < S3S_STAGE_COUNT; s++) ctx->stage_ms[s] = stage_acc[s];
-  return worst;
+  return verdict.finish(worst);
 }
 
 }  // extern "C"

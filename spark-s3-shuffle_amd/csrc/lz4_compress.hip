@@ -339,9 +339,6 @@ __device__ int lz4_compress_wave(const Src in, const Tab T, int len, uint8_t* ou
 #if defined(S3S_ABL_DUP_PW) || defined(S3S_ABL_DUP_GATHER)
                            "v160", "v161", "v162", "v163",
 #endif
-#ifdef S3S_X_ROLL_PREFETCH
-                           "v159", "v160",
-#endif
                            "vcc", "scc", "memory");
             pw0 = make_uint4((uint32_t)p0l, (uint32_t)(p0l >> 32), (uint32_t)p0h, (uint32_t)(p0h >> 32));
             pw1 = make_uint4((uint32_t)p1l, (uint32_t)(p1l >> 32), (uint32_t)p1h, (uint32_t)(p1h >> 32));
@@ -839,11 +836,7 @@ __global__ __launch_bounds__(kWave) void lz4_compress_l2_kernel(
   {
     const uint8_t* g = src + item.src_off;
     uint32_t acc = 0;
-#ifdef S3S_X_ROLL_PREFETCH  // (experiment: only the head of the block here, the window block touches the rest as it goes)
-    const int touch = item.len < S3S_X_ROLL_DIST + 512 ? item.len : S3S_X_ROLL_DIST + 512;
-#else
     const int touch = item.len;
-#endif
     for (int i = lane * 16; i + 16 <= touch; i += kWave * 16) {
       uint4 x;
       __builtin_memcpy(&x, g + i, 16);

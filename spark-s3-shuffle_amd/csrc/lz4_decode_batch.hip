@@ -28,10 +28,6 @@
 // tests/model/lz4_batch_decode_model.cpp is the lock-step CPU model of this kernel (fuzzed against
 // liblz4 incl. malformed blocks); malformed input ends in S3S_E_BAD_FRAME, never out of bounds.
 #include "s3s_internal.h"
-#ifdef S3S_DEC_PERSIST
-#include <atomic>
-#include <cstdlib>
-#endif
 
 #ifdef S3S_LZ4_TIMING
 __device__ unsigned long long g_bdec_dbg[16];  // (instrumented build: phase ticks of batch_decode_kernel)
@@ -171,20 +167,13 @@ template <int kFmt>
 __global__ __launch_bounds__(kWave) void batch_decode_kernel(
     const uint8_t* __restrict__ comp, const Frame* __restrict__ frames, int32_t n_frames,
     const int64_t* __restrict__ frame_out, uint8_t* dst, int32_t* __restrict__ status
-#ifdef S3S_DEC_PERSIST  // (experiment for the next round: a persistent grid that draws frames from a counter, as the LZ4 compressor)
-    , uint32_t* __restrict__ work
-#endif
 ) {
   __shared__ __attribute__((aligned(16))) uint8_t win[kBWin + kBPad];
   __shared__ uint2 rec[kWave];
 #ifdef S3S_DEC_RING
   __shared__ __attribute__((aligned(4))) uint8_t sring[kSRing + 8];
 #endif
-#ifdef S3S_DEC_PERSIST
-  auto decode_one = [&](const int f) __attribute__((always_inline)) {
-#else
   const int f = blockIdx.x;
-#endif
   if (f >= n_frames) return;
   const Frame fr = frames[f];
   const int olen = fr.orig_len, clen = fr.comp_len;
@@ -897,36 +886,8 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
     if (lane == 0) atomicExch(status, S3S_E_BAD_FRAME);
     return;
   }
-#ifdef S3S_DEC_PERSIST
-  };
-  for (;;) {
-    uint32_t f0 = 0;
-    if (threadIdx.x == 0) f0 = atomicAdd(work, 1u);
-    const int f = (int)__builtin_amdgcn_readfirstlane(f0);
-    if (f >= n_frames) break;
-    __syncthreads();  // (the previous frame's last LDS accesses are done before the window is written again)
-    decode_one(f);
-  }
-#endif
 }
 
-#ifdef S3S_DEC_PERSIST
-// one frame counter per launch in flight, from a ring of 256 per device (experiment build only)
-static uint32_t* persist_counter() {
-  static std::atomic<uint32_t*> ring[16];
-  static std::atomic<uint32_t> next{0};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  dev &= 15;
-  uint32_t* r = ring[dev].load();
-  if (!r) {
-    uint32_t* fresh = nullptr;
-    (void)hipMalloc(&fresh, 256 * sizeof(uint32_t));
-    if (ring[dev].compare_exchange_strong(r, fresh)) r = fresh; else (void)hipFree(fresh);
-  }
-  return r + (next.fetch_add(1) & 255u);
-}
-#endif
 
 // ---- frame checks: xxHash32 of every decoded block, four lanes per frame ------------------------------
 // xxHash32 has four accumulators, each a serial multiply chain over every fourth dword — a wavefront per
@@ -1010,18 +971,8 @@ void launch_lz4_decompress_batch(const uint8_t* d_comp, const Frame* d_frames, i
     if (after_decode) (void)hipEventRecord(after_decode, st);
     return;
   }
-#ifdef S3S_DEC_PERSIST
-  {  // counters from a small ring (one per launch in flight); grid from S3S_DEC_GRID (default 26 wavefronts per CU x 256 CUs)
-    uint32_t* work = persist_counter();
-    (void)hipMemsetAsync(work, 0, sizeof(uint32_t), st);
-    static const int genv = getenv("S3S_DEC_GRID") ? atoi(getenv("S3S_DEC_GRID")) : 26 * 256;
-    hipLaunchKernelGGL(batch_decode_kernel<kFmtLz4>, dim3((unsigned)(n_frames < genv ? n_frames : genv)), dim3(kWave), 0, st, d_comp,
-                       d_frames, n_frames, d_frame_out, d_dst, d_status, work);
-  }
-#else
   hipLaunchKernelGGL(batch_decode_kernel<kFmtLz4>, dim3((unsigned)n_frames), dim3(kWave), 0, st, d_comp, d_frames,
                      n_frames, d_frame_out, d_dst, d_status);
-#endif
   if (after_decode) (void)hipEventRecord(after_decode, st);
   hipLaunchKernelGGL(lz4_verify_frames_kernel, dim3((unsigned)((n_frames + kWave / 4 - 1) / (kWave / 4))), dim3(kWave),
                      0, st, d_frames, n_frames, d_frame_out, d_dst, d_status);
@@ -1031,18 +982,8 @@ void launch_snappy_decompress_batch(const uint8_t* d_comp, const Frame* d_frames
                                     const int64_t* d_frame_out, uint8_t* d_dst, int32_t* d_status,
                                     hipStream_t st) {
   if (n_frames <= 0) return;
-#ifdef S3S_DEC_PERSIST
-  {  // counters from a small ring (one per launch in flight); grid from S3S_DEC_GRID (default 26 wavefronts per CU x 256 CUs)
-    uint32_t* work = persist_counter();
-    (void)hipMemsetAsync(work, 0, sizeof(uint32_t), st);
-    static const int genv = getenv("S3S_DEC_GRID") ? atoi(getenv("S3S_DEC_GRID")) : 26 * 256;
-    hipLaunchKernelGGL(batch_decode_kernel<kFmtSnappy>, dim3((unsigned)(n_frames < genv ? n_frames : genv)), dim3(kWave), 0, st, d_comp,
-                       d_frames, n_frames, d_frame_out, d_dst, d_status, work);
-  }
-#else
   hipLaunchKernelGGL(batch_decode_kernel<kFmtSnappy>, dim3((unsigned)n_frames), dim3(kWave), 0, st, d_comp, d_frames,
                      n_frames, d_frame_out, d_dst, d_status);
-#endif
 }
 
 }  // namespace s3s

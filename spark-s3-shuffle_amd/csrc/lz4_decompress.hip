@@ -104,8 +104,7 @@ __device__ __forceinline__ void speculate_tile(const uint8_t* __restrict__ comp,
   if (k == 0) {
     entry = 0;
   } else {
-#ifdef S3S_X_SPEC_UNROLL
-    // (experiment for the next round) 256 positions per step: the four loads of a step are in flight together instead of one
+    // 256 positions per step (round 4, with the wide rebase +1.2 % on the reduce side, profiles/r04a_first_call.txt): the four loads of a step are in flight together instead of one
     // load -> ballot round trip per 64 positions (a tile's first header is ~8 KiB in: ~130 of those round trips today)
     for (int64_t p0 = t0; p0 < t1 && entry < 0; p0 += 4 * kWave) {
       uint64_t w[4];
@@ -128,19 +127,6 @@ __device__ __forceinline__ void speculate_tile(const uint8_t* __restrict__ comp,
         if (m && entry < 0) entry = p0 + u * kWave + __builtin_ctzll(m);
       }
     }
-#else
-    // first plausible header in the tile: 64 positions per step
-    for (int64_t p0 = t0; p0 < t1 && entry < 0; p0 += kWave) {
-      const int64_t p = p0 + lane;
-      bool hit = false;
-      if (p < t1 && comp_len - p >= kLz4FrameHeader && ld64u(comp + p) == kMagic) {
-        const Header hd = parse_header(comp + p);
-        hit = hd.ok && p + kLz4FrameHeader + hd.comp_len <= comp_len;
-      }
-      const uint64_t m = __ballot(hit);
-      if (m) entry = p0 + __builtin_ctzll(m);
-    }
-#endif
   }
   if (lane == 0) {
     int32_t cnt = 0;
@@ -336,8 +322,7 @@ __global__ __launch_bounds__(kWave) void frames_finish_batch_kernel(LzRange* __r
   }
   if (lane == 0) r.result[1] = total;
   const int64_t comp_base = (int64_t)reinterpret_cast<uintptr_t>(r.comp);
-#ifdef S3S_X_FINISH_WIDE
-  // (experiment for the next round) the rebase is one wavefront per range on the critical path in front of the decode launch
+  // (round 4) the rebase is one wavefront per range on the critical path in front of the decode launch
   // (50 us for four 128 MiB ranges, 3 % of the reduce-side step): four records per lane and iteration, their loads issued
   // together, instead of one load -> store round trip per record
   if (!skip) {
@@ -358,7 +343,6 @@ __global__ __launch_bounds__(kWave) void frames_finish_batch_kernel(LzRange* __r
     }
     return;
   }
-#endif
   for (int64_t i = lane; i < r.n_frames; i += kWave) {
     if (skip) {
       r.frames[i] = Frame{0, 0, 0, 0u, 0x10};

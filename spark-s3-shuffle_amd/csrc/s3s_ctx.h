@@ -77,6 +77,29 @@ inline int fail(s3s_ctx* ctx, int code, const char* fmt, ...) {
   return code;
 }
 
+// Batch entry points stamp every entry S3S_STATUS_NOT_RUN on entry and create one of these: a return that is not the call's
+// regular end (bad argument, HIP error between the groups, allocation failure) leaves NO entry reporting S3S_OK — an entry whose
+// kernels ran may still be waiting for its download — so the caller applies the call's return code to exactly the NOT_RUN ones
+// and keeps the verdict of every entry that has one (advisor r3: one task's error must not fail its neighbours).
+template <typename T>
+struct BatchVerdict {
+  T* e;
+  int32_t n;
+  bool done = false;
+  BatchVerdict(T* entries, int32_t count) : e(entries), n(count) {
+    for (int32_t i = 0; i < n; i++) e[i].status = S3S_STATUS_NOT_RUN;
+  }
+  ~BatchVerdict() {
+    if (done) return;
+    for (int32_t i = 0; i < n; i++)
+      if (e[i].status == S3S_OK) e[i].status = S3S_STATUS_NOT_RUN;
+  }
+  int finish(int rc) {
+    done = true;
+    return rc;
+  }
+};
+
 #define HIP_TRY(ctx, expr)                                                                  \
   do {                                                                                      \
     hipError_t e_ = (expr);                                                                 \

@@ -19,6 +19,7 @@ OPT_SNAPPY_VARIANT = 6
 OPT_LZ4_VARIANT_USED = 7
 
 E_INVALID, E_CAPACITY, E_BAD_FRAME, E_CHECKSUM, E_HIP, E_UNSUPPORTED, E_NOMEM = -1, -2, -3, -4, -5, -6, -7
+STATUS_NOT_RUN = -100  # per-entry status of a batch call that failed as a call before this entry had a verdict (ABI 6)
 _ERR_NAMES = {
     E_INVALID: "S3S_E_INVALID",
     E_CAPACITY: "S3S_E_CAPACITY",

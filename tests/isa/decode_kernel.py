@@ -37,10 +37,7 @@ def program(fmt, flags=(), kernel="batch"):
 
 def decode_blocks(blocks, fmt=0, methods=None, profile=None, flags=(), grid=None, kernel="batch", checks=None):
     """blocks: list of (payload bytes, decoded length).  fmt 0 = LZ4 block payloads, 1 = raw Snappy blocks.
-    Returns (list of decoded bytes, status word, waves).  flags: extra -D macros of an experiment build; with
-    -DS3S_DEC_PERSIST the kernel takes a frame counter as its last argument and `grid` wavefronts draw frames from it
-    (the interpreter runs them one after the other, so the first one decodes every frame through ONE window buffer
-    and the others find the counter exhausted).  checks: the frames' LZ4Block check fields (the LZ4 ring kernel verifies
+    Returns (list of decoded bytes, status word, waves).  flags: extra -D macros of an experiment build.  checks: the frames' LZ4Block check fields (the LZ4 ring kernel verifies
     xxHash32 itself; the batch decoder leaves that to lz4_verify_frames_kernel)."""
     prog, entry, text, lds = program(fmt, flags, kernel)
     mem = emu.Memory()
@@ -67,15 +64,10 @@ def decode_blocks(blocks, fmt=0, methods=None, profile=None, flags=(), grid=None
     a_dst = mem.map(dst, "dst")
     a_status = mem.map(status, "status")
     kernarg = struct.pack("<QQiiQQQ", a_comp, a_frames, len(blocks), 0, a_fout, a_dst, a_status)
-    work = np.zeros(1, dtype=np.uint32)
-    if "-DS3S_DEC_PERSIST" in flags:
-        kernarg += struct.pack("<Q", mem.map(work, "work"))
     objs = emu.parse_objects(text)
     waves = emu.launch(prog, entry, mem, kernarg, grid or len(blocks), lds, profile=profile,
                        objects={k: v for k, v in objs.items() if k.startswith("_ZN3s3s")})
     res = [bytes(dst[outs[k]:outs[k] + blocks[k][1]]) for k in range(len(blocks))]
-    if "-DS3S_DEC_PERSIST" in flags:
-        assert int(work[0]) == len(blocks) + (grid or len(blocks)), "every wavefront leaves through the counter"
     return res, int(status[0]), waves
 
 

@@ -20,7 +20,7 @@ TILE = 65536
 _PROG = {}
 
 
-FLAGS = ()  # extra hipcc flags of an experiment build (set before the first launch; e.g. ("-DS3S_X_FINISH_WIDE",))
+FLAGS = ()  # extra hipcc flags of an experiment build (set before the first launch; e.g. ("-DS3S_X_SOMETHING",))
 
 
 def use_flags(flags):

@@ -227,6 +227,23 @@ int main(void) {
     CLEAN();
     mj_free(short_total);
   }
+  /* an INNER array shorter than the partition count its task's offsets imply (advisor r3: the library would write past the
+     pinned JVM array): refused before anything is pinned, nothing written */
+  {
+    jlongArray short_index = mj_longs(NP), short_sums = mj_longs(NP - 1), keep_i = (jlongArray)mj_o(a_index)[1], keep_s = (jlongArray)mj_o(a_sums)[2];
+    mj_o(a_index)[1] = short_index;
+    mj_i(a_status)[0] = 77;
+    CHECK(FN(compressMapOutputsBatch)(e, NULL, h, CODEC, ALGO, a_src, a_offs, a_dst, a_cap, a_index, a_sums, a_total, a_status) == S3S_E_INVALID);
+    CLEAN();
+    CHECK(mj_i(a_status)[0] == 77);
+    mj_o(a_index)[1] = keep_i;
+    mj_o(a_sums)[2] = short_sums;
+    CHECK(FN(compressMapOutputsBatch)(e, NULL, h, CODEC, ALGO, a_src, a_offs, a_dst, a_cap, a_index, a_sums, a_total, a_status) == S3S_E_INVALID);
+    CLEAN();
+    mj_o(a_sums)[2] = keep_s;
+    mj_free(short_index);
+    mj_free(short_sums);
+  }
   CHECK(FN(compressMapOutputsBatch)(e, NULL, h, CODEC, ALGO, a_src, a_offs, a_dst, a_cap, a_index, a_sums, a_total, a_status) == S3S_OK);
 
   /* ---- decompressRangesBatch: the three images back to their sources; one damaged checksum names range + partition -- */
@@ -251,6 +268,14 @@ int main(void) {
     CLEAN();
     CHECK(mj_i(a_status)[0] == S3S_OK && mj_i(a_status)[1] == S3S_OK && mj_i(a_status)[2] == S3S_E_CHECKSUM && mj_i(a_bad)[2] == 0);
     mj_l(sums[2])[0] -= 1;
+    { /* reference checksums shorter than the range's partitions: refused */
+      jlongArray short_sums = mj_longs(NP - 1), keep_s = (jlongArray)mj_o(a_sums)[0];
+      mj_o(a_sums)[0] = short_sums;
+      CHECK(FN(decompressRangesBatch)(e, NULL, h, CODEC, ALGO, a_dst, a_clen, a_index, a_sums, a_back, a_bcap, a_olen, a_bad, a_status) == S3S_E_INVALID);
+      CLEAN();
+      mj_o(a_sums)[0] = keep_s;
+      mj_free(short_sums);
+    }
     /* no checksums: the reference array of arrays may be null */
     CHECK(FN(decompressRangesBatch)(e, NULL, h, CODEC, S3S_CHECKSUM_NONE, a_dst, a_clen, a_index, NULL, a_back, a_bcap, a_olen, a_bad, a_status) == S3S_OK);
     CLEAN();

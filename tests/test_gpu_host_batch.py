@@ -140,3 +140,46 @@ def test_host_batch_decompress_reports_the_bad_range(gpu_codec, oracle):
             assert st == -4 and bad == victims[r]
         else:
             assert st == 0 and np.array_equal(keep[r][1][:n], keep[r][2])
+
+
+def test_call_level_failure_marks_every_unfinished_entry_not_run(gpu_codec, oracle):
+    """ABI 6 (advisor r3): a batch call that fails as a CALL (here: an argument error the validation meets at the third
+    range) returns that code and leaves S3S_STATUS_NOT_RUN in every entry — the caller applies the return code to exactly
+    those — while a failure of ONE range (previous test) keeps its own verdict and its neighbours decode."""
+    from s3shuffle import codec as sc
+
+    rng = np.random.default_rng(71)
+    args, keep = [], []
+    for r in range(4):
+        data, offs = corpus.ragged_map_output(rng, 5, 200_000)
+        img, index, sums = oracle.compress_map_output(LZ4, ADLER, data, offs)
+        dst = np.zeros(data.size, np.uint8)
+        keep.append((img, dst, data))
+        if r == 2:
+            index = index.copy()
+            index[-1] += 1  # part_offsets must span [0, comp_len]: S3S_E_INVALID for the call
+        args.append((img.ctypes.data, img.size, index, sums, dst.ctypes.data, data.size))
+    res = gpu_codec.decompress_ranges_batch(LZ4, ADLER, args, raise_on_error=False)
+    assert [st for st, _, _ in res] == [sc.STATUS_NOT_RUN] * 4, res
+    assert gpu_codec._lib.s3s_last_error(gpu_codec._h)  # the message names the range
+    # the device form of the same call
+    import hipdev
+
+    dev = hipdev.Dev()
+    try:
+        dargs = [(dev.upload(np.asarray(k[0])), a[1], a[2], a[3], dev.alloc(max(a[5], 1)), a[5]) for k, a in zip(keep, args)]
+        res = gpu_codec.decompress_ranges_batch_device(LZ4, ADLER, dargs, raise_on_error=False)
+        assert [st for st, _, _ in res] == [sc.STATUS_NOT_RUN] * 4, res
+    finally:
+        dev.free()
+    # map side: the library refuses a zstd compress call as a whole
+    tasks = [(k[2].ctypes.data, np.array([0, k[2].size], np.int64), k[1].ctypes.data, k[1].size) for k in keep]
+    arr = (sc.MapTask * len(tasks))()
+    offs_keep = []
+    for i, (src, offs, dst, cap) in enumerate(tasks):
+        offs_keep.append(offs)
+        arr[i].d_src, arr[i].src_offsets, arr[i].num_partitions = src, offs.ctypes.data_as(sc.ctypes.POINTER(sc.ctypes.c_int64)), 1
+        arr[i].d_dst, arr[i].dst_capacity = dst, cap
+        arr[i].out_index = np.zeros(2, np.int64).ctypes.data_as(sc.ctypes.POINTER(sc.ctypes.c_int64))
+    rc = gpu_codec._lib.s3s_compress_map_outputs_batch(gpu_codec._h, 3, 0, arr, len(tasks))
+    assert rc in (-1, -6) and [arr[i].status for i in range(len(tasks))] == [sc.STATUS_NOT_RUN] * len(tasks)

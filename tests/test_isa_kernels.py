@@ -52,61 +52,6 @@ def test_compiled_kernel_matches_oracle(oracle, windows):
     _check(chunks, oracle, windows=windows)
 
 
-def test_rolling_prefetch_build_is_the_same_compressor(oracle):
-    """-DS3S_X_ROLL_PREFETCH (kept for the next round's measurement: lanes 20..23 of the window block's stream load touch
-    cache lines 3 KiB ahead instead of the whole block being touched up front): same bytes, and the extra lanes stay
-    inside the block — the source buffer ends with the last chunk's last byte."""
-    import lz4_kernel as lk
-    from s3shuffle import datagen
-
-    rng = np.random.default_rng(8)
-    data, _ = datagen.terasort_map_output(1 << 20, 4, seed=2, map_id=1)
-    chunks = [np.asarray(data[:32768]).copy(), corpus.chunk_corpus(6, 9000, rng), corpus.chunk_corpus(2, 3500, rng),
-              np.asarray(data[50000:50000 + 3300]).copy()]
-    out = lk.compress_chunks(chunks, windows=True, flags=("-DS3S_X_ROLL_PREFETCH",))
-    for c, (payload, _, _) in zip(chunks, out):
-        ref = bytes(oracle.lz4_compress_block(c))
-        assert (payload is None and len(ref) >= len(c)) or bytes(payload) == ref
-    import hazards
-
-    text = lk.compile_asm("lz4_compress.hip", ("-DS3S_X_ROLL_PREFETCH",))
-    asm_viol, cc_viol, _, _ = hazards.check_kernel(text, lk.find_kernel(text, "lz4_compress_l2_kernelILb1E"))
-    assert not asm_viol and not cc_viol, (asm_viol[:3], cc_viol[:3])
-
-
-def test_issue_priority_build_is_the_same_compressor(oracle):
-    """-DS3S_X_SETPRIO (kept for the next round's measurement: raised issue priority from the window's entry to its candidate
-    gather): same bytes, wait states intact, and the priority is back to 0 wherever the block is left"""
-    import hazards
-    import lz4_kernel as lk
-
-    rng = np.random.default_rng(9)
-    chunks = [corpus.chunk_corpus(7, 32768, rng), corpus.chunk_corpus(6, 9000, rng), corpus.chunk_corpus(3, 20000, rng)]
-    out = lk.compress_chunks(chunks, windows=True, flags=("-DS3S_X_SETPRIO",))
-    for c, (payload, _, _) in zip(chunks, out):
-        ref = bytes(oracle.lz4_compress_block(c))
-        assert (payload is None and len(ref) >= len(c)) or bytes(payload) == ref
-    text = lk.compile_asm("lz4_compress.hip", ("-DS3S_X_SETPRIO",))
-    entry = lk.find_kernel(text, "lz4_compress_l2_kernelILb1E")
-    asm_viol, cc_viol, _, _ = hazards.check_kernel(text, entry)
-    assert not asm_viol and not cc_viol, (asm_viol[:3], cc_viol[:3])
-    # between a raise and the next lowering there is no branch and no label: straight-line code
-    lines = [ln.split(";")[0].strip() for ln in text.splitlines()]
-    raised = 0
-    for ln in lines:
-        if ln.startswith("s_setprio"):
-            raised = int(ln.split()[1]) > 0
-        elif raised:
-            assert not ln.startswith(("s_branch", "s_cbranch", "s_endpgm", "s_setpc")) and not ln.endswith(":"), ln
-    assert sum(ln.startswith("s_setprio 2") for ln in lines) == 3 and not raised  # (three copies of the window body)
-    # the same switch in the Snappy block
-    import snappy_kernel as sk
-
-    for c, (slot, sz, w) in zip(chunks, sk.compress_chunks(chunks, flags=("-DS3S_X_SETPRIO",))):
-        assert bytes(slot[32:32 + sz - 4]) == bytes(oracle.snappy_compress_block(c))
-    text = lk.compile_asm("snappy_compress.hip", ("-DS3S_X_SETPRIO",))
-    asm_viol, cc_viol, _, _ = hazards.check_kernel(text, lk.find_kernel(text, "snappy_compress_kernelILb1E"))
-    assert not asm_viol and not cc_viol and sum(ln.strip().startswith("s_setprio 2") for ln in text.splitlines()) == 3
 
 
 def test_lds_race_winner_is_irrelevant(oracle):
@@ -293,29 +238,6 @@ def test_compiled_decoder_on_chained_sources(oracle):
         assert st == 0 and res == [w for _, w in cases], fmt
 
 
-def test_persistent_grid_decoder_build_is_the_same_decoder(oracle):
-    """-DS3S_DEC_PERSIST (an experiment kept for the next round's measurement): wavefronts draw
-    frames from a counter and decode them one after the other through the same LDS window.  Valid blocks of both
-    formats decode to the same bytes, a malformed frame between valid ones sets the status and does not stop the
-    frames after it, every wavefront leaves through the counter."""
-    import decode_kernel as dk
-    import framing
-
-    flags = ("-DS3S_DEC_PERSIST",)
-    rng = np.random.default_rng(43)
-    chunks = [corpus.chunk_corpus(k, n, rng) for k, n in [(7, 20000), (3, 5000), (6, 32768), (1, 4000), (7, 13), (2, 3000)]]
-    blocks = [(bytes(oracle.lz4_compress_block(c)), len(c)) for c in chunks]
-    res, st, _ = dk.decode_blocks(blocks, fmt=0, flags=flags, grid=3)
-    assert st == 0 and res == [c.tobytes() for c in chunks]
-    sblocks = [(bytes(oracle.snappy_compress_block(c)), len(c)) for c in chunks]
-    res, st, _ = dk.decode_blocks(sblocks, fmt=1, flags=flags, grid=2)
-    assert st == 0 and res == [c.tobytes() for c in chunks]
-    z = b"abcdefgh"
-    bad = framing.lz4_block([(z, 9, 4)], z)
-    mixed = blocks[:2] + [(bad, len(framing.lz4_decode_py(framing.lz4_block([(z, 8, 4)], z))))] + blocks[2:4]
-    res, st, _ = dk.decode_blocks(mixed, fmt=0, flags=flags, grid=1)
-    assert st == -3 and res[:2] == [c.tobytes() for c in chunks[:2]] and res[3:] == [c.tobytes() for c in chunks[2:4]]
-
 
 def test_compiled_ring_decoders(oracle):
     """the ring decoders (lz4_decompress_valu_kernel / snappy_decompress_valu_kernel: decode variant 3, and where LZ4 frames
@@ -487,38 +409,20 @@ def test_batched_reduce_side_call_through_the_compiled_kernels(oracle):
     assert res[0][1] == srcs[0] and res[3][1] == srcs[1]
 
 
-def test_unrolled_speculation_build_is_the_same_discovery(oracle):
-    """-DS3S_X_SPEC_UNROLL (kept for the next round's measurement: the tile speculation looks at 256 positions per step, four
-    loads in flight): every case of the frame-discovery test and of the batched reduce-side test, same answers, no access
-    outside a buffer (the range ends with its last byte: a step's fourth load must not look past it)"""
-    import discover_kernel as dsc
 
-    dsc.use_flags(("-DS3S_X_SPEC_UNROLL",))
-    try:
-        test_compiled_frame_discovery(oracle)
-        test_batched_reduce_side_call_through_the_compiled_kernels(oracle)
-    finally:
-        dsc.use_flags(())
-
-
-def test_wide_finish_build_is_the_same_reduce_side(oracle):
-    """-DS3S_X_FINISH_WIDE (kept for the next round's measurement: frames_finish_batch_kernel rebases four records per lane
-    and iteration): the batched reduce-side call gives the same bytes and the same verdicts, frame counts that are not a
-    multiple of four included"""
+def test_wide_finish_rebases_any_frame_count(oracle):
+    """frames_finish_batch_kernel rebases four records per lane and iteration (round 4: measured and shipped): the batched
+    reduce-side call gives the right bytes and verdicts for frame counts that are not a multiple of four"""
     import discover_kernel as dsc
 
     rng = np.random.default_rng(56)
     srcs = [corpus.chunk_corpus(7, 300_000, rng).tobytes(), corpus.chunk_corpus(6, 9000, rng).tobytes(), b"",
             corpus.chunk_corpus(2, 40_000, rng).tobytes()]
     streams = [oracle.compress_stream(1, np.frombuffer(b, np.uint8)).tobytes() if b else b"" for b in srcs]
-    dsc.use_flags(("-DS3S_X_FINISH_WIDE",))
-    try:
-        res, dec_status = dsc.decode_ranges_batch(streams, [len(b) for b in srcs])
-        assert dec_status == 0 and [st for st, _ in res] == [0] * 4 and [out for _, out in res] == srcs
-        res, _ = dsc.decode_ranges_batch([streams[0], streams[3], streams[1]], [len(srcs[0]), len(srcs[3]) - 1, len(srcs[1])], skip=(2,))
-        assert [st for st, _ in res] == [0, -2, -4] and res[0][1] == srcs[0]
-    finally:
-        dsc.use_flags(())
+    res, dec_status = dsc.decode_ranges_batch(streams, [len(b) for b in srcs])
+    assert dec_status == 0 and [st for st, _ in res] == [0] * 4 and [out for _, out in res] == srcs
+    res, _ = dsc.decode_ranges_batch([streams[0], streams[3], streams[1]], [len(srcs[0]), len(srcs[3]) - 1, len(srcs[1])], skip=(2,))
+    assert [st for st, _ in res] == [0, -2, -4] and res[0][1] == srcs[0]
 
 
 def test_whole_snappy_reduce_side_call_through_the_compiled_kernels(oracle):

@@ -179,6 +179,53 @@ def test_liblz4_backed_baseline_stream_equals_restatement(oracle):
         assert n == want.size and np.array_equal(out[:n], want)
 
 
+def test_libsnappy_backed_baseline_stream_equals_restatement(oracle):
+    """round 4: the Snappy legs of the cpu_baseline run libsnappy itself (as the LZ4 legs run liblz4): same image as the
+    restatement, and concatenated streams (a batch range) decode back through the library's decompressor"""
+    lib = oracle.lib()
+    if not lib.s3o_mt_have_libsnappy():
+        pytest.skip("libsnappy not loadable")
+    rng = np.random.default_rng(13)
+    images, srcs = [], []
+    for kind in (0, 1, 3, 7):
+        d = corpus.chunk_corpus(kind, 100_000, rng)
+        want = oracle.compress_stream(SNAPPY, d)
+        out = np.empty(want.size + 64, np.uint8)
+        n = lib.s3o_mt_stream_libsnappy(d.ctypes.data, d.size, 32768, out.ctypes.data)
+        assert n == want.size and np.array_equal(out[:n], want)
+        images.append(out[:n].copy())
+        srcs.append(d)
+    cat = np.concatenate(images)
+    back = np.empty(sum(d.size for d in srcs), np.uint8)
+    assert lib.s3o_mt_decode_libsnappy(cat.ctypes.data, cat.size, back.ctypes.data, back.size) == back.size
+    assert np.array_equal(back, np.concatenate(srcs))
+    cat[40] ^= 0x55
+    assert lib.s3o_mt_decode_libsnappy(cat.ctypes.data, cat.size, back.ctypes.data, back.size) < 0 or not np.array_equal(back, np.concatenate(srcs))
+
+
+def test_simd_checksums_of_the_baseline_equal_zlib(oracle):
+    """round 4 (the CPU leg's CRC32 must run at hardware speed): the carry-less-multiply CRC32 and the SSSE3
+    Adler32 the cpu_baseline uses give zlib's values for every length, alignment and running value; the folding constants
+    they derive from the polynomial are the ones Intel's paper tabulates"""
+    import zlib
+
+    if oracle.lib().s3o_simd_available() & 1:
+        assert oracle.simd_crc_constants() == [0x154442bd4, 0x1c6e41596, 0x1751997d0, 0x0ccaa009e, 0x163cd6124, 0x1db710641, 0x1f7011641]
+    rng = np.random.default_rng(14)
+    buf = rng.integers(0, 256, 1 << 19, dtype=np.uint8)
+    buf[1000:40000] = 0xFF  # the largest byte sums between two modulo steps
+    for t in range(1500):
+        n = int(rng.integers(0, 700)) if t % 3 else int(rng.integers(0, 1 << 19))
+        off = int(rng.integers(0, 67))
+        b = buf[off:min(off + n, buf.size)]
+        init = int(rng.integers(0, 1 << 32)) if t % 2 else 0
+        assert oracle.checksum_fast(CRC, b, init) == zlib.crc32(b.tobytes(), init)
+        ainit = 1 if not t % 2 else (init % 65521) | (((init >> 16) % 65521) << 16)
+        assert oracle.checksum_fast(ADLER, b, ainit) == zlib.adler32(b.tobytes(), ainit)
+    assert oracle.checksum_fast(CRC, np.frombuffer(b"123456789" * 20, np.uint8)) == zlib.crc32(b"123456789" * 20)
+    assert oracle.checksum_fast(ADLER, np.zeros(0, np.uint8)) == 1 and oracle.checksum_fast(CRC, np.zeros(0, np.uint8)) == 0
+
+
 # ---- Snappy (oracle restates libsnappy 1.1.8; JVM bundles 1.1.10: parity unpinned) ----------------
 def _libsnappy():
     for name in ("libsnappy.so.1", "/opt/conda/lib/libsnappy.so.1"):

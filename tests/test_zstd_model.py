@@ -16,8 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
-# the decoder as it ships, and with the build switches that are kept for the next round's measurements (same results demanded)
-@pytest.fixture(scope="module", params=["", "-DZS_SEQ_FASTBITS"], ids=["shipped", "fastbits"])
+# the decoder as it ships (round 4: the one-window sequence read, ex -DZS_SEQ_FASTBITS, is the only build)
+@pytest.fixture(scope="module", params=[""], ids=["shipped"])
 def model(request):
     src = os.path.join(HERE, "model", "zstd_decode_model.cpp")
     so = os.path.join(HERE, "model", "zstd_decode_model%s.so" % ("_" + request.param[3:].lower() if request.param else ""))
@@ -135,7 +135,7 @@ def test_mutated_streams_behave_like_libzstd(model):
     assert agree_fail > 300 and agree_ok > 200 and strict < 0.05 * (agree_ok + strict + 1)
 
 
-@pytest.mark.parametrize("flags", [(), ("-DZS_SEQ_FASTBITS",)], ids=["shipped", "fastbits"])
+@pytest.mark.parametrize("flags", [()], ids=["shipped"])
 def test_mutated_streams_never_leave_their_buffers_under_asan(flags):
     """the same core under ASan / UBSan, compressed stream and destination in heap blocks of exactly their sizes
     (tests/model/zstd_asan_fuzz.cpp): 20 000 mutations of libzstd streams — bit flips, truncations, splices, inserted /

@@ -19,6 +19,7 @@ def replay(d: bytes):
     H = lambda p: ((rd32(p) * 2654435761) & 0xFFFFFFFF) >> 19  # noqa: E731
     table = {}
     inserted, probes = set(), []
+    cands, matches = [], []   # (probe position, candidate the table returned), (ip, match, length) of every sequence
     out = bytearray()
     mfl1, matchlimit = n - 12 + 1, n - 5
     anchor = 0
@@ -59,6 +60,7 @@ def replay(d: bytes):
                 h = H(ip)
                 match = table.get(h, 0)
                 probes.append(ip)
+                cands.append((ip, match))
                 put(ip)
                 if rd32(match) == rd32(ip):
                     break
@@ -71,6 +73,7 @@ def replay(d: bytes):
                 while ip + m < matchlimit and d[ip + m] == d[match + m]:
                     m += 1
                 emit(ip, match, m)
+                matches.append((ip, match, m))
                 ip += m
                 anchor = ip
                 if ip >= mfl1:
@@ -79,6 +82,7 @@ def replay(d: bytes):
                 put(ip - 2)
                 match = table.get(H(ip), 0)
                 probes.append(ip)
+                cands.append((ip, match))
                 put(ip)
                 if rd32(match) == rd32(ip):
                     continue
@@ -91,6 +95,7 @@ def replay(d: bytes):
         while r >= 255: out.append(255); r -= 255
         out.append(r)
     out.extend(d[anchor:])
+    replay.cands, replay.matches = cands, matches
     return bytes(out), inserted, probes, H
 
 
@@ -98,6 +103,7 @@ for name, gen in (("terasort", lambda: datagen.skew_block(32768 * 4, "terasort",
                   ("wide rows", lambda: datagen.tpcds_wide_map_output(160000, 1, seed=3)[0][:32768 * 4])):
     data = np.ascontiguousarray(gen())
     hops_all, ins_frac = [], []
+    ring_c, ring_m = [], []
     for c in range(4):
         d = data[c * 32768:(c + 1) * 32768]
         blk, inserted, probes, H = replay(d.tobytes())
@@ -118,7 +124,27 @@ for name, gen in (("terasort", lambda: datagen.skew_block(32768 * 4, "terasort",
             if q >= 0:
                 hops_all.append(hops)
         ins_frac.append(len(inserted) / len(d))
+        ring_c.extend(replay.cands); ring_m.extend(replay.matches)
     h = np.array(hops_all)
     print(f"{name}: {len(h)} probes with a candidate; positions inserted {100 * np.mean(ins_frac):.0f} %; link hops to the first "
           f"inserted same-hash position: mean {h.mean():.2f}, p50 {np.percentile(h, 50):.0f}, p90 {np.percentile(h, 90):.0f}, "
           f"max {h.max()}; probes needing > 1 hop {100 * (h > 1).mean():.0f} %")
+
+    # round 4: would a ring of the most recent input bytes in LDS serve the window block's candidate
+    # gather and its match extensions?  Distances probe -> candidate (what the gather reads) and sequence -> match source
+    # (what an extension reads); per 64-byte window, how many probes have a candidate outside the ring.
+    c = np.array(ring_c); dist = c[:, 0] - c[:, 1]
+    m = np.array(ring_m); mdist = m[:, 0] - m[:, 1]
+    print(f"  probes {len(c)}, sequences {len(m)} ({len(m) / (4 * 512):.2f} per window), mean match {m[:, 2].mean():.1f} B, "
+          f"matches longer than 12 B (beyond the gather's 8 forward bytes + 4) {100 * (m[:, 2] > 12).mean():.0f} %")
+    for ring in (1024, 2048, 4096, 8192):
+        far = dist >= ring - 80
+        win = np.bincount(c[far, 0] // 64 + 0, minlength=1)
+        allw = np.bincount(c[:, 0] // 64)
+        nwin = (allw > 0).sum()
+        print(f"  ring {ring:5d}: candidate outside {100 * far.mean():5.1f} % of probes; windows with 0 far probes "
+              f"{100 * (1 - (np.bincount(c[far, 0] // 64, minlength=len(allw)) > 0).sum() / nwin):5.1f} %, far probes per window "
+              f"{far.sum() / nwin:.2f}; match sources outside {100 * (mdist >= ring - 80).mean():5.1f} % "
+              f"(of matches > 12 B: {100 * (mdist[m[:, 2] > 12] >= ring - 80).mean():5.1f} %)")
+    print("  candidate distance percentiles (10/50/90/99):", [int(np.percentile(dist, q)) for q in (10, 50, 90, 99)],
+          " match distance:", [int(np.percentile(mdist, q)) for q in (10, 50, 90, 99)])

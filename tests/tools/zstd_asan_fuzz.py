@@ -1,6 +1,6 @@
 """Memory-safety fuzz of the Zstandard decoder core under ASan / UBSan (TEST INFRASTRUCTURE).
 
-    python tests/tools/zstd_asan_fuzz.py --seed 3 --minutes 20 [--flags -DZS_SEQ_FASTBITS]
+    python tests/tools/zstd_asan_fuzz.py --seed 3 --minutes 20 [--flags -DZS_X_SOMETHING]
 
 Seed streams are written by libzstd 1.4.8 (oracle/zstd_ref.py: streaming frames as zstd-jni writes them, levels 1 / 5 / 19,
 with and without checksums, concatenated frames); tests/model/zstd_asan_fuzz.cpp mutates and decodes them from exact-size
