@@ -99,8 +99,8 @@ void s3s_destroy(s3s_ctx* ctx) {
     if (ctx->hb_ev_in[i]) hipEventDestroy(ctx->hb_ev_in[i]);
     if (ctx->hb_ev_out[i]) hipEventDestroy(ctx->hb_ev_out[i]);
   }
-  if (ctx->hb_in) hipStreamDestroy(ctx->hb_in);
-  if (ctx->hb_out) hipStreamDestroy(ctx->hb_out);
+  if (ctx->hb_in && !ctx->hb_shared) hipStreamDestroy(ctx->hb_in);
+  if (ctx->hb_out && !ctx->hb_shared) hipStreamDestroy(ctx->hb_out);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -329,7 +329,8 @@ int s3s_decompress_range_device(s3s_ctx* ctx, int codec, int checksum_algo, cons
   }
   int32_t st = *reinterpret_cast<int32_t*>(&h_misc[1]);
   if (st == S3S_E_UNSUPPORTED && ctx->lz4_decode_variant != 3) {
-    // a frame above 32 KiB (written with a larger spark.io.compression.lz4.blockSize): the ring decoder takes any size
+    // a frame above kBatchMaxBlock (32 MiB: larger than any LZ4BlockOutputStream block; frames of 32 KiB .. 32 MiB written
+    // with a larger spark.io.compression.lz4.blockSize are the batch decoder's since round 4): the ring decoder takes any size
     HIP_TRY(ctx, hipMemsetAsync(ctx->buf[B_STATUS].p, 0, 16, ctx->stream));
     launch_lz4_decompress(d_comp, dev<Frame>(ctx, B_FRAMES), (int32_t)n_frames, dev<int64_t>(ctx, B_FRAME_OUT), d_dst,
                           dev<int32_t>(ctx, B_STATUS), 3, ctx->stream);
@@ -338,7 +339,7 @@ int s3s_decompress_range_device(s3s_ctx* ctx, int codec, int checksum_algo, cons
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     st = *reinterpret_cast<int32_t*>(&h_misc[1]);
   }
-  if (st == S3S_E_UNSUPPORTED) return fail(ctx, S3S_E_UNSUPPORTED, "LZ4Block frame larger than %d bytes", kMaxBlock);
+  if (st == S3S_E_UNSUPPORTED) return fail(ctx, S3S_E_UNSUPPORTED, "LZ4Block frame larger than %d bytes", kBatchMaxBlock);
   if (st != 0) return fail(ctx, S3S_E_BAD_FRAME, "Stream is corrupted");
   return S3S_OK;
 }
@@ -454,7 +455,11 @@ extern "C" int s3s_decompress_ranges_batch_device(s3s_ctx* ctx, int codec, int c
   if (n_segs > 0x7fffff00ll || n_parts > 0x7fffff00ll) return fail(ctx, S3S_E_UNSUPPORTED, "batch too large for one call");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (codec == S3S_CODEC_ZSTD)  // the partitions of every range in one launch per pass: frames in flight are the throughput
-    return zstd_decompress_ranges(ctx, checksum_algo, R, n_ranges, false);
+  {
+    bool regular = false;
+    const int zrc = zstd_decompress_ranges(ctx, checksum_algo, R, n_ranges, false, &regular);
+    return regular ? verdict.finish(zrc) : zrc;
+  }
   for (auto& v : ctx->stage_ms) v = 0;
   const bool do_sum = checksum_algo != S3S_CHECKSUM_NONE;
   const size_t np1 = (size_t)n_parts + (size_t)n_ranges;  // sum of (n_r + 1)

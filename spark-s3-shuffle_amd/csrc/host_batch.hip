@@ -15,6 +15,8 @@
 // goes through the runtime's bounce buffers.
 #include "s3s_ctx.h"
 
+#include <mutex>
+
 using namespace s3s;
 
 namespace {
@@ -26,7 +28,45 @@ const int64_t kGroupBytes = [] {
   return (int64_t)(v > 0 ? v : 64) << 20;  // measured 32 / 64 / 128 MiB: 45.1 / 45.5 / 44.9 GB/s host to host with one task thread
 }();
 
+// ---- copy arbiter (round 4) -----------------------------------------------------------------------
+// Several task threads of one executor each run their own pipeline; with a pair of copy streams per CONTEXT their uploads
+// (and downloads) are in flight side by side and share the PCIe link in small slices: every pipeline's copy stage takes
+// n times longer while its codec stage waits (measured r03: 49.4 / 35.1 / 45.5 GB/s with 1 / 2 / 4 task threads).  The
+// arbiter gives a DEVICE one upload lane and one download lane - two streams shared by all contexts of the process - so
+// that copy groups of different pipelines go over the link ONE AFTER THE OTHER, each at the full rate, in the order they
+// were enqueued.  Nothing queued on a lane ever waits for an event (a group's copies are enqueued only when its staging
+// buffer is free and its source is ready), so the FIFO has no head-of-line blocking.  A mutex per lane keeps the copies of
+// one group contiguous.  S3S_HB_SHARED_COPY=0 gives every context its own pair again.
+struct CopyLanes {
+  std::mutex create;
+  hipStream_t in = nullptr, out = nullptr;
+  std::mutex in_mu, out_mu;
+};
+CopyLanes g_lanes[64];
+const bool kSharedCopy = [] {
+  const char* e = getenv("S3S_HB_SHARED_COPY");
+  return e ? atoi(e) != 0 : true;
+}();
+
 int hb_init(s3s_ctx* ctx) {
+  if (kSharedCopy && !ctx->hb_in && !ctx->hb_out) {
+    CopyLanes& L = g_lanes[ctx->device & 63];
+    std::lock_guard<std::mutex> g(L.create);
+    // The lanes are created at the HIGHEST stream priority: the runtime keeps one pool of hardware queues per priority, so a
+    // lane never shares a hardware queue with a context's (normal-priority) compute stream.  Streams that share a queue run
+    // one after the other; which streams share one depends on how many the process has created before, and that is what made
+    // the two-thread figure of the round-3 bench line dip (49 / 35 / 45 GB/s with 1 / 2 / 4 task threads after the other
+    // workloads had run in the process, 43 / 43 / 44 in a fresh one).  S3S_HB_LANE_PRIO=0: normal priority.
+    // S3S_HB_LANE_PRIO=2: upload lane highest, download lane LOWEST priority (three pools: the two lanes cannot share a queue either).
+    int least = 0, greatest = 0;
+    static const int prio = getenv("S3S_HB_LANE_PRIO") ? atoi(getenv("S3S_HB_LANE_PRIO")) : 1;
+    if (prio) (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (!L.in) HIP_TRY(ctx, hipStreamCreateWithPriority(&L.in, hipStreamNonBlocking, greatest));
+    if (!L.out) HIP_TRY(ctx, hipStreamCreateWithPriority(&L.out, hipStreamNonBlocking, prio == 2 ? least : greatest));
+    ctx->hb_in = L.in;
+    ctx->hb_out = L.out;
+    ctx->hb_shared = true;
+  }
   if (!ctx->hb_in) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->hb_in, hipStreamNonBlocking));
   if (!ctx->hb_out) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->hb_out, hipStreamNonBlocking));
   for (int i = 0; i < 2; i++) {
@@ -36,12 +76,36 @@ int hb_init(s3s_ctx* ctx) {
   return S3S_OK;
 }
 
+// holds the lane of one direction while a group's copies are enqueued (shared lanes only)
+struct LaneLock {
+  std::mutex* m;
+  LaneLock(s3s_ctx* ctx, bool upload) : m(nullptr) {
+    if (ctx->hb_shared) {
+      CopyLanes& L = g_lanes[ctx->device & 63];
+      m = upload ? &L.in_mu : &L.out_mu;
+      m->lock();
+    }
+  }
+  ~LaneLock() {
+    if (m) m->unlock();
+  }
+};
+
+// everything THIS context has put on the copy lanes is done (its group events; a shared lane may hold other contexts' copies)
+int hb_wait_own(s3s_ctx* ctx, bool in, bool out) {
+  for (int i = 0; i < 2; i++) {
+    if (in && ctx->hb_ev_in[i]) HIP_TRY(ctx, hipEventSynchronize(ctx->hb_ev_in[i]));
+    if (out && ctx->hb_ev_out[i]) HIP_TRY(ctx, hipEventSynchronize(ctx->hb_ev_out[i]));
+  }
+  return S3S_OK;
+}
+
 // the staging buffers are (re)allocated only while nothing of this context is in flight
 int hb_ensure(s3s_ctx* ctx, size_t in_bytes, size_t out_bytes) {
   if (in_bytes > ctx->buf[B_HB_IN0].cap || in_bytes > ctx->buf[B_HB_IN1].cap || out_bytes > ctx->buf[B_HB_OUT0].cap ||
       out_bytes > ctx->buf[B_HB_OUT1].cap) {
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->hb_in));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->hb_out));
+    int rc0 = hb_wait_own(ctx, true, true);
+    if (rc0) return rc0;
   }
   int rc;
   if ((rc = ensure(ctx, B_HB_IN0, in_bytes))) return rc;
@@ -53,10 +117,7 @@ int hb_ensure(s3s_ctx* ctx, size_t in_bytes, size_t out_bytes) {
 
 struct HbDrain {
   s3s_ctx* c;
-  ~HbDrain() {
-    (void)hipStreamSynchronize(c->hb_in);
-    (void)hipStreamSynchronize(c->hb_out);
-  }
+  ~HbDrain() { (void)hb_wait_own(c, true, true); }
 };
 
 inline int64_t al256(int64_t x) { return (x + 255) & ~int64_t(255); }
@@ -118,6 +179,7 @@ int s3s_compress_map_outputs_batch(s3s_ctx* ctx, int codec, int checksum_algo, s
   uint8_t* d_out[2] = {dev<uint8_t>(ctx, B_HB_OUT0), dev<uint8_t>(ctx, B_HB_OUT1)};
   // hb_in must not overwrite staging a previous call's kernels may still read: those calls synchronised ctx->stream
   auto upload = [&](int32_t g) -> int {
+    const LaneLock lane(ctx, true);
     int64_t off = 0;
     for (int32_t t = g0[(size_t)g]; t < g0[(size_t)g + 1]; t++) {
       const s3s_map_task& k = tasks[t];
@@ -161,6 +223,7 @@ int s3s_compress_map_outputs_batch(s3s_ctx* ctx, int codec, int checksum_algo, s
     if (rc != S3S_OK && rc != S3S_E_CAPACITY) return rc;
     if (ctx->profile)
       for (int s = 0; s < S3S_STAGE_COUNT; s++) stage_acc[s] += ctx->stage_ms[s];
+    const LaneLock lane(ctx, false);
     for (int32_t t = t0; t < t1; t++) {
       s3s_map_task& k = tasks[t];
       const s3s_map_task& d = dt[(size_t)(t - t0)];
@@ -176,7 +239,7 @@ int s3s_compress_map_outputs_batch(s3s_ctx* ctx, int codec, int checksum_algo, s
     }
     HIP_TRY(ctx, hipEventRecord(ctx->hb_ev_out[g & 1], ctx->hb_out));
   }
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->hb_out));
+  if ((rc = hb_wait_own(ctx, false, true))) return rc;
   if (ctx->profile)
     for (int s = 0; s < S3S_STAGE_COUNT; s++) ctx->stage_ms[s] = stage_acc[s];  // summed over the groups
   return verdict.finish(worst);
@@ -231,6 +294,7 @@ int s3s_decompress_ranges_batch(s3s_ctx* ctx, int codec, int checksum_algo, s3s_
   uint8_t* d_in[2] = {dev<uint8_t>(ctx, B_HB_IN0), dev<uint8_t>(ctx, B_HB_IN1)};
   uint8_t* d_out[2] = {dev<uint8_t>(ctx, B_HB_OUT0), dev<uint8_t>(ctx, B_HB_OUT1)};
   auto upload = [&](int32_t g) -> int {
+    const LaneLock lane(ctx, true);
     int64_t off = 0;
     for (int32_t r = g0[(size_t)g]; r < g0[(size_t)g + 1]; r++) {
       const s3s_fetch_range& k = ranges[r];
@@ -265,6 +329,7 @@ int s3s_decompress_ranges_batch(s3s_ctx* ctx, int codec, int checksum_algo, s3s_
     if (rc == S3S_E_INVALID || rc == S3S_E_HIP || rc == S3S_E_NOMEM) return rc;
     if (ctx->profile)
       for (int s = 0; s < S3S_STAGE_COUNT; s++) stage_acc[s] += ctx->stage_ms[s];
+    const LaneLock lane(ctx, false);
     for (int32_t r = r0; r < r1; r++) {
       s3s_fetch_range& k = ranges[r];
       const s3s_fetch_range& d = dr[(size_t)(r - r0)];
@@ -280,7 +345,7 @@ int s3s_decompress_ranges_batch(s3s_ctx* ctx, int codec, int checksum_algo, s3s_
     }
     HIP_TRY(ctx, hipEventRecord(ctx->hb_ev_out[g & 1], ctx->hb_out));
   }
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->hb_out));
+  if ((rc = hb_wait_own(ctx, false, true))) return rc;
   if (ctx->profile)
     for (int s = 0; s < S3S_STAGE_COUNT; s++) ctx->stage_ms[s] = stage_acc[s];
   return verdict.finish(worst);

@@ -178,9 +178,12 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
   const Frame fr = frames[f];
   const int olen = fr.orig_len, clen = fr.comp_len;
   const int lane = threadIdx.x;
-  // blocks above 32 KiB (a writer configured with a larger codec block size): not for this kernel — its sequence
-  // records keep stream offsets in 16 bits.  The host retries LZ4 ranges with the ring decoder, which has no limit.
-  if (olen > kMaxBlock && (kFmt == kFmtSnappy || fr.method != 0x10)) {
+  // LZ4 blocks above 32 KiB (a writer configured with a larger spark.io.compression.lz4.blockSize, S3ShuffleReader.scala:57-59)
+  // are decoded here as well since round 4: the records of a batch keep stream offsets and output positions RELATIVE to
+  // the batch's first token / first output byte (a batch of 64 fast-path sequences spans < 18 KiB of stream and < 35 KiB of
+  // output), so nothing but the frame header's own 32-bit lengths depends on the block size.  kBatchMaxBlock = lz4-java's
+  // largest block (1 << 25).  Snappy chunks stay at 32 KiB (snappy-java's block size cannot exceed the fragment size here).
+  if (olen > (kFmt == kFmtSnappy ? kMaxBlock : kBatchMaxBlock) && (kFmt == kFmtSnappy || fr.method != 0x10)) {
     if (lane == 0) atomicExch(status, S3S_E_UNSUPPORTED);
     return;
   }
@@ -218,8 +221,9 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
     if (!bad && (int)ulen != olen) bad = true;
   }
   if (bad) {
-  } else if (clen > kMaxBlock + kMaxBlock / 6 + 64 && !(kFmt == kFmtLz4 && fr.method == 0x10)) {
-    bad = true;  // no block of <= 32 KiB is that long (the records below keep stream offsets in 16 bits)
+  } else if ((kFmt == kFmtSnappy ? clen > kMaxBlock + kMaxBlock / 6 + 64 : (int64_t)clen > (int64_t)olen + olen / 255 + 16) &&
+             !(kFmt == kFmtLz4 && fr.method == 0x10)) {
+    bad = true;  // no block of that decoded size is that long (LZ4: LZ4_compressBound; a compressed frame is shorter than its block anyway)
   } else if (kFmt == kFmtLz4 && fr.method == 0x10) {  // stored frame
     for (int j = lane * 4; j < olen; j += kWave * 4) {
       if (j + 4 <= olen) {
@@ -235,6 +239,7 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
     bool need_drain = false;  // stores of a flush may still be in flight (matters to far matches only)
     int last_tokens = 0;      // tokens found in the previous parse window (picks the walk for this one)
     bool open_lit = false;    // Snappy: the batch's last record is a literal element that a following copy may join
+    int sbase = 0;            // stream position the batch's records count from (set with the batch's first record)
     BT_DECL;
 
     // ---- window management ---------------------------------------------------------------------------
@@ -379,7 +384,8 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
       const int lit = act ? (int)(rc.x & 0xffffu) : 0;
       const int ml = act ? (int)(rc.x >> 16) : 0;
       const int off = (int)(rc.y & 0xffffu);
-      const int src = (int)(rc.y >> 16);
+      const int src = (int)(rc.y >> 16) + sbase;
+      const int opb = op;  // the packed words below carry output positions relative to the batch's first byte
       // Pieces: a match of up to 64 bytes that is not an odd periodic pattern is copied as 1..4 PIECES of 16 bytes, one
       // lane per piece (`npc`); one inclusive prefix sum gives the output positions (low 22 bits; a lane's share is
       // clamped so that a malformed batch cannot carry into the piece count: its `end` is above olen either way) and
@@ -411,13 +417,13 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
       //   * a range that lies inside the output of ONE earlier match t reads what t copied: out[q] = out[q - off[t]]
       //     for every q there, so it can read from t's source instead — and so on along the chain (pointer doubling
       //     over the lanes; a match that overlaps its own output ends a chain, its bytes are not a plain shift).
-      const uint32_t me = (uint32_t)mstart | ((uint32_t)end << 16);
+      const uint32_t me = (uint32_t)(mstart - opb) | ((uint32_t)(end - opb) << 16);
       auto count_below = [&](int e) __attribute__((always_inline)) -> int {
         int n = 0;
 #pragma unroll
         for (int step = 32; step >= 1; step >>= 1) {
           const int probe = n + step - 1;  // candidate index
-          const int mv = (int)(__shfl(me, probe & 63) & 0xffffu);
+          const int mv = (int)(__shfl(me, probe & 63) & 0xffffu);  // (relative to opb, as is e)
           const bool take = probe < nseq && mv < e;
           n = take ? n + step : n;
         }
@@ -425,10 +431,10 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
       };
       const int need = off < ml ? off : ml;
       int a2 = mstart - off;
-      int dep = count_below(a2 + need);  // (<= lane: mstart[t] < a + need <= mstart[lane])
+      int dep = count_below(a2 + need - opb);  // (<= lane: mstart[t] < a + need <= mstart[lane])
       const int t1 = dep > 0 ? dep - 1 : 0;
       const uint32_t m1 = __shfl(me, t1);
-      const int ms1 = (int)(m1 & 0xffffu), en1 = (int)(m1 >> 16);
+      const int ms1 = (int)(m1 & 0xffffu) + opb, en1 = (int)(m1 >> 16) + opb;
       bool ground = ml == 0 || dep == 0 || a2 >= en1;  // in the literals of sequence `dep` / in front of the batch's matches
       const bool inside = ml > 0 && dep > 0 && a2 >= ms1 && a2 + need <= en1;  // inside the output of match t1
       if (ballot64(inside)) {
@@ -441,15 +447,16 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
         }
         const int st1 = __shfl(shift, t1);
         a2 -= inside ? st1 : 0;
-        dep = count_below(a2 + need);
+        dep = count_below(a2 + need - opb);
         const int t2 = dep > 0 ? dep - 1 : 0;
-        const int en2 = (int)(__shfl(me, t2) >> 16);
+        const int en2 = (int)(__shfl(me, t2) >> 16) + opb;
         ground = ml == 0 || dep == 0 || a2 >= en2;
       }
       if (ground) dep = 0;
       // what a piece's lane fetches from its sequence
-      const uint32_t W1 = (uint32_t)mstart | ((uint32_t)ml << 16);
-      const uint32_t W2 = (uint32_t)a2 | ((uint32_t)(off < ml ? off : 0) << 16);
+      // (a2 may lie up to a whole block in front of the batch: 28 signed bits; the period is 0, 1, 2 or 4)
+      const uint32_t W1 = (uint32_t)(mstart - opb) | ((uint32_t)ml << 16);
+      const uint32_t W2 = ((uint32_t)(a2 - opb) & 0x0fffffffu) | ((uint32_t)(off < ml ? off : 0) << 28);
       BT_MARK(1);
       int s0 = 0;
       while (s0 < nseq) {
@@ -534,8 +541,8 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
           const int sq = (int)(pe & 63u), k16 = (int)(pe >> 8) << 4;
           const uint32_t w1 = __shfl(W1, sq), w2 = __shfl(W2, sq);
           const bool actp = lane < np;
-          const int msq = (int)(w1 & 0xffffu), mlq = (int)(w1 >> 16);
-          const int aq = (int)(w2 & 0xffffu), pat = (int)(w2 >> 16);
+          const int msq = (int)(w1 & 0xffffu) + opb, mlq = (int)(w1 >> 16);
+          const int aq = ((int)(w2 << 4) >> 4) + opb, pat = (int)(w2 >> 28);
           int n = mlq - k16;
           n = n < 16 ? n : 16;
           const int so = aq + (pat ? 0 : k16);
@@ -725,7 +732,7 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
               cx = n6 > 61u || nxt > clen || len > kMaxBlock;
               is_lit = true;
               r0 = (uint32_t)len;
-              r1 = (uint32_t)(cpos + hdr) << 16;
+              r1 = (uint32_t)(lane + hdr) << 16;  // (window-relative; the batch's base is added when the record is stored)
             } else if (ty == 1u) {
               nxt = cpos + 2;
               cx = false;
@@ -763,7 +770,7 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
               cx = complex_;
               nxt = p2 + adv;
               r0 = (uint32_t)lit | ((uint32_t)(ml + 4) << 16);
-              r1 = (d1 & 0xffffu) | ((uint32_t)(cpos + hdr) << 16);
+              r1 = (d1 & 0xffffu) | ((uint32_t)(lane + hdr) << 16);
             }
           }
         }
@@ -858,9 +865,10 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
         if (r == 1) break;
         continue;
       }
+      if (nseq == 0) sbase = ip;  // (the batch in front of this window's records was flushed, or there was none)
       if ((mask >> lane) & 1ull) {
         const int t = nseq + __builtin_amdgcn_mbcnt_hi((uint32_t)(S >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)S, 0u));
-        if (!joined) rec[t] = make_uint2(r0, r1);
+        if (!joined) rec[t] = make_uint2(r0, r1 + ((uint32_t)(ip - sbase) << 16));  // stream offsets count from the batch's first token
       }
       if constexpr (kFmt == kFmtSnappy) {
         if (joined) {  // (after the record's first half has been stored by the literal's lane)
@@ -907,10 +915,10 @@ __global__ __launch_bounds__(kWave) void lz4_verify_frames_kernel(
     len = fr.orig_len;
     want = fr.check;
     g = dst + frame_out[f];
-    // a compressed frame above kMaxBlock was NOT decoded by batch_decode_kernel (status = S3S_E_UNSUPPORTED, the
+    // a compressed frame above kBatchMaxBlock was NOT decoded by batch_decode_kernel (status = S3S_E_UNSUPPORTED, the
     // caller retries with the ring decoder, which checks the hash itself): hashing the stale destination here
     // would replace that status with S3S_E_BAD_FRAME and suppress the retry
-    if (len > kMaxBlock && fr.method != 0x10) len = 0;
+    if (len > kBatchMaxBlock && fr.method != 0x10) len = 0;
   }
   const uint32_t seed = kLz4BlockSeed;
   uint32_t acc = l == 0 ? seed + XP1 + XP2 : l == 1 ? seed + XP2 : l == 2 ? seed : seed - XP1;

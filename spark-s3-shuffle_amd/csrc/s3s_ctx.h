@@ -62,6 +62,7 @@ struct s3s_ctx {
   const uint8_t* up_host = nullptr;  // host source of d_src[0, total_u), or nullptr (source already on the device)
   // host-buffer batch entry points (host_batch.hip): one DMA stream per PCIe direction next to the compute stream
   hipStream_t hb_in = nullptr, hb_out = nullptr;
+  bool hb_shared = false;  // hb_in / hb_out are the device's shared copy lanes (host_batch.hip: copy arbiter), not this context's to destroy
   hipEvent_t hb_ev_in[2] = {nullptr, nullptr}, hb_ev_out[2] = {nullptr, nullptr};
   double stage_ms[S3S_STAGE_COUNT] = {};
 };
@@ -202,6 +203,6 @@ inline int run_checksum(s3s_ctx* ctx, int algo, const uint8_t* d_data, const int
 }
 
 // Zstandard reduce side (zstd_decompress.hip): verify + decode (or only size) the frames of n_ranges device ranges
-int zstd_decompress_ranges(s3s_ctx* ctx, int checksum_algo, s3s_fetch_range* R, int32_t n_ranges, bool size_only);
+int zstd_decompress_ranges(s3s_ctx* ctx, int checksum_algo, s3s_fetch_range* R, int32_t n_ranges, bool size_only, bool* regular_end = nullptr);
 
 }  // namespace s3s

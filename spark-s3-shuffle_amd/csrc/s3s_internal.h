@@ -18,6 +18,7 @@ namespace s3s {
 
 constexpr int kWave = 64;
 constexpr int kMaxBlock = 32768;          // largest codec chunk the LDS-resident kernels take
+constexpr int kBatchMaxBlock = 1 << 25;   // largest LZ4Block frame the batch decoder takes (lz4-java's MAX_BLOCK_SIZE)
 constexpr int kSlotHeader = 32;           // bytes reserved in front of a slot's payload
 constexpr int kSlotBytes = kSlotHeader + kMaxBlock;
 constexpr int kLz4FrameHeader = 21;       // "LZ4Block" + token + 3 x i32

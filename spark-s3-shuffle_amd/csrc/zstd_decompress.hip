@@ -57,7 +57,8 @@ static_assert(s3s_zstd::ZS_BAD == S3S_E_BAD_FRAME && s3s_zstd::ZS_CAPACITY == S3
 
 // Verify + decode n_ranges fetched ranges (device buffers).  size_only: pass 1 alone, out_len = decoded bytes.
 // Per range: status / out_len / bad_partition as s3s_decompress_range_device reports them.  Returns the first error.
-int zstd_decompress_ranges(s3s_ctx* ctx, int checksum_algo, s3s_fetch_range* R, int32_t n_ranges, bool size_only) {
+int zstd_decompress_ranges(s3s_ctx* ctx, int checksum_algo, s3s_fetch_range* R, int32_t n_ranges, bool size_only, bool* regular_end) {
+  if (regular_end) *regular_end = false;  // true: every range has its own verdict (the return value is the first bad one's)
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   for (auto& v : ctx->stage_ms) v = 0;
   int64_t n_parts64 = 0, n_segs64 = 0;
@@ -82,7 +83,10 @@ int zstd_decompress_ranges(s3s_ctx* ctx, int checksum_algo, s3s_fetch_range* R, 
       }
     return S3S_OK;
   };
-  if (n_parts == 0) return S3S_OK;
+  if (n_parts == 0) {
+    if (regular_end) *regular_end = true;
+    return S3S_OK;
+  }
   // pinned staging: [ZPart n_parts][ZRes n_parts][offsets + seg starts + sums per range]
   auto al = [](size_t x) { return (x + 15) & ~size_t(15); };
   const size_t o_parts = 0, o_res = al(o_parts + sizeof(ZPart) * (size_t)n_parts), o_off = al(o_res + sizeof(ZRes) * (size_t)n_parts),
@@ -195,6 +199,7 @@ int zstd_decompress_ranges(s3s_ctx* ctx, int checksum_algo, s3s_fetch_range* R, 
       hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); ctx->stage_ms[S3S_STAGE_CHECKSUM] = ms;
       hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]); ctx->stage_ms[S3S_STAGE_DISCOVER] = ms;
     }
+    if (regular_end) *regular_end = true;
     return first_error();
   }
   // ---- pass 2: decode ------------------------------------------------------------------------------------------------------
@@ -222,6 +227,7 @@ int zstd_decompress_ranges(s3s_ctx* ctx, int checksum_algo, s3s_fetch_range* R, 
           k.status = h_res[pp].rc != 0 ? h_res[pp].rc : S3S_E_BAD_FRAME;
     }
   }
+  if (regular_end) *regular_end = true;
   return first_error();
 }
 

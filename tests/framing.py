@@ -239,6 +239,16 @@ def liblz4():
     return L
 
 
+def lz4_fast(d: np.ndarray) -> bytes:
+    """liblz4's LZ4_compress_default on the whole input (>= 64 KiB: its byU32 parse - what a JVM writer with
+    spark.io.compression.lz4.blockSize above 32k puts into one LZ4Block frame)"""
+    L = liblz4()
+    out = np.empty(d.size + d.size // 200 + 64, np.uint8)
+    n = L.LZ4_compress_default(d.ctypes.data, out.ctypes.data, d.size, out.size)
+    assert n > 0
+    return out[:n].tobytes()
+
+
 def lz4_hc(d: np.ndarray, level: int = 9) -> bytes:
     L = liblz4()
     out = np.empty(d.size + d.size // 200 + 64, np.uint8)

@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <cstring>
 #include <algorithm>
+#include <vector>
 
 namespace {
 
@@ -45,11 +46,11 @@ struct Model {
   long st_seqs = 0, st_roundseqs = 0, st_brk_len = 0, st_brk_dep = 0, st_brk_far = 0, st_windows = 0, st_batches = 0, st_rounds = 0, st_single = 0, st_slow = 0, st_slides = 0, st_far = 0;
 
   // which output bytes have their final value (test instrumentation: a round may only read such bytes)
-  uint8_t fin[32768 + 64];
+  std::vector<uint8_t> fin;  // (sized olen + 64 by the entry point: blocks above 32 KiB since round 4)
   bool hazard = false;
   uint16_t plist[256];
-  void fin_set(int o) { if (o >= 0 && o < (int)sizeof fin) fin[o] = 1; }
-  bool fin_get(int o) const { return o >= 0 && o < (int)sizeof fin && fin[o] != 0; }
+  void fin_set(int o) { if (o >= 0 && o < (int)fin.size()) fin[(size_t)o] = 1; }
+  bool fin_get(int o) const { return o >= 0 && o < (int)fin.size() && fin[(size_t)o] != 0; }
   uint8_t rdc(int pos) {
     if (pos < 0 || pos >= clen) { oob = true; return 0; }
     return c[pos];
@@ -535,6 +536,7 @@ extern "C" int batch_decode_model(int fmt, const uint8_t* comp, int clen, uint8_
   m.clen = clen;
   m.out = out;
   m.olen = olen;
+  m.fin.assign((size_t)(olen > 0 ? olen : 0) + 64, 0);
   m.sh = out_misalign & 15;
   int rc = m.run();
   if (m.hazard) rc = -3;  // a round read a byte that was not final yet: always a bug

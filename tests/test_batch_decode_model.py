@@ -98,7 +98,7 @@ def test_lz4_hand_made_blocks(model):
                 assert run(model, LZ4, blk, olen)[0] == -1, (i, olen)
 
 
-def _chain_sequences(rng, n_seq):
+def _chain_sequences(rng, n_seq, max_out=30000):
     """Random (literal length, offset, match length) lists in which matches copy from inside earlier matches, from
     literal runs, from periodic patterns and across several of them — what the decoder's source redirection
     (a match inside the output of one earlier match reads from that match's source) has to get right."""
@@ -129,7 +129,7 @@ def _chain_sequences(rng, n_seq):
         seqs.append((lit, off, ml))
         regions.append((pos, pos + ml))
         pos += ml
-        if pos > 30000:
+        if pos > max_out:
             break
     return seqs
 
@@ -158,6 +158,30 @@ def test_redirected_sources(model):
         if swant is not None and 0 < len(swant) <= 32768:
             rc, got = run(model, SNAPPY, sblk, len(swant), it)
             assert rc == 0 and got.tobytes() == swant, it
+
+
+def test_blocks_above_32k(model):
+    """round 4: the batch decoder takes LZ4 blocks of any size (records relative to the batch): liblz4 fast / HC blocks of
+    70 000 - 300 000 bytes with offsets up to 65 535, a chained 90 KB block; every index inside the buffers, no round reads a
+    byte before its last writer; a malformed big block is refused"""
+    from s3shuffle import datagen
+
+    rng = np.random.default_rng(31)
+    big1 = datagen.terasort_map_output(70_000, 1, seed=5)[0]
+    big2 = np.concatenate([datagen.tpcds_wide_map_output(200_000, 1, seed=6)[0][:200_000], corpus.chunk_corpus(7, 100_000, rng)])
+    cases = [(framing.lz4_fast(big1), big1.tobytes()), (framing.lz4_hc(big2, 9), big2.tobytes()), (framing.lz4_fast(big2), big2.tobytes())]
+    seqs = _chain_sequences(rng, 6000, max_out=90_000)
+    b = framing.lz4_block([(rng.integers(0, 256, l).astype(np.uint8).tobytes(), o, m) for l, o, m in seqs], b"abcdefg")
+    cases.append((b, framing.lz4_decode_py(b)))
+    assert len(cases[-1][1]) > 40_000
+    for mis in (0, 5):
+        for c, w in cases:
+            rc, got = run(model, 0, c, len(w), mis)
+            assert rc == 0 and got.tobytes() == w
+    z = rng.integers(0, 256, 40_000).astype(np.uint8).tobytes()
+    bad = framing.lz4_block([(z, 40_001, 8)], b"tail!")
+    rc, _ = run(model, 0, bad, 40_000 + 8 + 5)
+    assert rc == -1
 
 
 def test_lz4_malformed_blocks_are_refused(model):

@@ -156,11 +156,11 @@ def test_codec_none_passthrough(gpu_codec, oracle):
 
 
 def test_blocks_above_32k_from_a_foreign_writer(gpu_codec, oracle):
-    """A JVM writer configured with spark.io.compression.lz4.blockSize=64k produces 64 KiB LZ4Block frames.  The
-    batch decoder keeps stream offsets in 16 bits and reports such frames as unsupported; the library retries the
-    range with the ring decoder, so the caller gets the bytes either way (also through the batched entry point).
-    The destination is painted first: a decoder that skips the frames cannot pass on what an earlier call left there
-    (round-2 advisor finding: the frame-check kernel used to overwrite UNSUPPORTED with BAD_FRAME)."""
+    """A JVM writer configured with spark.io.compression.lz4.blockSize=64k produces 64 KiB LZ4Block frames.  Since round 4
+    the batch decoder takes them itself (its records are relative to the batch, see lz4_decode_batch.hip); before, the
+    library retried the range with the ring decoder.  The caller gets the bytes either way (also through the batched entry
+    point).  The destination is painted first: a decoder that skips the frames cannot pass on what an earlier call left
+    there (round-2 advisor finding: the frame-check kernel used to overwrite UNSUPPORTED with BAD_FRAME)."""
     from hipdev import Dev
 
     rng = np.random.default_rng(41)
@@ -190,3 +190,69 @@ def test_blocks_above_32k_from_a_foreign_writer(gpu_codec, oracle):
         assert np.array_equal(dev.download(d_out2, small.size), small)
     finally:
         dev.free()
+
+
+def _jvm_stream(data: np.ndarray, block_size: int) -> bytes:
+    """What LZ4BlockOutputStream(blockSize) writes for one partition, built WITHOUT oracle or product: liblz4's
+    LZ4_compress_default per block (>= 64 KiB: its byU32 parse), token level = log2(blockSize) - 10, stored block when
+    compression does not help, end frame."""
+    import struct
+
+    import framing
+
+    level = max(0, int(block_size).bit_length() - 1 - 10)
+    out = bytearray()
+    for p in range(0, data.size, block_size):
+        chunk = np.ascontiguousarray(data[p:p + block_size])
+        payload = framing.lz4_fast(chunk)
+        raw = len(payload) >= chunk.size
+        body = chunk.tobytes() if raw else payload
+        out += b"LZ4Block" + bytes([(0x10 if raw else 0x20) | level]) + struct.pack(
+            "<iiI", len(body), chunk.size, framing.xxh32(chunk.tobytes()) & 0x0FFFFFFF) + body
+    if data.size:
+        out += b"LZ4Block" + bytes([0x10 | level]) + struct.pack("<iii", 0, 0, 0)
+    return bytes(out)
+
+
+@pytest.mark.parametrize("block_size", [65536, 131072, 262144, 1 << 20])
+def test_blocks_above_32k_every_jvm_block_size(gpu_codec, block_size):
+    """objects of writers with spark.io.compression.lz4.blockSize = 64k ... 1m (S3ShuffleReader.scala:57-59
+    hands the key to the codec) decode through the default reduce-side call — partitions of ragged sizes, an incompressible
+    one (stored blocks), an empty one; single range, batch range and the batched entry point; checksums verified; a flipped
+    payload byte in a big frame is caught by the frame check when checksums are off."""
+    import zlib
+
+    from hipdev import Dev
+    from s3shuffle import datagen
+
+    rng = np.random.default_rng(block_size % 1000)
+    parts = [datagen.terasort_map_output(3 * block_size + 12_345, 1, seed=3)[0],
+             np.zeros(0, np.uint8),
+             rng.integers(0, 256, block_size + 77, dtype=np.uint8),
+             datagen.tpcds_wide_map_output(2 * block_size + 999, 1, seed=4)[0][:2 * block_size + 999],
+             corpus.chunk_corpus(7, block_size // 2 + 5, rng)]
+    streams = [np.frombuffer(_jvm_stream(p, block_size), np.uint8) for p in parts]
+    img = np.concatenate(streams)
+    index = np.concatenate([[0], np.cumsum([s.size for s in streams])]).astype(np.int64)
+    sums = np.array([zlib.adler32(s.tobytes()) for s in streams], np.int64)
+    data = np.concatenate(parts)
+    out = gpu_codec.decompress_range(LZ4, ADLER, img, index, sums, dst_capacity=data.size)
+    assert np.array_equal(out, data)
+    # partitions 2..4 as a batch range (relative index), then two ranges through the batched entry point
+    sub = gpu_codec.decompress_range(LZ4, ADLER, img[index[2]:], index[2:] - index[2], sums[2:],
+                                     dst_capacity=sum(p.size for p in parts[2:]))
+    assert np.array_equal(sub, np.concatenate(parts[2:]))
+    dev = Dev()
+    try:
+        d_img = dev.upload(img)
+        o1, o2 = dev.alloc(data.size), dev.alloc(parts[0].size)
+        res = gpu_codec.decompress_ranges_batch_device(
+            LZ4, ADLER, [(d_img, img.size, index, sums, o1, data.size), (d_img, int(index[1]), index[:2], sums[:1], o2, parts[0].size)])
+        assert [r[0] for r in res] == [0, 0] and [r[1] for r in res] == [data.size, parts[0].size]
+        assert np.array_equal(dev.download(o1, data.size), data) and np.array_equal(dev.download(o2, parts[0].size), parts[0])
+    finally:
+        dev.free()
+    bad = img.copy()
+    bad[index[0] + 21 + 5000] ^= 0x01  # inside the first big frame's payload
+    with pytest.raises(Exception):
+        gpu_codec.decompress_range(LZ4, 0, bad, index, None, dst_capacity=data.size)

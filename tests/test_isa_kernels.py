@@ -239,6 +239,34 @@ def test_compiled_decoder_on_chained_sources(oracle):
 
 
 
+def test_compiled_batch_decoder_takes_blocks_above_32k(oracle):
+    """round 4: LZ4Block frames of a writer with spark.io.compression.lz4.blockSize above 32k go through
+    the BATCH decoder (records relative to the batch's first token / first output byte): a 70 000-byte and a 150 000-byte
+    block of liblz4 (fast and HC: offsets up to 65 535 behind, far outside the LDS window), chained sources in a 90 KB block,
+    payload and destination of exactly their sizes; a malformed big block is S3S_E_BAD_FRAME without leaving its buffers"""
+    import decode_kernel as dk
+    import framing
+    import test_batch_decode_model as tm
+    from s3shuffle import datagen
+
+    rng = np.random.default_rng(47)
+    big1 = datagen.terasort_map_output(70_000, 1, seed=5)[0]
+    big2 = np.concatenate([datagen.tpcds_wide_map_output(100_000, 1, seed=6)[0][:100_000], corpus.chunk_corpus(7, 50_000, rng)])
+    cases = [(bytes(framing.lz4_fast(big1)), big1.tobytes()), (framing.lz4_hc(big2, 9), big2.tobytes())]
+    seqs = tm._chain_sequences(rng, 6000, max_out=60_000)
+    b = framing.lz4_block([(rng.integers(0, 256, l).astype(np.uint8).tobytes(), o, m) for l, o, m in seqs], b"abcdefg")
+    w = framing.lz4_decode_py(b)
+    assert len(w) > 40_000
+    cases.append((b, w))
+    res, st, _ = dk.decode_blocks([(c, len(x)) for c, x in cases], fmt=0)
+    assert st == 0 and res == [x for _, x in cases]
+    # malformed: an offset that points in front of the block, 40 KB into a big block
+    z = rng.integers(0, 256, 40_000).astype(np.uint8).tobytes()
+    bad = framing.lz4_block([(z, 40_001, 8)], b"tail!")
+    _, st, _ = dk.decode_blocks([(bad, 40_000 + 8 + 5)], fmt=0)
+    assert st == -3
+
+
 def test_compiled_ring_decoders(oracle):
     """the ring decoders (lz4_decompress_valu_kernel / snappy_decompress_valu_kernel: decode variant 3, and where LZ4 frames
     above 32 KiB go) as hipcc compiles them, payload buffer and destination of exactly their sizes (the payload rounded up to

@@ -148,3 +148,46 @@ for name, gen in (("terasort", lambda: datagen.skew_block(32768 * 4, "terasort",
               f"(of matches > 12 B: {100 * (mdist[m[:, 2] > 12] >= ring - 80).mean():5.1f} %)")
     print("  candidate distance percentiles (10/50/90/99):", [int(np.percentile(dist, q)) for q in (10, 50, 90, 99)],
           " match distance:", [int(np.percentile(mdist, q)) for q in (10, 50, 90, 99)])
+
+    # round 4: how much of a window's chain of sequences could be resolved lane-parallel?  A sequence is
+    # SIMPLE if nothing about it needs the scalar run loop: its match is what the window's one gather saw (the probe is no
+    # duplicate-hash suspect: no lower position of the same window has its hash), no suspect probe lies in the literal run in
+    # front of it, and the match is settled by the gather's 16 bytes (<= 4 backward, <= 8 + 4 forward).  The lane-parallel chain
+    # would take a window's leading run of simple sequences and hand the rest to the scalar loop.
+    hashes = {}
+    lead, total_seq, simple_seq, wins = [], 0, 0, 0
+    for c_i in range(4):
+        d = data[c_i * 32768:(c_i + 1) * 32768]
+        blk, inserted, probes, H = replay(d.tobytes())
+        hv = [H(p) for p in range(len(d) - 3)]
+        pset = set(probes)
+        by_win = {}
+        for ip, mt, ml in replay.matches:
+            by_win.setdefault(ip // 64, []).append((ip, mt, ml))
+        prev_end = 0
+        for w in sorted(by_win):
+            wb = w * 64
+            run, ok = 0, True
+            for ip, mt, ml in by_win[w]:
+                total_seq += 1
+                # suspects among the probes of this sequence's literal run (window part) and its own probe lane
+                lo = max(prev_end, wb)
+                susp = False
+                for p in range(lo, ip + 1):
+                    if p in pset and any(hv[q] == hv[p] for q in range(wb, p) if q < len(hv)):
+                        susp = True
+                        break
+                # the probe that found the match is at ip + (backward extension); backward <= 4 and forward <= 12 from the gather
+                simple = (not susp) and ml <= 12
+                if ok and simple:
+                    run += 1
+                    simple_seq += 1
+                else:
+                    ok = False
+                prev_end = ip + ml
+            lead.append(run)
+            wins += 1
+    lead = np.array(lead)
+    print(f"  lane-parallel chains: {total_seq} sequences in {wins} windows with a sequence; leading simple run per window: mean {lead.mean():.2f}, "
+          f"windows with a run >= 2: {100 * (lead >= 2).mean():.0f} %, >= 3: {100 * (lead >= 3).mean():.0f} %; sequences inside leading runs of >= 2: "
+          f"{100 * lead[lead >= 2].sum() / max(total_seq, 1):.0f} % of all sequences")
