@@ -1,7 +1,8 @@
 //
 // S3GpuBlockDecoder — what S3ShuffleReader.read (storage/S3ShuffleReader.scala:98-110) calls instead of
 //   new S3ChecksumValidationStream(blockId, stream, algo)  +  serializerManager.wrapStream(blockId, …)
-// when spark.shuffle.s3.gpu.enabled=true (scala/patches/0001-gpu-codec.patch): the prefetched block range (one
+// when the reduce side of the GPU path is on (dispatcher.gpuReadEnabled, scala/patches/0001-gpu-codec.patch: with GPU writers,
+// or on its own over the objects of JVM writers - lz4 of any block size, snappy, zstd): the prefetched block range (one
 // ShuffleBlockId or one ShuffleBlockBatchId = several contiguous partitions of one map output,
 // S3ShuffleBlockIterator.scala:37-42) is verified per partition against the `.checksum` object and decoded in ONE
 // library call; the deserializer then reads plain bytes.
@@ -36,12 +37,19 @@ object S3GpuBlockDecoder {
     lengths(r1) - lengths(r0)
   }
 
-  /** True when `decode` should take this block (the reader keeps the JVM stack otherwise). */
+  /** True when `decode` should take this block (the reader keeps the JVM stack otherwise).  The codec is the one the stored
+    * objects carry (dispatcher.gpuReadCodec: spark.shuffle.s3.gpu.codec for GPU writers, spark.io.compression.codec for JVM
+    * writers).  Zstandard: one wavefront decodes one partition's frame at ~10 MB/s, so the library only pays when a range
+    * holds MANY small frames - a batch range of at least spark.shuffle.s3.gpu.zstd.minPartitions partitions whose mean size
+    * is at most spark.shuffle.s3.gpu.zstd.maxFrameBytes; everything else stays with zstd-jni on the task thread. */
   def accepts(blockId: BlockId): Boolean = {
     val d = S3ShuffleDispatcher.get
-    d.gpuEnabled && S3SCodec.supports(d.gpuCodec) && {
+    d.gpuReadEnabled && S3SCodec.supportsDecode(d.gpuReadCodec) && {
       val n = compressedLength(blockId)
-      n >= d.gpuMinBytes && n <= S3GpuBuffers.MaxBuffer
+      val (_, _, r0, r1) = range(blockId)
+      val zstdOk = d.gpuReadCodec != "zstd" ||
+        (r1 - r0 >= d.gpuZstdMinPartitions && n / math.max(r1 - r0, 1) <= d.gpuZstdMaxFrameBytes)
+      n >= d.gpuMinBytes && n <= S3GpuBuffers.MaxBuffer && zstdOk
     }
   }
 
@@ -51,7 +59,7 @@ object S3GpuBlockDecoder {
     val dispatcher = S3ShuffleDispatcher.get
     val (shuffleId, mapId, r0, r1) = range(blockId)
     val ctx = S3SCodec.forThread(S3SCodec.deviceFor(mapId, S3SCodec.devices()))
-    val codec = S3SCodec.codecId(dispatcher.gpuCodec)
+    val codec = S3SCodec.decodeCodecId(dispatcher.gpuReadCodec)
     val algo = S3SCodec.checksumId(dispatcher.checksumEnabled, dispatcher.checksumAlgorithm)
     // cumulative `.index` of the map output, relative to the range
     val lengths = S3ShuffleHelper.getPartitionLengths(shuffleId, mapId)

@@ -23,7 +23,7 @@ import org.apache.spark.SparkException
 object S3SCodec {
   // ---- constants of include/s3shuffle_codec.h ----------------------------------------------------------------
   val CODEC_NONE = 0; val CODEC_LZ4 = 1; val CODEC_SNAPPY = 2
-  val CODEC_ZSTD = 3 // reduce side only (decompressRange*, decompressedSize); the shipped patch keeps zstd jobs on the JVM, INTEGRATION.md
+  val CODEC_ZSTD = 3 // reduce side only (decompressRange*, decompressedSize): S3GpuBlockDecoder takes ranges of many small frames, INTEGRATION.md
   val CHECKSUM_NONE = 0; val CHECKSUM_ADLER32 = 1; val CHECKSUM_CRC32 = 2
   val OK = 0; val E_INVALID = -1; val E_CAPACITY = -2; val E_BAD_FRAME = -3; val E_CHECKSUM = -4; val E_HIP = -5
   val STATUS_NOT_RUN = -100 // per-entry status of a batch call that failed before this entry had a verdict: the call's return code is its error
@@ -153,6 +153,18 @@ object S3SCodec {
     case "lz4" => CODEC_LZ4
     case "snappy" => CODEC_SNAPPY
     case other => throw new IllegalArgumentException(s"spark.io.compression.codec=$other stays on the JVM codecs")
+  }
+
+  /** The reduce side decodes one codec more than the map side compresses: Zstandard frames as zstd-jni writes them
+    * (S3S_CODEC_ZSTD: decompressRange*, decompressedSize).  LZF stays on the JVM. */
+  def supportsDecode(sparkCodecShortName: String): Boolean = sparkCodecShortName.toLowerCase match {
+    case "lz4" | "snappy" | "zstd" => true
+    case _ => false
+  }
+
+  def decodeCodecId(sparkCodecShortName: String): Int = sparkCodecShortName.toLowerCase match {
+    case "zstd" => CODEC_ZSTD
+    case other => codecId(other)
   }
 
   def checksumId(enabled: Boolean, algorithm: String): Int =

@@ -46,7 +46,11 @@ def test_patch_applies_to_the_reference(patched_tree):
     w = _read(patched_tree, "src/main/scala/org/apache/spark/shuffle/S3ShuffleMapOutputWriter.scala")
     assert "gpu.append(reduceId, b, off, len)" in w and "return gpu.commit()" in w
     r = _read(patched_tree, "src/main/scala/org/apache/spark/storage/S3ShuffleReader.scala")
-    assert "S3GpuBlockDecoder.decode(blockId, stream, jvmStack)" in r
+    assert "S3GpuBlockDecoder.decode(blockId, stream, jvmPlain)" in r
+    # the reduce side on its own (round 4): JVM-written objects go through wrapStream inside the fallback stack, GPU-written
+    # ones through the codec named by spark.shuffle.s3.gpu.codec; what reaches the deserializer is plain either way
+    assert "serializerManager.wrapStream(blockId, checkedStream)" in r and ".deserializeStream(plainStream)" in r
+    assert "dispatcher.gpuReadEnabled && S3GpuBlockDecoder.accepts(blockId)" in r
 
 
 def test_config_keys_used_by_the_shim_are_defined_by_the_patch(patched_tree):
@@ -62,6 +66,30 @@ def test_config_keys_used_by_the_shim_are_defined_by_the_patch(patched_tree):
     integ = _read(ROOT, "INTEGRATION.md")
     for key in re.findall(r'"(spark\.shuffle\.s3\.gpu\.\w+)"', disp):
         assert key in integ, key
+
+
+def test_reduce_side_on_its_own_and_the_zstd_gate(patched_tree):
+    """the Zstandard decoder and the big-block LZ4 decoder have a caller.  With JVM writers
+    (spark.shuffle.compress=true) the patched reader still hands prefetched ranges to the library: lz4 of any block size,
+    snappy up to 32k, zstd only for batch ranges of many small frames; never together with IO encryption or
+    useSparkShuffleFetch.  The map side keeps its own gate (lz4 / snappy, blocks up to 32k)."""
+    disp = _read(patched_tree, "src/main/scala/org/apache/spark/shuffle/helper/S3ShuffleDispatcher.scala")
+    m = re.search(r"val gpuReadEnabled: Boolean = gpuEnabled \|\| \{(.*?)\n  \}", disp, re.S)
+    assert m, "gpuReadEnabled"
+    body = m.group(1)
+    for needle in ('case "lz4" | "zstd" => true', 'case "snappy" => gpuSnappyBlockSize <= 32768', "conf.get(config.SHUFFLE_COMPRESS)",
+                   "!conf.get(config.IO_ENCRYPTION_ENABLED)", "!useSparkShuffleFetch", "spark.shuffle.s3.gpu.read.enabled"):
+        assert needle in body, needle
+    assert 'val gpuReadCodec: String = if (gpuEnabled) gpuCodec else conf.get("spark.io.compression.codec", "lz4")' in disp
+    # the write-side gate is unchanged: blocks above 32k and zstd / lzf keep the JVM codecs there
+    assert "val blockSupported = blockSize >= 64 && blockSize <= 32768" in disp and 'val supported = gpuCodec == "lz4" || gpuCodec == "snappy"' in disp
+    dec = _read(SHIM, "S3GpuBlockDecoder.scala")
+    assert "S3SCodec.decodeCodecId(dispatcher.gpuReadCodec)" in dec
+    assert "r1 - r0 >= d.gpuZstdMinPartitions" in dec and "<= d.gpuZstdMaxFrameBytes" in dec
+    codec = _read(SHIM, "S3SCodec.scala")
+    assert re.search(r'def supportsDecode.*?case "lz4" \| "snappy" \| "zstd" => true', codec, re.S)
+    assert re.search(r'def supports\(.*?case "lz4" \| "snappy" => true', codec, re.S)  # the map side: no zstd
+    assert re.search(r'def decodeCodecId.*?case "zstd" => CODEC_ZSTD', codec, re.S)
 
 
 def test_methods_the_patch_calls_exist_in_the_shim():
