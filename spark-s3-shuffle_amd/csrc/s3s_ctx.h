@@ -25,6 +25,7 @@ enum BufId {
   B_FRAME_OUT, B_REF_SUMS, B_ITEM_CHECK, B_RANGES, B_TILE_RANGE,
   B_HB_IN0, B_HB_IN1, B_HB_OUT0, B_HB_OUT1,  // host-buffer batch pipeline (host_batch.hip): double-buffered device staging
   B_WORK,  // block counter of the persistent codec grid
+  B_ZSCRATCH, B_ZPIECES,  // zstd single pass: decoded partitions at guessed capacities, and the compaction's piece list
   B_COUNT
 };
 

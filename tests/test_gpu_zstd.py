@@ -138,3 +138,40 @@ def test_compression_with_zstd_is_refused(gpu_codec):
     with pytest.raises(s3shuffle.CodecError) as ei:
         gpu_codec.compress_map_output(ZSTD, ADLER, data, [0, 1000])
     assert ei.value.code in (-6, -1)
+
+
+def test_single_pass_and_its_fallback(gpu_codec):
+    """round 4: partitions are decoded ONCE into a scratch area at a guessed capacity (8 x the compressed size) and moved
+    back to back by a copy kernel; one partition that outgrows the guess (zeros: 1000 : 1) sends the call to the two-pass
+    form.  Both forms give the same bytes, single range and batched ranges, ragged partition sizes incl. empty ones, a
+    destination painted behind its end."""
+    from hipdev import Dev
+    from s3shuffle import datagen
+
+    rng = np.random.default_rng(9)
+    plain, poffs = corpus.ragged_map_output(rng, 23, 600_000)
+    z_parts = [np.zeros(300_000, np.uint8), corpus.chunk_corpus(7, 50_000, rng), np.zeros(0, np.uint8), np.full(70_000, 65, np.uint8)]
+    zdata = np.concatenate(z_parts)
+    zoffs = np.concatenate([[0], np.cumsum([p.size for p in z_parts])]).astype(np.int64)
+    cases = [(plain, poffs), (zdata, zoffs)]  # the second one cannot stay inside its guesses
+    imgs = [_image(CRC, d, o) for d, o in cases]
+    for (d, o), (img, index, sums) in zip(cases, imgs):
+        assert np.array_equal(gpu_codec.decompress_range(ZSTD, CRC, img, index, sums, dst_capacity=d.size), d)
+    dev = Dev()
+    try:
+        args, outs = [], []
+        for (d, o), (img, index, sums) in zip(cases + cases[:1], imgs + imgs[:1]):
+            d_out = dev.upload(np.full(d.size + 32, 0x5A, np.uint8))
+            outs.append((d_out, d))
+            args.append((dev.upload(img), img.size, index, sums, d_out, d.size))
+        for sel in ([0, 2], [0, 1, 2]):  # all inside their guesses / one range outgrows -> whole call in two passes
+            res = gpu_codec.decompress_ranges_batch_device(ZSTD, CRC, [args[i] for i in sel])
+            for i, (st, n, bad) in zip(sel, res):
+                back = dev.download(outs[i][0], outs[i][1].size + 32)
+                assert st == 0 and n == outs[i][1].size and np.array_equal(back[:n], outs[i][1]) and np.all(back[n:] == 0x5A)
+        # a destination one byte short is S3S_E_CAPACITY in the single pass too, with the size it needs
+        a = args[0]
+        res = gpu_codec.decompress_ranges_batch_device(ZSTD, CRC, [(a[0], a[1], a[2], a[3], a[4], plain.size - 1), args[2]], raise_on_error=False)
+        assert res[0][0] == -2 and res[0][1] == plain.size and res[1][0] == 0
+    finally:
+        dev.free()

@@ -19,6 +19,7 @@ def replay(d: bytes):
     H = lambda p: ((rd32(p) * 2654435761) & 0xFFFFFFFF) >> 19  # noqa: E731
     table = {}
     inserted, probes = set(), []
+    seqinfo = []
     cands, matches = [], []   # (probe position, candidate the table returned), (ip, match, length) of every sequence
     out = bytearray()
     mfl1, matchlimit = n - 12 + 1, n - 5
@@ -66,14 +67,23 @@ def replay(d: bytes):
                     break
             if done:
                 break
+            probe_pos = ip
             while ip > anchor and match > 0 and d[ip - 1] == d[match - 1]:
                 ip -= 1; match -= 1
+            replay.probe_of = getattr(replay, "probe_of", {})
             while True:
                 m = 4
                 while ip + m < matchlimit and d[ip + m] == d[match + m]:
                     m += 1
                 emit(ip, match, m)
                 matches.append((ip, match, m))
+                pp = probe_pos if probe_pos >= ip else ip  # (a sequence found by the immediate re-probe behind a match has no backward part)
+                k = 0  # what the gather sees: equal bytes in front of probe / candidate, up to 4, whatever the anchor
+                cpos = match + (pp - ip)
+                while k < 5 and pp - 1 - k >= 0 and cpos - 1 - k >= 0 and d[pp - 1 - k] == d[cpos - 1 - k]:
+                    k += 1
+                seqinfo.append((pp, ip + m, m - (pp - ip) - 4, k, cpos))  # probe, end, forward bytes beyond the 4, backward seen, candidate
+                probe_pos = -1
                 ip += m
                 anchor = ip
                 if ip >= mfl1:
@@ -95,7 +105,7 @@ def replay(d: bytes):
         while r >= 255: out.append(255); r -= 255
         out.append(r)
     out.extend(d[anchor:])
-    replay.cands, replay.matches = cands, matches
+    replay.cands, replay.matches, replay.seqinfo = cands, matches, seqinfo
     return bytes(out), inserted, probes, H
 
 
@@ -191,3 +201,51 @@ for name, gen in (("terasort", lambda: datagen.skew_block(32768 * 4, "terasort",
     print(f"  lane-parallel chains: {total_seq} sequences in {wins} windows with a sequence; leading simple run per window: mean {lead.mean():.2f}, "
           f"windows with a run >= 2: {100 * (lead >= 2).mean():.0f} %, >= 3: {100 * (lead >= 3).mean():.0f} %; sequences inside leading runs of >= 2: "
           f"{100 * lead[lead >= 2].sum() / max(total_seq, 1):.0f} % of all sequences")
+
+    # round 4: the lane-parallel stage exactly as designed for the window block: chain = consecutive SIMPLE events from
+    # the window's first event: match seen by the gather, probe lane in no duplicate-hash group of the window's live lanes, forward
+    # length uncapped (< 8 beyond the 4), backward count exact (< 4, candidate >= 4), the match ends inside the window, at most 14
+    # literals; the stage runs when the chain has at least 2 elements.
+    cov = tot = stages = 0
+    clen = []
+    for c_i in range(4):
+        d = data[c_i * 32768:(c_i + 1) * 32768]
+        blk, inserted, probes, H = replay(d.tobytes())
+        hv = [H(p) for p in range(len(d) - 3)]
+        pset = set(probes)
+        info = {pp: (end, fwd, k, cpos) for pp, end, fwd, k, cpos in replay.seqinfo}
+        wins = {}
+        for pp in sorted(info):
+            wins.setdefault(pp // 64, []).append(pp)
+        tot += len(info)
+        prev_end = {}
+        ends = sorted((pp, info[pp][0]) for pp in info)
+        for w, pps in wins.items():
+            wb = w * 64
+            # live lanes: from the run start (the end of the last sequence that began before the window, or wb)
+            live0 = wb
+            for pp, e in ends:
+                if pp < wb and e > live0: live0 = e
+                if pp >= wb: break
+            groups = {}
+            for q in range(max(live0, wb), min(wb + 64, len(hv))):
+                groups.setdefault(hv[q], []).append(q)
+            dup = {q for g in groups.values() if len(g) > 1 for q in g}
+            chain, start = 0, None
+            for i, pp in enumerate(pps):
+                end, fwd, k, cpos = info[pp]
+                st = live0 if i == 0 else info[pps[i - 1]][0]
+                # dup probes in the literal run in front of it make it not the next event
+                lits_ok = not any((q in dup) for q in range(max(st, wb), pp) if q in pset)
+                nb = min(k, pp - (st if i else st))
+                lit = pp - nb - st
+                simple = lits_ok and pp not in dup and fwd < 8 and k < 4 and cpos >= 4 and end < wb + 64 and lit <= 14
+                if i == 0 and st < wb: lit = pp - nb - st  # literals from the previous window (anchor earlier) are fine up to 14
+                if not simple: break
+                chain += 1
+            if chain >= 2:
+                cov += chain; stages += 1
+            clen.append(chain)
+    clen = np.array(clen)
+    print(f"  stage as designed: fires in {100 * stages / max(len(clen), 1):.0f} % of the windows with a sequence, covers {100 * cov / max(tot, 1):.0f} % of all sequences, "
+          f"{cov / max(stages, 1):.2f} sequences per firing")
