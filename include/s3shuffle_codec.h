@@ -66,16 +66,20 @@
 extern "C" {
 #endif
 
-#define S3S_ABI_VERSION 6 /* 2: + segments entry points, page-locked staging, tuning options 6, 7;
+#define S3S_ABI_VERSION 7 /* 2: + segments entry points, page-locked staging, tuning options 6, 7;
                              3: + s3s_compress_map_outputs_batch_device;
                              4: + s3s_decompress_ranges_batch_device; decode variants {3, 4}, LZ4 parses {1, 9, 10};
                              5: + s3s_compress_map_outputs_batch / s3s_decompress_ranges_batch (host buffers),
                                 S3S_CODEC_ZSTD on the reduce side;
                              6: S3S_STATUS_NOT_RUN in the per-entry status of the batched calls (a call-level failure is told
-                                apart from an entry's own verdict) */
+                                apart from an entry's own verdict);
+                             7: + S3S_CODEC_LZF on the reduce side; LZ4Block frames above 32 KiB through the batch decoder */
 
 /* spark.io.compression.codec (only when spark.shuffle.compress=true) */
 enum { S3S_CODEC_NONE = 0, S3S_CODEC_LZ4 = 1, S3S_CODEC_SNAPPY = 2,
+       S3S_CODEC_LZF = 4, /* reduce side only (ABI 7): LZFCompressionCodec streams (compress-lzf chunks 'Z' 'V' type | len ...
+                             around liblzf blocks, up to 65 535 bytes each) through the batch decoder; compression stays on
+                             the JVM - compress-lzf's output is not a function of the partition's bytes */
        S3S_CODEC_ZSTD = 3 /* reduce side only (s3s_decompress_range*, s3s_decompressed_size): Zstandard frames as
                              ZStdCompressionCodec / zstd-jni write them, one per non-empty partition; the compress
                              entry points answer S3S_E_UNSUPPORTED (the codec stays on the JVM) */ };

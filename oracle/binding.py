@@ -16,6 +16,7 @@ _DIR = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 CODEC_NONE, CODEC_LZ4, CODEC_SNAPPY = 0, 1, 2
+CODEC_LZF = 4  # the oracle writes LZF streams with its own greedy encoder (test data); the GPU path only decodes them
 CHECKSUM_NONE, CHECKSUM_ADLER32, CHECKSUM_CRC32 = 0, 1, 2
 E_INVALID, E_CAPACITY, E_BAD_FRAME, E_CHECKSUM, E_UNSUPPORTED = -1, -2, -3, -4, -6
 
@@ -56,6 +57,14 @@ def lib() -> ctypes.CDLL:
         f = getattr(L, f"s3o_{name}_decompress_stream")
         f.restype = i64
         f.argtypes = [vp, i64, vp, i64]
+    L.s3o_lzf_decompress_block.argtypes = [vp, i32, vp, i32]
+    L.s3o_lzf_compress_block.argtypes = [vp, i32, vp, i32]
+    L.s3o_lzf_max_stream_size.restype = i64
+    L.s3o_lzf_max_stream_size.argtypes = [i64]
+    L.s3o_lzf_compress_stream.restype = i64
+    L.s3o_lzf_compress_stream.argtypes = [vp, i64, vp, i64]
+    L.s3o_lzf_decompress_stream.restype = i64
+    L.s3o_lzf_decompress_stream.argtypes = [vp, i64, vp, i64]
     L.s3o_snappy_max_compressed_length.argtypes = [i32]
     L.s3o_snappy_compress_block.argtypes = [vp, i32, vp, i32]
     L.s3o_snappy_decompress_block.argtypes = [vp, i32, vp, i32]
@@ -128,6 +137,24 @@ def lz4_compress_block(data) -> np.ndarray:
     out = np.empty(cap + 8, dtype=np.uint8)
     r = lib().s3o_lz4_compress_block(d.ctypes.data, d.size, out.ctypes.data, cap)
     return out[:r].copy()
+
+
+def lzf_compress_block(data) -> np.ndarray:
+    """the oracle's own greedy LZF encoder (test data only)"""
+    d = _u8(data)
+    out = np.empty(d.size + d.size // 16 + 64, dtype=np.uint8)
+    r = lib().s3o_lzf_compress_block(d.ctypes.data, d.size, out.ctypes.data, out.size)
+    if r < 0:
+        raise RuntimeError(f"oracle lzf_compress_block rc={r}")
+    return out[:r].copy()
+
+
+def lzf_decompress_block(block, ulen: int):
+    """-> decoded bytes, or the negative error code"""
+    b = _u8(block)
+    out = np.empty(max(ulen, 1), dtype=np.uint8)
+    r = lib().s3o_lzf_decompress_block(b.ctypes.data, b.size, out.ctypes.data, ulen)
+    return out[:r].copy() if r >= 0 else int(r)
 
 
 def snappy_compress_block(data) -> np.ndarray:

@@ -517,6 +517,9 @@ int64_t s3o_max_compressed_size(int codec, int block_size, const int64_t* src_of
       case S3O_CODEC_SNAPPY:
         total += s3o_snappy_max_stream_size(u, block_size);
         break;
+      case S3O_CODEC_LZF:
+        total += s3o_lzf_max_stream_size(u);
+        break;
       default:
         return S3O_E_INVALID;
     }
@@ -548,6 +551,9 @@ int s3o_compress_map_output(int codec, int checksum_algo, int block_size, const 
         break;
       case S3O_CODEC_SNAPPY:
         w = s3o_snappy_compress_stream(s, u, block_size, dst + op, dst_capacity - op);
+        break;
+      case S3O_CODEC_LZF:
+        w = s3o_lzf_compress_stream(s, u, dst + op, dst_capacity - op);
         break;
       default:
         return S3O_E_INVALID;
@@ -598,6 +604,9 @@ int s3o_decompress_range(int codec, int checksum_algo, const uint8_t* comp, int6
       break;
     case S3O_CODEC_SNAPPY:
       w = s3o_snappy_decompress_stream(comp, comp_len, dst, dst_capacity);
+      break;
+    case S3O_CODEC_LZF:
+      w = s3o_lzf_decompress_stream(comp, comp_len, dst, dst_capacity);
       break;
     default:
       return S3O_E_INVALID;

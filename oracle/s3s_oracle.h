@@ -43,7 +43,8 @@ extern "C" {
 #endif
 
 /* codec / checksum selectors — same numeric values as include/s3shuffle_codec.h */
-enum { S3O_CODEC_NONE = 0, S3O_CODEC_LZ4 = 1, S3O_CODEC_SNAPPY = 2 };
+enum { S3O_CODEC_NONE = 0, S3O_CODEC_LZ4 = 1, S3O_CODEC_SNAPPY = 2,
+       S3O_CODEC_LZF = 4 /* reduce side only on the GPU; the oracle also WRITES such streams (test data, s3s_oracle_lzf.c) */ };
 enum { S3O_CHECKSUM_NONE = 0, S3O_CHECKSUM_ADLER32 = 1, S3O_CHECKSUM_CRC32 = 2 };
 
 /* error codes — same numeric values as include/s3shuffle_codec.h */
@@ -99,6 +100,12 @@ int s3o_snappy_decompress_block(const uint8_t* src, int src_len, uint8_t* dst, i
 int64_t s3o_snappy_max_stream_size(int64_t ulen, int block_size);
 int64_t s3o_snappy_compress_stream(const uint8_t* src, int64_t ulen, int block_size,
                                    uint8_t* dst, int64_t dst_cap);
+/* LZF (s3s_oracle_lzf.c): liblzf block format in compress-lzf's chunk framing */
+int s3o_lzf_decompress_block(const uint8_t* src, int src_len, uint8_t* dst, int dst_cap);
+int s3o_lzf_compress_block(const uint8_t* src, int src_len, uint8_t* dst, int dst_cap); /* test encoder, not compress-lzf's */
+int64_t s3o_lzf_max_stream_size(int64_t ulen);
+int64_t s3o_lzf_compress_stream(const uint8_t* src, int64_t ulen, uint8_t* dst, int64_t dst_cap);
+int64_t s3o_lzf_decompress_stream(const uint8_t* src, int64_t clen, uint8_t* dst, int64_t dst_cap);
 int64_t s3o_snappy_decompress_stream(const uint8_t* src, int64_t clen, uint8_t* dst,
                                      int64_t dst_cap);
 

@@ -24,11 +24,12 @@ object S3SCodec {
   // ---- constants of include/s3shuffle_codec.h ----------------------------------------------------------------
   val CODEC_NONE = 0; val CODEC_LZ4 = 1; val CODEC_SNAPPY = 2
   val CODEC_ZSTD = 3 // reduce side only (decompressRange*, decompressedSize): S3GpuBlockDecoder takes ranges of many small frames, INTEGRATION.md
+  val CODEC_LZF = 4 // reduce side only: LZFCompressionCodec streams (compress-lzf chunks around liblzf blocks)
   val CHECKSUM_NONE = 0; val CHECKSUM_ADLER32 = 1; val CHECKSUM_CRC32 = 2
   val OK = 0; val E_INVALID = -1; val E_CAPACITY = -2; val E_BAD_FRAME = -3; val E_CHECKSUM = -4; val E_HIP = -5
   val STATUS_NOT_RUN = -100 // per-entry status of a batch call that failed before this entry had a verdict: the call's return code is its error
   val OPT_LZ4_BLOCK_SIZE = 1; val OPT_SNAPPY_BLOCK_SIZE = 2
-  val ABI_VERSION = 6
+  val ABI_VERSION = 7
 
   // ---- native entry points (jni/s3s_jni.c, one line each) -------------------------------------------------------
   @native def abiVersion(): Int
@@ -156,14 +157,15 @@ object S3SCodec {
   }
 
   /** The reduce side decodes one codec more than the map side compresses: Zstandard frames as zstd-jni writes them
-    * (S3S_CODEC_ZSTD: decompressRange*, decompressedSize).  LZF stays on the JVM. */
+    * (S3S_CODEC_ZSTD) and LZF streams (S3S_CODEC_LZF): all four codecs of CompressionCodec.createCodec decode on the GPU. */
   def supportsDecode(sparkCodecShortName: String): Boolean = sparkCodecShortName.toLowerCase match {
-    case "lz4" | "snappy" | "zstd" => true
+    case "lz4" | "snappy" | "zstd" | "lzf" => true
     case _ => false
   }
 
   def decodeCodecId(sparkCodecShortName: String): Int = sparkCodecShortName.toLowerCase match {
     case "zstd" => CODEC_ZSTD
+    case "lzf" => CODEC_LZF
     case other => codecId(other)
   }
 

@@ -219,8 +219,8 @@ static int compress_core(s3s_ctx* ctx, int codec, int checksum_algo, const uint8
   if (pfs[0] != 0 || pfs[n] != ns) return fail(ctx, S3S_E_INVALID, "part_first_seg must start at 0 and end at n_segs");
   for (int32_t p = 0; p < n; p++)
     if (pfs[p + 1] < pfs[p]) return fail(ctx, S3S_E_INVALID, "part_first_seg not monotonic at %d", p);
-  if (codec == S3S_CODEC_ZSTD)
-    return fail(ctx, S3S_E_UNSUPPORTED, "zstd compression stays on the JVM codec (decode only: s3s_decompress_range*)");
+  if (codec == S3S_CODEC_ZSTD || codec == S3S_CODEC_LZF)
+    return fail(ctx, S3S_E_UNSUPPORTED, "%s compression stays on the JVM codec (decode only: s3s_decompress_range*)", codec == S3S_CODEC_LZF ? "lzf" : "zstd");
   if (codec != S3S_CODEC_NONE && codec != S3S_CODEC_LZ4 && codec != S3S_CODEC_SNAPPY)
     return fail(ctx, S3S_E_INVALID, "unknown codec %d", codec);
   if (checksum_algo != S3S_CHECKSUM_NONE && checksum_algo != S3S_CHECKSUM_ADLER32 &&
@@ -479,8 +479,8 @@ int s3s_compress_map_outputs_batch_device(s3s_ctx* ctx, int codec, int checksum_
   ctx->err[0] = 0;
   const CompressCallScope in_flight(ctx);
   if (n_tasks < 0 || (n_tasks > 0 && !tasks)) return fail(ctx, S3S_E_INVALID, "null task array or negative count");
-  if (codec == S3S_CODEC_ZSTD)
-    return fail(ctx, S3S_E_UNSUPPORTED, "zstd compression stays on the JVM codec (decode only: s3s_decompress_range*)");
+  if (codec == S3S_CODEC_ZSTD || codec == S3S_CODEC_LZF)
+    return fail(ctx, S3S_E_UNSUPPORTED, "%s compression stays on the JVM codec (decode only: s3s_decompress_range*)", codec == S3S_CODEC_LZF ? "lzf" : "zstd");
   if (codec != S3S_CODEC_NONE && codec != S3S_CODEC_LZ4 && codec != S3S_CODEC_SNAPPY)
     return fail(ctx, S3S_E_INVALID, "unknown codec %d", codec);
   if (checksum_algo != S3S_CHECKSUM_NONE && checksum_algo != S3S_CHECKSUM_ADLER32 &&

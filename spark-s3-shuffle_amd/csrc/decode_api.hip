@@ -32,6 +32,28 @@ int lz4block_decoded_size_host(const uint8_t* c, int64_t n, int64_t* out) {
   return S3S_OK;
 }
 
+int lzf_decoded_size_host(const uint8_t* c, int64_t n, int64_t* out) {  // LZFInputStream: chunk headers carry both lengths
+  int64_t ip = 0, total = 0;
+  while (ip < n) {
+    if (n - ip < 5 || c[ip] != 'Z' || c[ip + 1] != 'V' || c[ip + 2] > 1) return S3S_E_BAD_FRAME;
+    const int type = c[ip + 2];
+    const int64_t len = (int64_t)c[ip + 3] << 8 | c[ip + 4];
+    ip += 5;
+    int64_t ulen = len;
+    if (type == 1) {
+      if (n - ip < 2) return S3S_E_BAD_FRAME;
+      ulen = (int64_t)c[ip] << 8 | c[ip + 1];
+      ip += 2;
+      if (len == 0 || ulen == 0) return S3S_E_BAD_FRAME;
+    }
+    if (len > n - ip) return S3S_E_BAD_FRAME;
+    ip += len;
+    total += ulen;
+  }
+  *out = total;
+  return S3S_OK;
+}
+
 int snappy_decoded_size_host(const uint8_t* c, int64_t n, int64_t* out) {
   static const uint8_t hdr[8] = {0x82, 'S', 'N', 'A', 'P', 'P', 'Y', 0};
   int64_t ip = 0, total = 0;
@@ -86,6 +108,9 @@ int s3s_decompressed_size(s3s_ctx* ctx, int codec, const uint8_t* comp, int64_t 
     case S3S_CODEC_SNAPPY:
       rc = snappy_decoded_size_host(comp, comp_len, out_len);
       break;
+    case S3S_CODEC_LZF:
+      rc = lzf_decoded_size_host(comp, comp_len, out_len);
+      break;
     case S3S_CODEC_ZSTD: {
       // a Spark writer's frames carry no content size: the size pass of the device decoder walks them (pass 1 of
       // zstd_decompress.hip); the whole buffer is one "partition" of concatenated frames
@@ -121,7 +146,7 @@ int s3s_decompress_range_device(s3s_ctx* ctx, int codec, int checksum_algo, cons
   if (out_len) *out_len = 0;
   if (nparts < 0 || !part_offsets || comp_len < 0 || dst_capacity < 0)
     return fail(ctx, S3S_E_INVALID, "null/invalid argument");
-  if (codec != S3S_CODEC_NONE && codec != S3S_CODEC_LZ4 && codec != S3S_CODEC_SNAPPY && codec != S3S_CODEC_ZSTD)
+  if (codec != S3S_CODEC_NONE && codec != S3S_CODEC_LZ4 && codec != S3S_CODEC_SNAPPY && codec != S3S_CODEC_ZSTD && codec != S3S_CODEC_LZF)
     return fail(ctx, S3S_E_INVALID, "unknown codec %d", codec);
   if (checksum_algo != S3S_CHECKSUM_NONE && checksum_algo != S3S_CHECKSUM_ADLER32 &&
       checksum_algo != S3S_CHECKSUM_CRC32)
@@ -219,8 +244,9 @@ int s3s_decompress_range_device(s3s_ctx* ctx, int codec, int checksum_algo, cons
     return S3S_OK;
   }
 
-  if (codec == S3S_CODEC_SNAPPY) {
-    // ---- SnappyInputStream framing: count chunks per partition, scan, emit frames, decode ---------
+  if (codec == S3S_CODEC_SNAPPY || codec == S3S_CODEC_LZF) {
+    // ---- SnappyInputStream / LZFInputStream framing: count chunks per partition, scan, emit frames, decode ---------
+    const int cf = codec == S3S_CODEC_LZF ? kChunkLzf : kChunkSnappy;
     if (comp_len == 0 || n == 0) {
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
       if ((rc = verify_sums())) return rc;
@@ -235,21 +261,21 @@ int s3s_decompress_range_device(s3s_ctx* ctx, int codec, int checksum_algo, cons
     if ((rc = ensure(ctx, B_PART_NFRAMES, cnt_bytes + sizeof(int64_t) * (size_t)(n + 2)))) return rc;
     uint32_t* d_cnt = dev<uint32_t>(ctx, B_PART_NFRAMES);
     int64_t* d_base = reinterpret_cast<int64_t*>(dev<uint8_t>(ctx, B_PART_NFRAMES) + cnt_bytes);
-    launch_snappy_count_frames(d_comp, dev<int64_t>(ctx, B_OFFSETS), n, d_cnt, dev<int32_t>(ctx, B_STATUS), ctx->stream);
+    launch_snappy_count_frames(d_comp, dev<int64_t>(ctx, B_OFFSETS), n, d_cnt, dev<int32_t>(ctx, B_STATUS), ctx->stream, cf);
     launch_scan_u32(d_cnt, n, d_base, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(&h_misc[0], d_base + n, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(&h_misc[1], ctx->buf[B_STATUS].p, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if ((rc = verify_sums())) return rc;
-    if (*reinterpret_cast<int32_t*>(&h_misc[1]) != 0) return fail(ctx, S3S_E_BAD_FRAME, "Stream is corrupted (snappy chunk chain)");
+    if (*reinterpret_cast<int32_t*>(&h_misc[1]) != 0) return fail(ctx, S3S_E_BAD_FRAME, "Stream is corrupted (%s chunk chain)", cf == kChunkLzf ? "lzf" : "snappy");
     const int64_t n_frames = h_misc[0];
     if (n_frames > 0x7fffff00ll) return fail(ctx, S3S_E_UNSUPPORTED, "too many frames in one call");
     if ((rc = ensure(ctx, B_FRAMES, sizeof(Frame) * (size_t)(n_frames + 1)))) return rc;
     if ((rc = ensure(ctx, B_ITEM_SIZE, sizeof(uint32_t) * (size_t)(n_frames + 1)))) return rc;
     if ((rc = ensure(ctx, B_FRAME_OUT, sizeof(int64_t) * (size_t)(n_frames + 1)))) return rc;
     launch_snappy_emit_frames(d_comp, dev<int64_t>(ctx, B_OFFSETS), n, d_base, dev<Frame>(ctx, B_FRAMES),
-                              dev<uint32_t>(ctx, B_ITEM_SIZE), dev<int32_t>(ctx, B_STATUS), ctx->stream);
+                              dev<uint32_t>(ctx, B_ITEM_SIZE), dev<int32_t>(ctx, B_STATUS), ctx->stream, cf);
     launch_scan_u32(dev<uint32_t>(ctx, B_ITEM_SIZE), n_frames, dev<int64_t>(ctx, B_FRAME_OUT), ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(&h_misc[0], dev<int64_t>(ctx, B_FRAME_OUT) + n_frames, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -260,7 +286,7 @@ int s3s_decompress_range_device(s3s_ctx* ctx, int codec, int checksum_algo, cons
     if (total > dst_capacity)
       return fail(ctx, S3S_E_CAPACITY, "dst_capacity %lld < %lld decoded bytes", (long long)dst_capacity, (long long)total);
     launch_snappy_decompress(d_comp, dev<Frame>(ctx, B_FRAMES), (int32_t)n_frames, dev<int64_t>(ctx, B_FRAME_OUT),
-                             d_dst, dev<int32_t>(ctx, B_STATUS), ctx->lz4_decode_variant, ctx->stream);
+                             d_dst, dev<int32_t>(ctx, B_STATUS), ctx->lz4_decode_variant, ctx->stream, cf);
     HIP_TRY(ctx, hipGetLastError());
     record(ctx, 3);
     HIP_TRY(ctx, hipMemcpyAsync(&h_misc[1], ctx->buf[B_STATUS].p, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -410,7 +436,7 @@ extern "C" int s3s_decompress_ranges_batch_device(s3s_ctx* ctx, int codec, int c
   if (!ctx) return S3S_E_INVALID;
   ctx->err[0] = 0;
   if (n_ranges < 0 || (n_ranges > 0 && !R)) return fail(ctx, S3S_E_INVALID, "null range array or negative count");
-  if (codec != S3S_CODEC_NONE && codec != S3S_CODEC_LZ4 && codec != S3S_CODEC_SNAPPY && codec != S3S_CODEC_ZSTD)
+  if (codec != S3S_CODEC_NONE && codec != S3S_CODEC_LZ4 && codec != S3S_CODEC_SNAPPY && codec != S3S_CODEC_ZSTD && codec != S3S_CODEC_LZF)
     return fail(ctx, S3S_E_INVALID, "unknown codec %d", codec);
   if (checksum_algo != S3S_CHECKSUM_NONE && checksum_algo != S3S_CHECKSUM_ADLER32 && checksum_algo != S3S_CHECKSUM_CRC32)
     return fail(ctx, S3S_E_INVALID, "Unsupported shuffle checksum algorithm: %d", checksum_algo);
@@ -585,7 +611,8 @@ extern "C" int s3s_decompress_ranges_batch_device(s3s_ctx* ctx, int codec, int c
       const size_t pp = first_part[(size_t)r] + (size_t)r;
       uint32_t* d_cnt = reinterpret_cast<uint32_t*>(ws);
       int64_t* d_base = reinterpret_cast<int64_t*>(ws + al(4 * ((size_t)k.num_partitions + 1)));
-      launch_snappy_count_frames(k.d_comp, dev<int64_t>(ctx, B_OFFSETS) + pp, k.num_partitions, d_cnt, d_status + r, ctx->stream);
+      launch_snappy_count_frames(k.d_comp, dev<int64_t>(ctx, B_OFFSETS) + pp, k.num_partitions, d_cnt, d_status + r, ctx->stream,
+                                 codec == S3S_CODEC_LZF ? kChunkLzf : kChunkSnappy);
       launch_scan_u32(d_cnt, k.num_partitions, d_base, ctx->stream);
       HIP_TRY(ctx, hipMemcpyAsync(&h_nf[r], d_base + k.num_partitions, 8, hipMemcpyDeviceToHost, ctx->stream));
     }
@@ -669,7 +696,8 @@ extern "C" int s3s_decompress_ranges_batch_device(s3s_ctx* ctx, int codec, int c
       int64_t* d_out_rel = dev<int64_t>(ctx, B_FRAME_OUT) + f0 + r;
       const size_t pp = first_part[(size_t)r] + (size_t)r;
       int64_t* d_base = reinterpret_cast<int64_t*>(ws + al(4 * ((size_t)k.num_partitions + 1)));
-      launch_snappy_emit_frames(k.d_comp, dev<int64_t>(ctx, B_OFFSETS) + pp, k.num_partitions, d_base, d_fr, d_orig, d_status + r, ctx->stream);
+      launch_snappy_emit_frames(k.d_comp, dev<int64_t>(ctx, B_OFFSETS) + pp, k.num_partitions, d_base, d_fr, d_orig, d_status + r, ctx->stream,
+                                codec == S3S_CODEC_LZF ? kChunkLzf : kChunkSnappy);
       launch_scan_u32(d_orig, nf, d_out_rel, ctx->stream);
       HIP_TRY(ctx, hipMemcpyAsync(&h_tot[r], d_out_rel + nf, 8, hipMemcpyDeviceToHost, ctx->stream));
     }
@@ -693,7 +721,7 @@ extern "C" int s3s_decompress_ranges_batch_device(s3s_ctx* ctx, int codec, int c
     }
     if (total_frames > 0)
       launch_snappy_decompress(nullptr, dev<Frame>(ctx, B_FRAMES), (int32_t)total_frames, dev<int64_t>(ctx, B_ITEM_OFF), nullptr,
-                               d_dec_status, ctx->lz4_decode_variant, ctx->stream);
+                               d_dec_status, ctx->lz4_decode_variant, ctx->stream, codec == S3S_CODEC_LZF ? kChunkLzf : kChunkSnappy);
     HIP_TRY(ctx, hipGetLastError());
     record(ctx, 3);
     HIP_TRY(ctx, hipMemcpyAsync(&h_st[n_ranges], d_dec_status, 4, hipMemcpyDeviceToHost, ctx->stream));

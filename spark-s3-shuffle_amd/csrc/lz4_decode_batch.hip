@@ -133,7 +133,7 @@ __device__ __forceinline__ int wave_scan_add(int v) {
   return v;
 }
 
-enum { kFmtLz4 = 0, kFmtSnappy = 1 };
+enum { kFmtLz4 = 0, kFmtSnappy = 1, kFmtLzf = 2 };  // kFmtLzf (round 4): liblzf blocks of compress-lzf chunks, elements like Snappy's
 
 #ifdef S3S_LZ4_TIMING
 // phase accounting of the batch decoder (instrumented build only; tools/dec_timing.py): s_memtime ticks per phase
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
   // the batch's first token / first output byte (a batch of 64 fast-path sequences spans < 18 KiB of stream and < 35 KiB of
   // output), so nothing but the frame header's own 32-bit lengths depends on the block size.  kBatchMaxBlock = lz4-java's
   // largest block (1 << 25).  Snappy chunks stay at 32 KiB (snappy-java's block size cannot exceed the fragment size here).
-  if (olen > (kFmt == kFmtSnappy ? kMaxBlock : kBatchMaxBlock) && (kFmt == kFmtSnappy || fr.method != 0x10)) {
+  if (olen > (kFmt == kFmtSnappy ? kMaxBlock : kFmt == kFmtLzf ? 0xFFFF : kBatchMaxBlock) && (kFmt == kFmtSnappy || fr.method != 0x10)) {
     if (lane == 0) atomicExch(status, S3S_E_UNSUPPORTED);
     return;
   }
@@ -221,10 +221,11 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
     if (!bad && (int)ulen != olen) bad = true;
   }
   if (bad) {
-  } else if ((kFmt == kFmtSnappy ? clen > kMaxBlock + kMaxBlock / 6 + 64 : (int64_t)clen > (int64_t)olen + olen / 255 + 16) &&
-             !(kFmt == kFmtLz4 && fr.method == 0x10)) {
+  } else if ((kFmt == kFmtSnappy ? clen > kMaxBlock + kMaxBlock / 6 + 64
+                                 : (int64_t)clen > (int64_t)olen + olen / (kFmt == kFmtLzf ? 16 : 255) + 16) &&
+             !(kFmt != kFmtSnappy && fr.method == 0x10)) {
     bad = true;  // no block of that decoded size is that long (LZ4: LZ4_compressBound; a compressed frame is shorter than its block anyway)
-  } else if (kFmt == kFmtLz4 && fr.method == 0x10) {  // stored frame
+  } else if (kFmt != kFmtSnappy && fr.method == 0x10) {  // stored frame (LZ4Block RAW / LZF non-compressed chunk)
     for (int j = lane * 4; j < olen; j += kWave * 4) {
       if (j + 4 <= olen) {
         const uint32_t x = g_ld32(c + j);
@@ -579,6 +580,31 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
     auto slow_sequence = [&]() __attribute__((always_inline)) -> int {
       int ips = ip;
       if (ips >= clen) return -1;
+      if constexpr (kFmt == kFmtLzf) {
+        // one element: ctrl < 32: ctrl + 1 literals; else a back reference of (ctrl >> 5 [7: + next byte]) + 2 bytes,
+        // ((ctrl & 31) << 8 | next byte) + 1 back (liblzf's lzf_decompress; every bound checked here or by the emitters)
+        const uint32_t ctrl = __builtin_amdgcn_readfirstlane((uint32_t)c[ips]);
+        ips++;
+        if (ctrl < 32u) {
+          const int n = (int)ctrl + 1;
+          if (n > clen - ips || n > olen - op) return -1;
+          if (!emit_literals(ips, n)) return -1;
+          ip = ips + n;
+          return 0;
+        }
+        int len = (int)(ctrl >> 5);
+        if (len == 7) {
+          if (ips >= clen) return -1;
+          len += (int)__builtin_amdgcn_readfirstlane((uint32_t)c[ips]);
+          ips++;
+        }
+        if (ips >= clen) return -1;
+        const int off = (int)(((ctrl & 0x1fu) << 8) | __builtin_amdgcn_readfirstlane((uint32_t)c[ips])) + 1;
+        ips++;
+        ip = ips;
+        if (!emit_match(off, len + 2)) return -1;
+        return 0;
+      }
       if constexpr (kFmt == kFmtSnappy) {
         // one element: literal (length in the tag or in 1-4 bytes behind it) or copy with 1 / 2 / 4 offset bytes
         const uint32_t tag = __builtin_amdgcn_readfirstlane((uint32_t)c[ips]);
@@ -717,7 +743,24 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
 #else
           const uint32_t d0 = g_ld32(c + cpos);
 #endif
-          if constexpr (kFmt == kFmtSnappy) {
+          if constexpr (kFmt == kFmtLzf) {
+            const uint32_t ctrl = d0 & 0xffu;
+            if (ctrl < 32u) {  // literal run (1 .. 32 bytes)
+              const int len = (int)ctrl + 1;
+              nxt = cpos + 1 + len;
+              cx = nxt > clen;
+              is_lit = true;
+              r0 = (uint32_t)len;
+              r1 = (uint32_t)(lane + 1) << 16;
+            } else {           // back reference: 2 or 3 bytes
+              const uint32_t l3 = ctrl >> 5, b1 = (d0 >> 8) & 0xffu, b2 = (d0 >> 16) & 0xffu;
+              const bool ext = l3 == 7u;
+              nxt = cpos + (ext ? 3 : 2);
+              cx = false;
+              r0 = ((ext ? 7u + b1 : l3) + 2u) << 16;
+              r1 = (((ctrl & 0x1fu) << 8) | (ext ? b2 : b1)) + 1u;
+            }
+          } else if constexpr (kFmt == kFmtSnappy) {
             const uint32_t tag = d0 & 0xffu, ty = tag & 3u, n6 = tag >> 2;
             if (ty == 0u) {
               int len = (int)n6 + 1, hdr = 1;
@@ -780,7 +823,7 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
       const int nrel = cx ? -1 : nxt - ip;
       uint64_t mask = 0;
       int rel = 0;
-      if (last_tokens >= (kFmt == kFmtSnappy ? kSnappyWalkTokens : kParallelWalkTokens)) {
+      if (last_tokens >= (kFmt != kFmtLz4 ? kSnappyWalkTokens : kParallelWalkTokens)) {
         // many short tokens (Snappy elements are 2-3 bytes long on match-dense data, 25 and more per window): the chain
         // is followed by pointer doubling — six rounds of "lanes on the chain mark the lane 2^k tokens behind them"
         // through 64 bytes of LDS (the window's pad), whatever the number of tokens.
@@ -832,7 +875,7 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
       // literal whose successor is this window's first token).
       uint64_t S = mask, J = 0ull;
       bool joined = false;
-      if constexpr (kFmt == kFmtSnappy) {
+      if constexpr (kFmt != kFmtLz4) {
         const uint64_t LM = ballot64(is_lit) & mask;
         const uint64_t below = mask & ((1ull << lane) - 1ull);
         const bool prev_lit = below ? ((LM >> (63 - __builtin_clzll(below))) & 1ull) != 0ull : open_lit;
@@ -845,7 +888,7 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
       // sequence of the byte-wise path (so in particular in front of the block's last sequence)
       if (mask == 0ull || nseq + cnt > kWave) {
         if (!flush_batch()) { bad = true; break; }
-        if constexpr (kFmt == kFmtSnappy) {
+        if constexpr (kFmt != kFmtLz4) {
           if (open_lit && (J & mask & (0ull - mask)) != 0ull) {  // the first token cannot join a flushed record any more
             const uint64_t first = mask & (0ull - mask);
             J &= ~first;
@@ -870,7 +913,7 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
         const int t = nseq + __builtin_amdgcn_mbcnt_hi((uint32_t)(S >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)S, 0u));
         if (!joined) rec[t] = make_uint2(r0, r1 + ((uint32_t)(ip - sbase) << 16));  // stream offsets count from the batch's first token
       }
-      if constexpr (kFmt == kFmtSnappy) {
+      if constexpr (kFmt != kFmtLz4) {
         if (joined) {  // (after the record's first half has been stored by the literal's lane)
           const int t = nseq + __builtin_amdgcn_mbcnt_hi((uint32_t)(S >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)S, 0u)) - 1;
           uint16_t* h16 = reinterpret_cast<uint16_t*>(rec + t);
@@ -984,6 +1027,13 @@ void launch_lz4_decompress_batch(const uint8_t* d_comp, const Frame* d_frames, i
   if (after_decode) (void)hipEventRecord(after_decode, st);
   hipLaunchKernelGGL(lz4_verify_frames_kernel, dim3((unsigned)((n_frames + kWave / 4 - 1) / (kWave / 4))), dim3(kWave),
                      0, st, d_frames, n_frames, d_frame_out, d_dst, d_status);
+}
+
+void launch_lzf_decompress_batch(const uint8_t* d_comp, const Frame* d_frames, int32_t n_frames, const int64_t* d_frame_out,
+                                 uint8_t* d_dst, int32_t* d_status, hipStream_t st) {
+  if (n_frames <= 0) return;
+  hipLaunchKernelGGL(batch_decode_kernel<kFmtLzf>, dim3((unsigned)n_frames), dim3(kWave), 0, st, d_comp, d_frames, n_frames,
+                     d_frame_out, d_dst, d_status);
 }
 
 void launch_snappy_decompress_batch(const uint8_t* d_comp, const Frame* d_frames, int32_t n_frames,

@@ -84,7 +84,7 @@ struct Frame {        // one discovered codec frame
   int32_t comp_len;   // payload bytes
   int32_t orig_len;   // decoded bytes
   uint32_t check;     // LZ4Block: xxh32 & 0x0FFFFFFF; snappy: unused
-  int32_t method;     // 0x10 raw / 0x20 lz4 (LZ4Block); 1 = snappy chunk
+  int32_t method;     // 0x10 raw / 0x20 lz4 (LZ4Block); 1 = snappy chunk; LZF: 0x10 stored chunk / 2 compressed chunk
 };
 // LZ4Block frame discovery over the whole range (see lz4_decompress.hip): 64 KiB tiles are
 // walked speculatively, resolved into the true chain, then emitted in stream order.
@@ -135,19 +135,24 @@ void launch_lz4_decompress_batch(const uint8_t* d_comp, const Frame* d_frames, i
 void launch_snappy_decompress_batch(const uint8_t* d_comp, const Frame* d_frames, int32_t n_frames,
                                     const int64_t* d_frame_out, uint8_t* d_dst, int32_t* d_status,
                                     hipStream_t st);
+void launch_lzf_decompress_batch(const uint8_t* d_comp, const Frame* d_frames, int32_t n_frames,
+                                 const int64_t* d_frame_out, uint8_t* d_dst, int32_t* d_status, hipStream_t st);
 // Snappy (SnappyInputStream framing): chunks are chained by their i32 BE length only, so the walk
 // is one lane per partition (each non-empty partition is one or more complete streams, each
 // starting with the 16-byte header).  Pass 1 counts, pass 2 (after a scan of the counts) writes
 // d_frames / d_frame_orig at d_frame_base[partition].
+// chunk_format: kChunkSnappy, or kChunkLzf (round 4: compress-lzf chunks 'Z' 'V' type | len BE [| ulen BE]; stored chunks
+// become frames with method 0x10, compressed ones method 2) - the same two passes, the same batch decoder behind them.
+enum { kChunkSnappy = 0, kChunkLzf = 1 };
 void launch_snappy_count_frames(const uint8_t* d_comp, const int64_t* d_part_off, int32_t n_parts,
-                                uint32_t* d_part_nframes, int32_t* d_status, hipStream_t st);
+                                uint32_t* d_part_nframes, int32_t* d_status, hipStream_t st, int chunk_format = kChunkSnappy);
 void launch_snappy_emit_frames(const uint8_t* d_comp, const int64_t* d_part_off, int32_t n_parts,
                                const int64_t* d_frame_base, Frame* d_frames, uint32_t* d_frame_orig,
-                               int32_t* d_status, hipStream_t st);
+                               int32_t* d_status, hipStream_t st, int chunk_format = kChunkSnappy);
 //   variant 0: block staged in LDS; otherwise the VALU ring decoder
 void launch_snappy_decompress(const uint8_t* d_comp, const Frame* d_frames, int32_t n_frames,
                               const int64_t* d_frame_out, uint8_t* d_dst, int32_t* d_status,
-                              int variant, hipStream_t st);
+                              int variant, hipStream_t st, int chunk_format = kChunkSnappy);
 void launch_scan_u32(const uint32_t* d_in, int64_t n, int64_t* d_out, hipStream_t st);
 
 // ---- device helpers shared by several kernels --------------------------------------------

@@ -16,6 +16,40 @@ __device__ __forceinline__ bool is_stream_header(const uint8_t* c) {
          c[6] == 'Y' && c[7] == 0;
 }
 
+// LZFInputStream (compress-lzf) framing: 'Z' 'V' 0 | len u16 BE | bytes   or   'Z' 'V' 1 | clen u16 BE | ulen u16 BE | LZF block;
+// chunks until the end of the partition (concatenated streams are simply more chunks).
+__device__ int walk_partition_lzf(const uint8_t* comp, int64_t beg, int64_t end, bool emit, Frame* frames, uint32_t* frame_orig) {
+  int64_t ip = beg;
+  int n = 0;
+  while (ip < end) {
+    if (end - ip < 5 || comp[ip] != 'Z' || comp[ip + 1] != 'V' || comp[ip + 2] > 1) return -1;
+    const int type = comp[ip + 2];
+    const uint32_t len = (uint32_t)comp[ip + 3] << 8 | comp[ip + 4];
+    ip += 5;
+    uint32_t ulen = len;
+    if (type == 1) {
+      if (end - ip < 2) return -1;
+      ulen = (uint32_t)comp[ip] << 8 | comp[ip + 1];
+      ip += 2;
+      if (len == 0 || ulen == 0) return -1;  // (a compressed chunk of nothing is not something the encoder writes)
+    }
+    if ((int64_t)len > end - ip) return -1;
+    if (emit) {
+      Frame f;
+      f.comp_off = ip;
+      f.comp_len = (int32_t)len;
+      f.orig_len = (int32_t)ulen;
+      f.check = 0;
+      f.method = type == 1 ? 2 : 0x10;
+      frames[n] = f;
+      frame_orig[n] = ulen;
+    }
+    n++;
+    ip += len;
+  }
+  return n;
+}
+
 // Walks partition p.  emit == false: counts chunks.  emit == true: writes frames.
 // Returns the chunk count or -1 on a malformed stream.
 __device__ int walk_partition(const uint8_t* comp, int64_t beg, int64_t end, bool emit, Frame* frames,
@@ -63,10 +97,11 @@ __device__ int walk_partition(const uint8_t* comp, int64_t beg, int64_t end, boo
 
 __global__ void snappy_count_kernel(const uint8_t* __restrict__ comp, const int64_t* __restrict__ part_off,
                                     int32_t n_parts, uint32_t* __restrict__ part_nframes,
-                                    int32_t* __restrict__ status) {
+                                    int32_t* __restrict__ status, int chunk_format) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_parts) return;
-  const int n = walk_partition(comp, part_off[p], part_off[p + 1], false, nullptr, nullptr);
+  const int n = chunk_format == kChunkLzf ? walk_partition_lzf(comp, part_off[p], part_off[p + 1], false, nullptr, nullptr)
+                                          : walk_partition(comp, part_off[p], part_off[p + 1], false, nullptr, nullptr);
   if (n < 0) {
     atomicExch(status, S3S_E_BAD_FRAME);
     part_nframes[p] = 0;
@@ -78,11 +113,12 @@ __global__ void snappy_count_kernel(const uint8_t* __restrict__ comp, const int6
 __global__ void snappy_emit_kernel(const uint8_t* __restrict__ comp, const int64_t* __restrict__ part_off,
                                    int32_t n_parts, const int64_t* __restrict__ frame_base,
                                    Frame* __restrict__ frames, uint32_t* __restrict__ frame_orig,
-                                   int32_t* __restrict__ status) {
+                                   int32_t* __restrict__ status, int chunk_format) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_parts) return;
   const int64_t b = frame_base[p];
-  if (walk_partition(comp, part_off[p], part_off[p + 1], true, frames + b, frame_orig + b) < 0)
+  if ((chunk_format == kChunkLzf ? walk_partition_lzf(comp, part_off[p], part_off[p + 1], true, frames + b, frame_orig + b)
+                                 : walk_partition(comp, part_off[p], part_off[p + 1], true, frames + b, frame_orig + b)) < 0)
     atomicExch(status, S3S_E_BAD_FRAME);
 }
 
@@ -271,24 +307,28 @@ __global__ __launch_bounds__(kWave) void snappy_decompress_valu_kernel(
 }  // namespace
 
 void launch_snappy_count_frames(const uint8_t* d_comp, const int64_t* d_part_off, int32_t n_parts,
-                                uint32_t* d_part_nframes, int32_t* d_status, hipStream_t st) {
+                                uint32_t* d_part_nframes, int32_t* d_status, hipStream_t st, int chunk_format) {
   if (n_parts <= 0) return;
   hipLaunchKernelGGL(snappy_count_kernel, dim3((unsigned)((n_parts + 63) / 64)), dim3(64), 0, st, d_comp,
-                     d_part_off, n_parts, d_part_nframes, d_status);
+                     d_part_off, n_parts, d_part_nframes, d_status, chunk_format);
 }
 
 void launch_snappy_emit_frames(const uint8_t* d_comp, const int64_t* d_part_off, int32_t n_parts,
                                const int64_t* d_frame_base, Frame* d_frames, uint32_t* d_frame_orig,
-                               int32_t* d_status, hipStream_t st) {
+                               int32_t* d_status, hipStream_t st, int chunk_format) {
   if (n_parts <= 0) return;
   hipLaunchKernelGGL(snappy_emit_kernel, dim3((unsigned)((n_parts + 63) / 64)), dim3(64), 0, st, d_comp,
-                     d_part_off, n_parts, d_frame_base, d_frames, d_frame_orig, d_status);
+                     d_part_off, n_parts, d_frame_base, d_frames, d_frame_orig, d_status, chunk_format);
 }
 
 void launch_snappy_decompress(const uint8_t* d_comp, const Frame* d_frames, int32_t n_frames,
                               const int64_t* d_frame_out, uint8_t* d_dst, int32_t* d_status,
-                              int variant, hipStream_t st) {
+                              int variant, hipStream_t st, int chunk_format) {
   if (n_frames <= 0) return;
+  if (chunk_format == kChunkLzf) {  // (LZF has the batch decoder only)
+    launch_lzf_decompress_batch(d_comp, d_frames, n_frames, d_frame_out, d_dst, d_status, st);
+    return;
+  }
   if (variant == 3) {  // ring decoder on the vector ALU (round 1)
     hipLaunchKernelGGL(snappy_decompress_valu_kernel, dim3((unsigned)n_frames), dim3(kWave), 0, st, d_comp,
                        d_frames, n_frames, d_frame_out, d_dst, d_status);

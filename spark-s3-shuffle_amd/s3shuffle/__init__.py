@@ -11,6 +11,7 @@ from .codec import (  # noqa: F401
     CHECKSUM_CRC32,
     CHECKSUM_NONE,
     CODEC_LZ4,
+    CODEC_LZF,
     CODEC_NONE,
     CODEC_SNAPPY,
     CODEC_ZSTD,

@@ -267,6 +267,33 @@ def test_compiled_batch_decoder_takes_blocks_above_32k(oracle):
     assert st == -3
 
 
+def test_compiled_batch_decoder_lzf_front_end(oracle):
+    """round 4: LZF chunks (Spark's LZFCompressionCodec) through the batch decoder's third front end: blocks written by liblzf
+    itself (tests/golden/lzf_liblzf.npz, up to the 65 535-byte chunk limit), blocks of the oracle's encoder over the corpora,
+    a stored chunk; payload and destination of exactly their sizes; malformed blocks - a reference in front of the block, a
+    literal run and a reference cut off by the end of the block, a block that decodes to more than its chunk header says -
+    end in S3S_E_BAD_FRAME without an access outside the buffers"""
+    import decode_kernel as dk
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lzf_liblzf.npz"))
+    names = sorted(k[4:] for k in g.files if k.startswith("raw_"))
+    cases = [(g["lzf_" + n].tobytes(), g["raw_" + n].tobytes()) for n in names]
+    rng = np.random.default_rng(61)
+    for kind, n in [(7, 20000), (3, 5000), (6, 6000), (1, 4000), (2, 40000), (7, 13)]:
+        c = corpus.chunk_corpus(kind, n, rng)
+        cases.append((bytes(oracle.lzf_compress_block(c)), c.tobytes()))
+    blocks = [(b, len(w)) for b, w in cases]
+    res, st, _ = dk.decode_blocks(blocks, fmt=2, methods=[2] * len(blocks))
+    assert st == 0 and res == [w for _, w in cases]
+    raw = rng.integers(0, 256, 3000, dtype=np.uint8).tobytes()
+    res, st, _ = dk.decode_blocks([(raw, len(raw)), blocks[0]], fmt=2, methods=[0x10, 2])
+    assert st == 0 and res == [raw, cases[0][1]]
+    for bad, olen in ((bytes([0x20, 0x05]), 16), (bytes([0x03, 1, 2]), 16), (bytes([0x00, 7, 0xE0]), 16), (bytes([0x00, 7, 0x20, 0x00]), 2),
+                      (bytes([0x00, 7, 0x20, 0x00]), 9), (cases[0][0][:-3], len(cases[0][1]))):
+        _, st, _ = dk.decode_blocks([(bad, olen)], fmt=2, methods=[2])
+        assert st == -3, (bad[:8], olen)
+
+
 def test_compiled_ring_decoders(oracle):
     """the ring decoders (lz4_decompress_valu_kernel / snappy_decompress_valu_kernel: decode variant 3, and where LZ4 frames
     above 32 KiB go) as hipcc compiles them, payload buffer and destination of exactly their sizes (the payload rounded up to

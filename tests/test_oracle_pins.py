@@ -271,6 +271,89 @@ def test_snappy_stream_framing(oracle):
     assert oracle.decompress_stream(SNAPPY, np.frombuffer(s, np.uint8), d.size).tobytes() == d.tobytes()
 
 
+# ---- LZF (round 4: decode only on the GPU; liblzf 3.6 is the pin for the block format) --------------------
+LZF = 4
+HERE = os.path.dirname(os.path.abspath(__file__))
+_CONDA39 = "/opt/conda/bin/python3.9"
+
+
+def test_lzf_block_decoder_against_liblzf_fixtures(oracle):
+    """tests/golden/lzf_liblzf.npz was written by liblzf itself (imagecodecs of the conda python3.9,
+    tests/golden/make_lzf_golden.py): the oracle's block decoder gives the raw bytes back for every case, and its own
+    encoder's blocks decode to the source as well (a valid stream, not compress-lzf's bytes)"""
+    g = np.load(os.path.join(HERE, "golden", "lzf_liblzf.npz"))
+    names = sorted(k[4:] for k in g.files if k.startswith("raw_"))
+    assert len(names) >= 8
+    for n in names:
+        raw, enc = g["raw_" + n], g["lzf_" + n]
+        got = oracle.lzf_decompress_block(enc, raw.size)
+        assert not isinstance(got, int) and np.array_equal(got, raw), n
+        mine = oracle.lzf_compress_block(raw)
+        back = oracle.lzf_decompress_block(mine, raw.size)
+        assert not isinstance(back, int) and np.array_equal(back, raw), n
+    # malformed blocks: a reference in front of the block, a literal run / a reference cut off by the end
+    assert oracle.lzf_decompress_block(np.array([0x20, 0x05], np.uint8), 16) == -3
+    assert oracle.lzf_decompress_block(np.array([0x03, 1, 2], np.uint8), 16) == -3
+    assert oracle.lzf_decompress_block(np.array([0x00, 7, 0xE0], np.uint8), 16) == -3
+    assert oracle.lzf_decompress_block(np.array([0x00, 7, 0x20, 0x00], np.uint8), 2) == -2
+
+
+def test_lzf_live_against_liblzf(oracle):
+    """both directions against the C library, when the image's conda python3.9 (imagecodecs) is there: liblzf decodes what the
+    oracle's encoder writes, the oracle decodes what liblzf writes, on fresh corpora"""
+    import subprocess
+
+    if not os.path.exists(_CONDA39):
+        pytest.skip("no conda python3.9 with imagecodecs")
+    script = os.path.join(HERE, "golden", "make_lzf_golden.py")
+    probe = subprocess.run([_CONDA39, "-c", "import imagecodecs"], capture_output=True)
+    if probe.returncode != 0:
+        pytest.skip("imagecodecs not importable")
+    rng = np.random.default_rng(44)
+    for kind in (0, 2, 3, 6, 7):
+        d = corpus.chunk_corpus(kind, 40_000 if kind != 6 else 6000, rng)
+        enc = subprocess.run([_CONDA39, script, "--encode"], input=d.tobytes(), capture_output=True, check=True).stdout
+        got = oracle.lzf_decompress_block(np.frombuffer(enc, np.uint8), d.size)
+        assert not isinstance(got, int) and np.array_equal(got, d), kind
+        mine = oracle.lzf_compress_block(d)
+        back = subprocess.run([_CONDA39, script, "--decode", str(d.size)], input=mine.tobytes(), capture_output=True, check=True).stdout
+        assert back == d.tobytes(), kind
+
+
+def test_lzf_chunk_stream_framing(oracle):
+    """compress-lzf chunks: 'Z' 'V' type | len BE [| ulen BE]; chunks of at most 65 535 bytes, stored when they do not shrink;
+    concatenated streams are more chunks; the layout functions take the codec like the others"""
+    rng = np.random.default_rng(45)
+    d = np.concatenate([corpus.chunk_corpus(7, 100_000, rng), rng.integers(0, 256, 70_000, dtype=np.uint8)])
+    offs = np.array([0, 90_000, 90_000, 150_000, d.size], np.int64)
+    img, index, sums = oracle.compress_map_output(LZF, ADLER, d, offs)
+    pos, seen, kinds = 0, 0, set()
+    first = img[:index[1]].tobytes()
+    while pos < len(first):
+        assert first[pos:pos + 2] == b"ZV" and first[pos + 2] in (0, 1)
+        kinds.add(first[pos + 2])
+        n = struct.unpack(">H", first[pos + 3:pos + 5])[0]
+        if first[pos + 2] == 1:
+            u = struct.unpack(">H", first[pos + 5:pos + 7])[0]
+            blk = np.frombuffer(first[pos + 7:pos + 7 + n], np.uint8)
+            assert np.array_equal(oracle.lzf_decompress_block(blk, u), d[seen:seen + u])
+            pos += 7 + n
+            seen += u
+        else:
+            assert first[pos + 5:pos + 5 + n] == d[seen:seen + n].tobytes()
+            pos += 5 + n
+            seen += n
+    assert seen == 90_000 and index[2] == index[1]
+    rc, back, bad = oracle.decompress_range(LZF, ADLER, img, index, sums, d.size)
+    assert rc == 0 and np.array_equal(back, d)
+    # the random partition is stored chunks
+    third = img[index[3]:index[4]].tobytes()
+    assert third[2] == 0
+    bad_img = img.copy()
+    bad_img[1] = ord("X")
+    assert oracle.decompress_range(LZF, 0, bad_img, index, None, d.size)[0] == -3
+
+
 # ---- map-output layout (.data / .index / .checksum) ------------------------------------------------
 @pytest.mark.parametrize("codec", [LZ4, SNAPPY, NONE])
 @pytest.mark.parametrize("algo", [ADLER, CRC])

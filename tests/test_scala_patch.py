@@ -77,7 +77,7 @@ def test_reduce_side_on_its_own_and_the_zstd_gate(patched_tree):
     m = re.search(r"val gpuReadEnabled: Boolean = gpuEnabled \|\| \{(.*?)\n  \}", disp, re.S)
     assert m, "gpuReadEnabled"
     body = m.group(1)
-    for needle in ('case "lz4" | "zstd" => true', 'case "snappy" => gpuSnappyBlockSize <= 32768', "conf.get(config.SHUFFLE_COMPRESS)",
+    for needle in ('case "lz4" | "zstd" | "lzf" => true', 'case "snappy" => gpuSnappyBlockSize <= 32768', "conf.get(config.SHUFFLE_COMPRESS)",
                    "!conf.get(config.IO_ENCRYPTION_ENABLED)", "!useSparkShuffleFetch", "spark.shuffle.s3.gpu.read.enabled"):
         assert needle in body, needle
     assert 'val gpuReadCodec: String = if (gpuEnabled) gpuCodec else conf.get("spark.io.compression.codec", "lz4")' in disp
@@ -87,9 +87,9 @@ def test_reduce_side_on_its_own_and_the_zstd_gate(patched_tree):
     assert "S3SCodec.decodeCodecId(dispatcher.gpuReadCodec)" in dec
     assert "r1 - r0 >= d.gpuZstdMinPartitions" in dec and "<= d.gpuZstdMaxFrameBytes" in dec
     codec = _read(SHIM, "S3SCodec.scala")
-    assert re.search(r'def supportsDecode.*?case "lz4" \| "snappy" \| "zstd" => true', codec, re.S)
+    assert re.search(r'def supportsDecode.*?case "lz4" \| "snappy" \| "zstd" \| "lzf" => true', codec, re.S)
     assert re.search(r'def supports\(.*?case "lz4" \| "snappy" => true', codec, re.S)  # the map side: no zstd
-    assert re.search(r'def decodeCodecId.*?case "zstd" => CODEC_ZSTD', codec, re.S)
+    assert re.search(r'def decodeCodecId.*?case "zstd" => CODEC_ZSTD.*?case "lzf" => CODEC_LZF', codec, re.S)
 
 
 def test_methods_the_patch_calls_exist_in_the_shim():
