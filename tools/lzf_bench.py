@@ -1,0 +1,91 @@
+"""(GPU) verify + decompress of LZF map outputs (spark.io.compression.codec=lzf): 200 partitions of 128 MiB TeraSort map outputs
+written as LZFOutputStream writes them - compress-lzf chunks of 65 535 bytes around blocks encoded by liblzf 3.6 (the C library,
+through the image's conda python3.9: tests/golden/make_lzf_golden.py --stream) - decoded by the batched reduce-side call.
+The product never compresses LZF; the inputs are built by the third-party library, the library under test only decodes them.
+usage: python tools/lzf_bench.py [--maps 4] [--mib 128] [--steps 5]"""
+import argparse
+import os
+import subprocess
+import sys
+import time
+import zlib
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "spark-s3-shuffle_amd"))
+import numpy as np  # noqa: E402
+
+CONDA39 = "/opt/conda/bin/python3.9"
+SCRIPT = os.path.join(ROOT, "tests", "golden", "make_lzf_golden.py")
+
+
+def lzf_stream(raw: bytes) -> bytes:
+    return subprocess.run([CONDA39, SCRIPT, "--stream"], input=raw, capture_output=True, check=True).stdout if raw else b""
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--maps", type=int, default=4)
+    ap.add_argument("--mib", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--partitions", type=int, default=200)
+    args = ap.parse_args()
+    import torch
+
+    import s3shuffle
+    from s3shuffle import datagen
+
+    dev = torch.device("cuda", 0)
+    codec = s3shuffle.Codec(0)
+    ranges, keep, total_u, total_c = [], [], 0, 0
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(16) as ex:
+        for m in range(args.maps):
+            data, offs = datagen.terasort_map_output(args.mib << 20, args.partitions, seed=2, map_id=m)
+            streams = list(ex.map(lambda p: lzf_stream(data[offs[p]:offs[p + 1]].tobytes()), range(args.partitions)))
+            img = np.frombuffer(b"".join(streams), np.uint8)
+            index = np.concatenate([[0], np.cumsum([len(s) for s in streams])]).astype(np.int64)
+            sums = np.array([zlib.adler32(s) for s in streams], np.int64)
+            d_img = torch.from_numpy(img.copy()).to(dev)
+            d_out = torch.empty(data.size, dtype=torch.uint8, device=dev)
+            keep.append((d_img, d_out, data))
+            ranges.append((d_img.data_ptr(), img.size, index, sums, d_out.data_ptr(), data.size))
+            total_u += data.size
+            total_c += img.size
+    print(f"inputs: {args.maps} map outputs, {total_u / 1e6:.0f} MB -> {total_c / 1e6:.0f} MB of LZF chunks (ratio {total_u / total_c:.2f}), "
+          f"built by liblzf in {time.perf_counter() - t0:.0f} s", flush=True)
+    res = codec.decompress_ranges_batch_device(s3shuffle.CODEC_LZF, s3shuffle.CHECKSUM_ADLER32, ranges)
+    assert all(r[0] == 0 for r in res)
+    for d_img, d_out, data in keep:
+        assert np.array_equal(d_out.cpu().numpy(), data)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        codec.decompress_ranges_batch_device(s3shuffle.CODEC_LZF, s3shuffle.CHECKSUM_ADLER32, ranges)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    print(f"lzf verify + decompress, {args.maps} x {args.mib} MiB map outputs per call: {total_u / dt / 1e9:.1f} GB/s ({dt * 1e3:.2f} ms per call), bit-exact", flush=True)
+    # the host beside it: the oracle's block decoder (a plain C restatement of liblzf's lzf_decompress), one range per thread
+    try:
+        sys.path.insert(0, ROOT)
+        from oracle import binding as oracle
+
+        cores = len(os.sched_getaffinity(0))
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if q != "max":
+                cores = max(1, min(cores, int(float(q) / float(per) + 0.5)))
+        except Exception:
+            pass
+        d_img, d_out, data = keep[0]
+        img = d_img.cpu().numpy()
+        idx, sm = ranges[0][2], ranges[0][3]
+        s1, n = oracle.mt_decompress_bench(oracle.CODEC_LZF, oracle.CHECKSUM_ADLER32, img, idx, sm, data.size, cores, reps=3, use_liblz4=False)
+        print(f"host: {cores} threads x 3 reps of one map output (oracle restatement of lzf_decompress + Adler32): {data.size * cores * 3 / s1 / 1e9:.1f} GB/s", flush=True)
+    except Exception as e:
+        print("host leg failed:", repr(e))
+    codec.close()
+
+
+if __name__ == "__main__":
+    main()
