@@ -14,7 +14,7 @@ import gfx950_emu as emu  # noqa: E402
 import lz4_kernel as lk  # noqa: E402
 
 _PROG = None
-FLAGS = ()  # extra hipcc flags (build switches kept for measurements, e.g. ("-DZS_X_SOMETHING",)); set before program()
+FLAGS = tuple(__import__("os").environ.get("ZK_FLAGS", "").split())  # extra hipcc flags (env ZK_FLAGS for tools) (build switches kept for measurements, e.g. ("-DZS_X_SOMETHING",)); set before program()
 
 
 def program():
