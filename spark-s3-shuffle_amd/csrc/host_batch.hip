@@ -53,10 +53,10 @@ int hb_init(s3s_ctx* ctx) {
     CopyLanes& L = g_lanes[ctx->device & 63];
     std::lock_guard<std::mutex> g(L.create);
     // The lanes are created at the HIGHEST stream priority: the runtime keeps one pool of hardware queues per priority, so a
-    // lane never shares a hardware queue with a context's (normal-priority) compute stream.  Streams that share a queue run
-    // one after the other; which streams share one depends on how many the process has created before, and that is what made
-    // the two-thread figure of the round-3 bench line dip (49 / 35 / 45 GB/s with 1 / 2 / 4 task threads after the other
-    // workloads had run in the process, 43 / 43 / 44 in a fresh one).  S3S_HB_LANE_PRIO=0: normal priority.
+    // lane never shares a hardware queue with a context's (normal-priority) compute stream - streams that share a queue run
+    // one after the other.  Measured in the bench process (profiles/r04d, r04e): shared lanes at normal priority 49.6 / 52.8 /
+    // 43.5 GB/s with 1 / 2 / 4 task threads, at the highest priority 49.5 / 53.3 / 50.9 (three runs within 1 GB/s); own
+    // streams per context (round 3) 49.7 / 47.1 / 43.5.  S3S_HB_LANE_PRIO=0: normal priority.
     // S3S_HB_LANE_PRIO=2: upload lane highest, download lane LOWEST priority (three pools: the two lanes cannot share a queue either).
     int least = 0, greatest = 0;
     static const int prio = getenv("S3S_HB_LANE_PRIO") ? atoi(getenv("S3S_HB_LANE_PRIO")) : 1;
