@@ -101,8 +101,9 @@ def reference_frames(stream: bytes):
     return out
 
 
-def discover_snappy(stream: bytes, part_offsets):
-    """SnappyOutputStream images of several partitions in one range (csrc/snappy_decompress.hip: snappy_count_kernel ->
+def discover_snappy(stream: bytes, part_offsets, chunk_format=0):
+    """chunk_format 1: compress-lzf chunk chains (LZFInputStream) through the same two kernels (round 4).
+    SnappyOutputStream images of several partitions in one range (csrc/snappy_decompress.hip: snappy_count_kernel ->
     scan_u32_kernel -> snappy_emit_kernel -> scan_u32_kernel, as decode_api.hip launches them).
     -> (status, frames [(payload offset, payload bytes, decoded bytes, 0, 1)], output offsets)"""
     offs = np.asarray(part_offsets, np.int64)
@@ -126,7 +127,7 @@ def discover_snappy(stream: bytes, part_offsets):
     base = np.full(n_parts + 1, -7, np.int64)
     status = np.zeros(1, np.int32)
     a_cnt, a_base, a_st = mem.map(cnt, "part_nframes"), mem.map(base, "frame_base"), mem.map(status, "status")
-    run("snappy_count_kernel", struct.pack("<QQiiQQ", a_comp, a_off, n_parts, 0, a_cnt, a_st), (n_parts + 63) // 64)
+    run("snappy_count_kernel", struct.pack("<QQiiQQi", a_comp, a_off, n_parts, 0, a_cnt, a_st, chunk_format), (n_parts + 63) // 64)
     if int(status[0]) != 0:
         return int(status[0]), [], [0]  # (the host stops here: "Stream is corrupted (snappy chunk chain)")
     _launch("scan_u32_kernel", mem, struct.pack("<QqQ", a_cnt, n_parts, a_base), 1)
@@ -137,7 +138,7 @@ def discover_snappy(stream: bytes, part_offsets):
     a_fr = mem.map(frames if n_frames else np.zeros(1, np.uint8), "frames")
     a_or = mem.map(orig if n_frames else np.zeros(1, np.uint32), "frame_orig")
     a_fo = mem.map(fout, "frame_out")
-    run("snappy_emit_kernel", struct.pack("<QQiiQQQQ", a_comp, a_off, n_parts, 0, a_base, a_fr, a_or, a_st), (n_parts + 63) // 64)
+    run("snappy_emit_kernel", struct.pack("<QQiiQQQQi", a_comp, a_off, n_parts, 0, a_base, a_fr, a_or, a_st, chunk_format), (n_parts + 63) // 64)
     _launch("scan_u32_kernel", mem, struct.pack("<QqQ", a_or, n_frames, a_fo), 1)
     recs = [struct.unpack_from("<qiiIi", frames, 24 * k) for k in range(n_frames)]
     return int(status[0]), recs, [int(x) for x in fout]

@@ -511,6 +511,37 @@ def test_whole_snappy_reduce_side_call_through_the_compiled_kernels(oracle):
     assert dsc.discover_snappy(bytes(bad), idx)[0] == -3
 
 
+def test_whole_lzf_reduce_side_call_through_the_compiled_kernels(oracle):
+    """round 4: LZFInputStream images: the chunk walk of walk_partition_lzf (count -> scan -> emit; compressed and stored chunks,
+    chunks of the 65 535-byte maximum, an empty partition, two streams in one partition) feeds the compiled batch decoder's LZF
+    front end (stored chunks are copied); chains that end inside a header / a chunk, a wrong magic, a chunk type above 1 are
+    S3S_E_BAD_FRAME without leaving the range"""
+    import decode_kernel as dk
+    import discover_kernel as dsc
+
+    rng = np.random.default_rng(57)
+    parts = [corpus.chunk_corpus(7, 150_000, rng).tobytes(), b"", rng.integers(0, 256, 70_000, dtype=np.uint8).tobytes(),
+             corpus.chunk_corpus(6, 9000, rng).tobytes(), corpus.chunk_corpus(3, 11, rng).tobytes()]
+    data = np.frombuffer(b"".join(parts), np.uint8)
+    offs = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int64)
+    img, idx, _ = oracle.compress_map_output(4, 0, data, offs)
+    image = img.tobytes()
+    st, recs, outs = dsc.discover_snappy(image, idx, chunk_format=1)
+    assert st == 0 and outs[-1] == data.size and len(recs) == 3 + 2 + 1 + 1
+    assert {r[4] for r in recs} == {2, 0x10}  # compressed chunks and stored ones (the random partition)
+    st, back = dk.decode_range(image, recs, outs, fmt=2)
+    assert st == 0 and back == data.tobytes()
+    twice = image[: int(idx[1])] * 2  # a multi-spill merge: simply more chunks
+    st, recs, outs = dsc.discover_snappy(twice, [0, len(twice)], chunk_format=1)
+    assert st == 0 and len(recs) == 6 and outs[-1] == 2 * len(parts[0])
+    for cut in (1, 3, 4, 6, 17, 100, int(idx[1]) - 1):
+        assert dsc.discover_snappy(image[:cut], [0, cut], chunk_format=1)[0] == -3, cut
+    for at, v in ((0, ord("X")), (1, ord("W")), (2, 2)):
+        bad = bytearray(image)
+        bad[at] = v
+        assert dsc.discover_snappy(bytes(bad), idx, chunk_format=1)[0] == -3, at
+
+
 # ---- the compiled checksum kernels under the interpreter ----------------------------------------------------------------------
 @pytest.mark.parametrize("algo", [1, 2], ids=["adler32", "crc32"])
 def test_compiled_checksum_kernels(algo):
