@@ -382,7 +382,33 @@ ZS_HD int huf_decode_stream(const Work& w, const uint8_t* p, int64_t size, uint8
   BitR r;
   if (!bitr_init(r, p, size, false)) return ZS_FAIL();
   const int log = w.huf_log;
-  for (int64_t i = 0; i < n; i++) {
+  int64_t i = 0;
+#ifndef ZS_NO_HUF4
+  // Four symbols per refill (round 4): a window of 64 bits whose top byte holds bit pos - 1 has at least 57 bits below the cursor, four
+  // codes take at most 44 (kHufLogMax = 11), so the cursor never leaves the window in between: one bounds-free 8-byte load, four
+  // table lookups, one 4-byte store - instead of a refill check and a byte store per symbol.  pos >= 64 keeps the window inside the
+  // stream (no zero fill below its first byte); the last symbols of a stream take the loop below.
+  {
+    const uint32_t mask = (1u << log) - 1u;
+    while (i + 4 <= n && r.pos >= 64) {
+      const int32_t b0 = ((r.pos - 1) >> 3) - 7;
+      uint64_t cache;
+      memcpy(&cache, r.p + b0, 8);
+      int32_t rel = r.pos - b0 * 8;  // 57 .. 64 bits below the cursor
+      uint32_t out4 = 0;
+      for (int k = 0; k < 4; k++) {  // (unrolled by both compilers)
+        const uint16_t e = w.huf[(uint32_t)(cache >> (rel - log)) & mask];
+        rel -= e & 0xff;
+        out4 |= (uint32_t)(e >> 8) << (8 * k);
+      }
+      r.pos = b0 * 8 + rel;
+      memcpy(dst + i, &out4, 4);
+      i += 4;
+    }
+    r.cbase = 1 << 30;  // (the per-symbol loop refills its own window)
+  }
+#endif
+  for (; i < n; i++) {
     const uint32_t v = bitr_peek(r, log);  // (bits below the start of the stream read as zero, like libzstd's container)
     const uint16_t e = w.huf[v];
     r.pos -= e & 0xff;
