@@ -15,7 +15,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--encode":
     sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "--stream":
     # stdin: one partition's bytes -> stdout: what LZFOutputStream writes for it (chunks of at most 65 535 bytes, liblzf
-    # blocks, a chunk that does not shrink by at least two bytes stored) - tools/lzf_bench.py builds its inputs with this
+    # blocks, a chunk that does not shrink by at least two bytes stored) - tests/tools/lzf_bench.py builds its inputs with this
     import struct
 
     raw = sys.stdin.buffer.read()

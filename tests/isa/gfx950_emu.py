@@ -1335,6 +1335,37 @@ class Program:
         x = np.where((width > 0) & (sign == 1), x - (np.int64(1) << width.astype(np.int64)), x)
         w.wv32(i.ops[0], (np.where(width == 0, 0, x) & 0xFFFFFFFF).astype(np.uint32))
 
+    @staticmethod
+    def _pk_sel(i, name, default):
+        """op_sel / op_sel_hi of a packed (VOP3P) instruction -> list of 0 / 1 per source"""
+        v = i.mods.get(name)
+        if v is None:
+            return default
+        return [int(x) for x in v.strip("[]").split(",")]
+
+    def _pk_shift(self, w, i, left):
+        # D.lo = S1.[lo|hi] shifted by S0.[lo|hi] & 15, D.hi likewise; op_sel picks the halves for the LOW result (default
+        # low, low), op_sel_hi for the HIGH result (default high, high); an inline constant has its value in the low half
+        sel_lo, sel_hi = self._pk_sel(i, "op_sel", [0, 0]), self._pk_sel(i, "op_sel_hi", [1, 1])
+        a, b = w.rv32(i.ops[1]), w.rv32(i.ops[2])
+
+        def half(x, hi):
+            return (x >> np.uint32(16)) if hi else (x & np.uint32(0xFFFF))
+
+        def sh(x, n):
+            n = n & np.uint32(15)
+            return ((x << n) if left else (x >> n)) & np.uint32(0xFFFF)
+
+        lo = sh(half(b, sel_lo[1]), half(a, sel_lo[0]))
+        hi = sh(half(b, sel_hi[1]), half(a, sel_hi[0]))
+        w.wv32(i.ops[0], lo | (hi << np.uint32(16)))
+
+    def x_v_pk_lshlrev_b16(self, w, i):
+        self._pk_shift(w, i, True)
+
+    def x_v_pk_lshrrev_b16(self, w, i):
+        self._pk_shift(w, i, False)
+
     def x_v_bitop3_b16(self, w, i):
         # as v_bitop3_b32 on the low halves (the high half of the destination is kept)
         tt = int(i.mods["bitop3"], 0)

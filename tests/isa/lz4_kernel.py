@@ -29,8 +29,8 @@ def compile_asm(src="lz4_compress.hip", flags=(), cache_dir=None):
     h = hashlib.sha1()
     for p in (path, os.path.join(CSRC, "s3s_internal.h"), os.path.join(CSRC, "s3s_ctx.h")):
         h.update(open(p, "rb").read())
-    for extra in sorted(os.listdir(CSRC)):
-        if extra.endswith(".inc"):
+    for extra in sorted(os.listdir(CSRC)):  # every header and include a kernel source can pull in (zstd_decode_core.h was missing
+        if extra.endswith((".inc", ".h")):  # until round 4: a header-only change ran the interpreter tests on a stale assembly)
             h.update(open(os.path.join(CSRC, extra), "rb").read())
     h.update(" ".join(flags).encode())
     out = os.path.join(cache_dir, "%s.%s.s" % (src, h.hexdigest()[:12]))

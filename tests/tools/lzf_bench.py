@@ -2,7 +2,7 @@
 written as LZFOutputStream writes them - compress-lzf chunks of 65 535 bytes around blocks encoded by liblzf 3.6 (the C library,
 through the image's conda python3.9: tests/golden/make_lzf_golden.py --stream) - decoded by the batched reduce-side call.
 The product never compresses LZF; the inputs are built by the third-party library, the library under test only decodes them.
-usage: python tools/lzf_bench.py [--maps 4] [--mib 128] [--steps 5]"""
+usage: python tests/tools/lzf_bench.py [--maps 4] [--mib 128] [--steps 5]"""
 import argparse
 import os
 import subprocess
@@ -11,7 +11,7 @@ import time
 import zlib
 from concurrent.futures import ThreadPoolExecutor
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "spark-s3-shuffle_amd"))
 import numpy as np  # noqa: E402
 
