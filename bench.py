@@ -49,7 +49,44 @@ WORKLOADS = {
     "terasort-100g-2000p-lz4-crc32": ("terasort", 2000, "lz4", "crc32"),  # configs[3]
     "skew-1part-lz4": ("skew", 1, "lz4", "adler32"),                  # configs[4] (use --direction decompress)
     "terasort-10g-200p-zstd": ("terasort", 200, "zstd", "adler32"),   # reduce side only (--direction decompress)
+    # objects of a JVM writer with spark.io.compression.lz4.blockSize=256k (S3ShuffleReader.scala:57-59): reduce side only
+    "terasort-10g-200p-lz4-256k": ("terasort", 200, "lz4", "adler32"),
 }
+JVM_LZ4_BLOCK = {"terasort-10g-200p-lz4-256k": 262144}  # workloads whose inputs are LZ4Block images written by liblz4 on the host
+
+
+def jvm_lz4_map_output_image(data, offs, algo_name: str, block_size: int):
+    """What LZ4BlockOutputStream(blockSize) writes per partition, built with liblz4 (third-party library of the image, as libzstd for
+    the zstd inputs): LZ4_compress_default per block (>= 64 KiB: its byU32 parse), token level = log2(blockSize) - 10, stored block when
+    compression does not help, end frame; per-partition checksums by zlib.  The product only decodes these."""
+    import ctypes
+    import struct
+    import zlib
+
+    import xxhash
+
+    L = ctypes.CDLL("liblz4.so.1")
+    L.LZ4_compress_default.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    level = max(0, int(block_size).bit_length() - 1 - 10)
+    buf = np.empty(block_size + block_size // 200 + 64, np.uint8)
+    streams = []
+    for p in range(len(offs) - 1):
+        part = np.ascontiguousarray(data[offs[p]:offs[p + 1]])
+        out = bytearray()
+        for q in range(0, part.size, block_size):
+            chunk = part[q:q + block_size]
+            n = L.LZ4_compress_default(chunk.ctypes.data, buf.ctypes.data, chunk.size, buf.size)
+            raw = n <= 0 or n >= chunk.size
+            body = chunk.tobytes() if raw else buf[:n].tobytes()
+            out += b"LZ4Block" + bytes([(0x10 if raw else 0x20) | level]) + struct.pack(
+                "<iiI", len(body), chunk.size, xxhash.xxh32(chunk.tobytes(), seed=0x9747B28C).intdigest() & 0x0FFFFFFF) + body
+        if part.size:
+            out += b"LZ4Block" + bytes([0x10 | level]) + struct.pack("<iii", 0, 0, 0)
+        streams.append(bytes(out))
+    img = np.frombuffer(b"".join(streams), np.uint8)
+    index = np.concatenate([[0], np.cumsum([len(x) for x in streams])]).astype(np.int64)
+    f = zlib.adler32 if algo_name == "adler32" else zlib.crc32
+    return img, index, np.array([f(x) for x in streams], np.int64)
 
 
 # ---- Zstandard inputs (reduce side only): the map outputs a JVM writer produces with spark.io.compression.codec=zstd ----
@@ -296,7 +333,7 @@ def cpu_baseline(workload: str, target_s: float, map_mib: int = 128):
     }
 
 
-def cpu_baseline_decompress(workload: str, target_s: float, map_mib: int = 128):
+def cpu_baseline_decompress(workload: str, target_s: float, map_mib: int = 128, block_size: int = 0):
     """Reduce side on the host cores: one fetched block range per thread, per-partition checksum validation
     (S3ChecksumValidationStream) + LZ4BlockInputStream over liblz4 1.9.3's LZ4_decompress_safe + xxh32 frame
     checks (oracle/s3s_oracle_mt.c) — what the JVM reader does per task, without JVM/JNI overheads."""
@@ -310,7 +347,10 @@ def cpu_baseline_decompress(workload: str, target_s: float, map_mib: int = 128):
     data, offs = make_map_output(workload, 0, sample_mib << 20)
     algo_id = {"adler32": oracle.CHECKSUM_ADLER32, "crc32": oracle.CHECKSUM_CRC32}[algo]
     codec_o = oracle.CODEC_LZ4 if codec == "lz4" else oracle.CODEC_SNAPPY
-    img, index, sums = oracle.compress_map_output(codec_o, algo_id, data, offs)
+    if block_size:  # a JVM writer's larger LZ4 blocks: the same liblz4-written image the GPU leg decodes
+        img, index, sums = jvm_lz4_map_output_image(data, offs, algo, block_size)
+    else:
+        img, index, sums = oracle.compress_map_output(codec_o, algo_id, data, offs)
     have_lib = bool(oracle.lib().s3o_mt_have_liblz4()) if codec == "lz4" else bool(oracle.lib().s3o_mt_have_libsnappy())
     simd = int(oracle.lib().s3o_simd_available())
     s1, n = oracle.mt_decompress_bench(codec_o, algo_id, img, index, sums, data.size, cores, reps=1)
@@ -404,12 +444,18 @@ def run_workload(args, rank: int, local_rank: int, world: int, dist):
             c.set_option(s3shuffle.codec.OPT_LZ4_VARIANT, args.lz4_variant)
         if args.lz4_decode_variant >= 0:
             c.set_option(s3shuffle.codec.OPT_LZ4_DECODE_VARIANT, args.lz4_decode_variant)
-    zstd_images = None
-    if codec_name == "zstd":  # the JVM-written objects: built on the host with libzstd (input generation, untimed)
+    zstd_images = None  # (host-built images of JVM writers: zstd frames, or LZ4Block frames of a larger block size)
+    jvm_block = JVM_LZ4_BLOCK.get(args.workload)
+    if jvm_block and args.direction != "decompress":
+        raise SystemExit("LZ4 blocks above 32 KiB are decoded, not written, by the GPU path: use --direction decompress")
+    if codec_name == "zstd" or jvm_block:  # the JVM-written objects: built on the host with libzstd / liblz4 (input generation, untimed)
         zstd_images = [None] * len(outputs)
 
         def _zimg(i):
-            zstd_images[i] = zstd_map_output_image(outputs[i][0], outputs[i][1], algo_name)
+            if jvm_block:
+                zstd_images[i] = jvm_lz4_map_output_image(outputs[i][0], outputs[i][1], algo_name, jvm_block)
+            else:
+                zstd_images[i] = zstd_map_output_image(outputs[i][0], outputs[i][1], algo_name)
 
         zt = [threading.Thread(target=_zimg, args=(i,)) for i in range(len(outputs))]
         [t.start() for t in zt]
@@ -621,7 +667,8 @@ def run_workload(args, rank: int, local_rank: int, world: int, dist):
                 "generator": {"terasort": "TeraGen-like 100-byte records, seed 2", "tpcds": "UnsafeRow-like wide rows, seed 3",
                               "skew": "single-partition TeraGen-like block, seed 5"}[gen],
                 "direction": args.direction,
-                "codec": "lz4 (LZ4Block frames, 32 KiB blocks; payload bit-exact with liblz4 1.9.3 LZ4_compress_default, framing restated from lz4-java 1.8.0)" if codec_name == "lz4"
+                "codec": ("lz4 (decode only: LZ4Block frames of %d KiB blocks written by liblz4 1.9.3 on the host, as a JVM writer with that spark.io.compression.lz4.blockSize)" % (jvm_block >> 10)) if jvm_block
+                         else "lz4 (LZ4Block frames, 32 KiB blocks; payload bit-exact with liblz4 1.9.3 LZ4_compress_default, framing restated from lz4-java 1.8.0)" if codec_name == "lz4"
                          else "snappy (SnappyOutputStream framing, 32 KiB blocks, byte-exact with snappy 1.1.8)" if codec_name == "snappy"
                          else "zstd (decode only: libzstd 1.4.8 streaming frames, level 1, one per partition, as zstd-jni writes them)",
                 "checksum": algo_name,
@@ -663,7 +710,10 @@ def run_workload(args, rank: int, local_rank: int, world: int, dist):
             if codec_name == "zstd":
                 cb = cpu_baseline_zstd_decompress(args.workload, args.cpu_seconds, args.map_mib)
             else:
-                cb = (cpu_baseline_decompress if decompress else cpu_baseline)(args.workload, args.cpu_seconds, args.map_mib)
+                if decompress:
+                    cb = cpu_baseline_decompress(args.workload, args.cpu_seconds, args.map_mib, JVM_LZ4_BLOCK.get(args.workload, 0))
+                else:
+                    cb = cpu_baseline(args.workload, args.cpu_seconds, args.map_mib)
             out["cpu_baseline"] = cb
             if cb:
                 out["speedup_vs_cpu_all_cores"] = round(value / cb["value"], 3)
@@ -715,6 +765,7 @@ SECONDARY = [
     ("skew-1gib-lz4:compress", "skew-1part-lz4", "compress", 1024, 1),
     ("skew-1gib-lz4:decompress", "skew-1part-lz4", "decompress", 1024, 1),
     ("terasort-200p-zstd:decompress", "terasort-10g-200p-zstd", "decompress", 128, 8),  # frames in flight are its throughput
+    ("terasort-200p-lz4-256k-blocks:decompress", "terasort-10g-200p-lz4-256k", "decompress", 128, 4),  # round 4: frames above 32 KiB, batch decoder
 ]
 
 
