@@ -143,3 +143,103 @@ def test_snappy_foreign_valid_and_malformed_blocks(gpu_codec):
     for i, blk in enumerate(bad):
         rc, _ = _decode_guarded(gpu_codec, SNAPPY, framing.snappy_stream([good[0], blk]), 4096)
         assert rc == -3, (i, rc)
+
+
+def _lzf_chunk(block: bytes, ulen: int) -> bytes:
+    import struct
+
+    return b"ZV\x01" + struct.pack(">HH", len(block), ulen) + block
+
+
+def test_lzf_mutated_streams_agree_with_the_oracle_and_stay_inside(gpu_codec, oracle, decode_variant):
+    """round 4: LZF chunk streams (liblzf-written blocks from tests/golden/lzf_liblzf.npz and the oracle's encoder) under random
+    damage - flipped bits in chunk headers and block payloads, truncations, spliced chunks: the GPU decoder gives the oracle's
+    verdict (same bytes when both accept; S3S_E_BAD_FRAME when the oracle refuses) and never writes outside the destination.
+    (LZF has the batch decoder only: the decode-variant option does not change the path.)"""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lzf_liblzf.npz"))
+    rng = np.random.default_rng(77)
+    seeds = []
+    for n in ("records", "runs", "mixed", "far"):
+        seeds.append((_lzf_chunk(g["lzf_" + n].tobytes(), g["raw_" + n].size), g["raw_" + n].size))
+    d = corpus.chunk_corpus(7, 90_000, rng)
+    s = oracle.compress_map_output(4, 0, d, [0, d.size])[0].tobytes()
+    seeds.append((s, d.size))
+    agree_ok = agree_bad = 0
+    for it in range(120):
+        stream, ulen = seeds[it % len(seeds)]
+        b = bytearray(stream)
+        how = it % 4
+        if how == 0:
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        elif how == 1:
+            b = b[: int(rng.integers(1, len(b)))]
+        elif how == 2:
+            at = int(rng.integers(0, len(b)))
+            b[at:at] = bytes(rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8))
+        else:
+            other = seeds[(it + 1) % len(seeds)][0]
+            cut = int(rng.integers(5, min(len(b), len(other))))
+            b = b[:cut] + bytearray(other[cut:])
+        b = bytes(b)
+        cap = ulen + 300
+        ref_rc, ref_out, _ = oracle.decompress_range(4, 0, np.frombuffer(b, np.uint8), [0, len(b)], None, cap)
+        rc, out = _decode_guarded(gpu_codec, 4, b, cap, misalign=it % 5)
+        if ref_rc == 0:
+            assert rc == 0 and out == ref_out.tobytes(), (it, how)
+            agree_ok += 1
+        else:
+            assert rc in (-3, -2), (it, how, rc, ref_rc)
+            agree_bad += 1
+    assert agree_bad > 30 and agree_ok > 5, (agree_ok, agree_bad)
+
+
+def test_big_lz4_frames_malformed_payloads(gpu_codec, decode_variant):
+    """round 4: LZ4Block frames of 256 KiB blocks (liblz4's byU32 parse) with damaged payloads - flipped bytes, an offset that points in
+    front of the block 100 KB in, a literal run that overruns the block - are S3S_E_BAD_FRAME, valid ones decode exactly, and nothing outside
+    the destination changes (the frame check catches what still decodes)."""
+    import struct
+
+    rng = np.random.default_rng(78)
+    from s3shuffle import datagen
+
+    data = datagen.terasort_map_output(600_000, 1, seed=9)[0]
+    bs = 262144
+
+    def stream(payload_edit=None):
+        out = bytearray()
+        for p in range(0, data.size, bs):
+            chunk = np.ascontiguousarray(data[p:p + bs])
+            pay = bytearray(framing.lz4_fast(chunk))
+            if payload_edit and p == 0:
+                payload_edit(pay)
+            out += b"LZ4Block" + bytes([0x20 | 8]) + struct.pack("<iiI", len(pay), chunk.size, framing.xxh32(chunk.tobytes()) & 0x0FFFFFFF) + bytes(pay)
+        out += b"LZ4Block" + bytes([0x10 | 8]) + struct.pack("<iii", 0, 0, 0)
+        return bytes(out)
+
+    rc, out = _decode_guarded(gpu_codec, LZ4, stream(), data.size, misalign=3)
+    assert rc == 0 and out == data.tobytes()
+
+    def flip(pay):
+        for _ in range(3):
+            pay[int(rng.integers(100, len(pay)))] ^= 0x5A
+
+    def cut_tail(pay):
+        del pay[-7:]
+
+    for edit in (flip, cut_tail):
+        for _ in range(3):
+            rc, out = _decode_guarded(gpu_codec, LZ4, stream(edit), data.size)
+            assert rc == -3, edit.__name__
+    # hand-made: 100 000 literals, then a match whose offset reaches in front of the block
+    z = rng.integers(0, 256, 100_000, dtype=np.uint8).tobytes()
+    bad = framing.lz4_block([(z, 100_001, 8)], b"tail!")
+    good = framing.lz4_block([(z, 100_000, 8)], b"tail!")
+    orig = framing.lz4_decode_py(good, max_out=1 << 20)
+    for blk, want in ((good, 0), (bad, -3)):
+        s = b"LZ4Block" + bytes([0x20 | 8]) + struct.pack("<iiI", len(blk), len(orig), framing.xxh32(orig) & 0x0FFFFFFF) + blk + \
+            b"LZ4Block" + bytes([0x10 | 8]) + struct.pack("<iii", 0, 0, 0)
+        rc, out = _decode_guarded(gpu_codec, LZ4, s, len(orig), misalign=1)
+        assert rc == want and (want != 0 or out == orig)
