@@ -7,12 +7,13 @@
 // the JVM (libzstd's output is not reproducible by a data-parallel program), so the parity bar here is
 // "decodes every stream libzstd 1.4.8 — the library in this image, and the format zstd-jni writes — produces".
 //
-// Shape: one wavefront per partition.  The entropy stages are serial by construction (one FSE bit stream for a
+// Shape: one SEQUENCE wavefront per partition.  The entropy stages are serial by construction (one FSE bit stream for a
 // block's sequences, four Huffman streams for its literals), so the wave runs the control flow uniformly — every lane
-// computes the same header / table / sequence values — and spreads only what has width: the four Huffman streams go
-// to lanes 0..3, literal runs and matches are copied 64 bytes per step, table fills are strided over the lanes.
-// Throughput therefore comes from the number of partitions in flight (a batched call holds thousands), not from a
-// single frame; a 1 GiB single-partition block is one wavefront's serial work and belongs on the host.
+// computes the same header / table / sequence values — and spreads only what has width: literal runs and matches are copied
+// 64 bytes per step, table fills are strided over the lanes.  The four Huffman streams of a block go to lanes 0..3 of a
+// LITERAL wavefront (round 4), which works one block ahead of the sequence wavefront and serves two partitions (literal_side,
+// LitPipe below).  Throughput therefore comes from the number of partitions in flight (a batched call holds thousands), not
+// from a single frame; a 1 GiB single-partition block is one wavefront's serial work and belongs on the host.
 //
 // Compiled by hipcc (S3S_ZSTD_DEVICE: zstd_decompress.hip) and by g++ (tests/model/zstd_decode_model.cpp: the same
 // code with one "lane", checked against libzstd on the CPU before it ever reaches a GPU).
@@ -46,20 +47,36 @@ constexpr int kHufLogMax = 11;
 constexpr int kLLLogMax = 9, kMLLogMax = 9, kOFLogMax = 8;
 constexpr int kRing = 4096, kLitW = 1024;
 
-// per-wavefront tables (LDS on the device: 4 KiB + 5 KiB + scratch)
-struct Work {
+// The Huffman side of a partition (round 4: its own wavefront on the device, see literal_side): the literals table and the
+// scratch its description is read through.
+struct HufWork {
   uint16_t huf[1 << kHufLogMax];   // (symbol << 8) | nbBits
+  int16_t norm[16];                // normalized counts of the FSE-coded weights (weights are 0..12)
+  uint16_t next[16];
+  uint8_t weights[256];
+  uint32_t wtab[64];               // FSE table of the Huffman weights (tableLog <= 6)
+  int32_t huf_log, have_huf;       // have_huf: "treeless" literals need a previous table (of the same frame)
+};
+// What the two sides of a partition share.  Device: the literal wavefront decodes the Huffman streams of block k + 1 into
+// literal buffer (k + 1) & 1 while the sequence wavefront executes block k from buffer k & 1; `ready` / `consumed` count the
+// Huffman-coded blocks handed over / given back, `err` is the literal side's verdict, `quit` the sequence side's leave.
+// Host model: one thread does both, block by block (the counters stay unused).
+struct LitPipe {
+  HufWork h;
+  int32_t ready, consumed, err, quit;
+};
+
+// per-wavefront tables of the sequence side (LDS on the device)
+struct Work {
   uint32_t ll[1 << kLLLogMax];     // baseline | nbBits << 16 | symbol << 24
   uint32_t ml[1 << kMLLogMax];
   uint32_t of[1 << kOFLogMax];
   uint32_t llv[1 << kLLLogMax];    // per state: literal-length base | extra bits << 24 (so the loop reads no constant tables)
   uint32_t mlv[1 << kMLLogMax];    // per state: match-length base | extra bits << 24
-  int16_t norm[256];               // normalized counts (FSE header), also Huffman weight scratch
-  uint16_t next[256];              // symbolNext / rank starts
-  uint8_t weights[256];
-  uint32_t wtab[64];               // FSE table of the Huffman weights (tableLog <= 6)
-  int32_t huf_log, ll_log, ml_log, of_log;
-  int32_t have_huf, have_ll, have_ml, have_of;  // "repeat" modes need a previous table
+  int16_t norm[64];                // normalized counts (FSE header; at most 53 symbols: match-length codes)
+  uint16_t next[64];               // symbolNext
+  int32_t ll_log, ml_log, of_log;
+  int32_t have_ll, have_ml, have_of;  // "repeat" modes need a previous table
   int32_t vals_ll, vals_ml;
   // the frame's most recent output (position q lives at ring[q & (kRing - 1)]): match sources come from here, not from
   // global memory (a global source would need the stores of the sequences before it to have completed: ~1 us each)
@@ -294,7 +311,7 @@ ZS_HD int ml_bits(int c) {
 
 // ---- Huffman ----------------------------------------------------------------------------------------------------------------
 // Tree description -> decoding table.  Returns bytes consumed or a negative error.
-ZS_HD int read_huf_table(Work& w, const uint8_t* p, int64_t size) {
+ZS_HD int read_huf_table(HufWork& w, const uint8_t* p, int64_t size) {
   if (size < 1) return ZS_FAIL();
   const int hb = p[0];
   int nsym = 0;  // weights given explicitly
@@ -308,9 +325,8 @@ ZS_HD int read_huf_table(Work& w, const uint8_t* p, int64_t size) {
     used = 1 + hb;
     if (hb == 0 || used > size) return ZS_FAIL();
     int max_sym, log;
-    const int hdr = read_ncount(w.norm, 255, 6, p + 1, hb, &max_sym, &log);
+    const int hdr = read_ncount(w.norm, 12, 6, p + 1, hb, &max_sym, &log);  // weights are 0..12 (HUF_TABLELOG_ABSOLUTEMAX)
     if (hdr < 0) return hdr;
-    if (max_sym > 12) return ZS_FAIL();  // weights are 0..12 (HUF_TABLELOG_ABSOLUTEMAX)
     if (build_fse(w.wtab, w.norm, max_sym, log, w.next) != ZS_OK) return ZS_FAIL();
     BitR r;
     if (!bitr_init(r, p + 1 + hdr, hb - hdr)) return ZS_FAIL();
@@ -378,7 +394,7 @@ ZS_HD int read_huf_table(Work& w, const uint8_t* p, int64_t size) {
 }
 
 // one Huffman stream: n symbols into dst
-ZS_HD int huf_decode_stream(const Work& w, const uint8_t* p, int64_t size, uint8_t* dst, int64_t n) {
+ZS_HD int huf_decode_stream(const HufWork& w, const uint8_t* p, int64_t size, uint8_t* dst, int64_t n) {
   BitR r;
   if (!bitr_init(r, p, size, false)) return ZS_FAIL();
   const int log = w.huf_log;
@@ -516,58 +532,187 @@ ZS_HD void put_match(Work& w, uint8_t* out, int64_t q, int64_t offset64, int64_t
 struct FrameOut {
   int64_t consumed;  // bytes of src this frame occupied
   int64_t produced;  // decoded bytes
-  int64_t lit_need;  // largest regenerated (Huffman-coded) literals section of any block: what lit_buf must hold
+  int64_t lit_need;  // largest regenerated (Huffman-coded) literals section of any block: what one literal buffer must hold
 };
 
-// Decodes (execute = true) or only sizes (execute = false) the frame at src[0, size).  dst = where this frame's output
-// starts (history never reaches in front of it), cap = bytes available there.  lit_buf: kMaxBlock + 32 bytes of scratch.
-ZS_HD int decode_frame(Work& w, const uint8_t* src, int64_t size, uint8_t* dst, int64_t cap, bool execute, uint8_t* lit_buf,
-                       Lanes L, FrameOut* out) {
+struct FrameHdr {
+  int64_t bytes;     // header bytes (skippable frame: the whole frame)
+  int64_t fcs;       // frame content size, -1 when absent
+  int has_check, skippable;
+};
+// Frame header at src[0, size) (RFC 8878 3.1.1.1); both sides of a partition walk the same headers.
+ZS_HD int frame_header(const uint8_t* src, int64_t size, FrameHdr* fh) {
+  fh->fcs = -1;
+  fh->has_check = fh->skippable = 0;
   if (size < 4) return ZS_FAIL();
   const uint32_t magic = rd_le(src, 4);
   if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {  // skippable frame
     if (size < 8) return ZS_FAIL();
     const int64_t n = rd_le(src + 4, 4);
     if (8 + n > size) return ZS_FAIL();
-    out->consumed = 8 + n;
-    out->produced = 0;
-    out->lit_need = 0;
+    fh->bytes = 8 + n;
+    fh->skippable = 1;
     return ZS_OK;
   }
   if (magic != 0xFD2FB528u) return ZS_FAIL();
   if (size < 6) return ZS_FAIL();
   const uint32_t fhd = src[4];
-  const int fcs_flag = (int)(fhd >> 6), single = (int)((fhd >> 5) & 1), has_check = (int)((fhd >> 2) & 1), did_flag = (int)(fhd & 3);
+  const int fcs_flag = (int)(fhd >> 6), single = (int)((fhd >> 5) & 1), did_flag = (int)(fhd & 3);
+  fh->has_check = (int)((fhd >> 2) & 1);
   if (fhd & 0x08) return ZS_FAIL();  // reserved bit
   int64_t ip = 5;
-  int64_t window = 0;
-  if (!single) {
-    const uint32_t wd = src[ip++];
-    const int exp = (int)(wd >> 3), man = (int)(wd & 7);
-    const int64_t base = 1ll << (10 + exp);
-    window = base + (base >> 3) * man;
-  }
+  if (!single) ip++;  // window descriptor: a block is at most kMaxBlock whatever it says, and history is the whole frame here
   static const int did_bytes[4] = {0, 1, 2, 4};
   if (ip + did_bytes[did_flag] > size) return ZS_FAIL();
   if (did_flag && rd_le(src + ip, did_bytes[did_flag]) != 0) return ZS_UNSUPPORTED;  // dictionaries are not used by Spark
   ip += did_bytes[did_flag];
   const int fcs_bytes = fcs_flag == 0 ? (single ? 1 : 0) : (fcs_flag == 1 ? 2 : (fcs_flag == 2 ? 4 : 8));
   if (ip + fcs_bytes > size) return ZS_FAIL();
-  int64_t fcs = -1;
   if (fcs_bytes) {
     uint64_t v = 0;
     for (int i = 0; i < fcs_bytes; i++) v |= (uint64_t)src[ip + i] << (8 * i);
     if (fcs_bytes == 2) v += 256;
-    fcs = (int64_t)v;
+    fh->fcs = (int64_t)v;
     ip += fcs_bytes;
   }
-  if (single) window = fcs;
-  const int64_t block_max = window < kMaxBlock ? (window > 0 ? window : 1) : kMaxBlock;
-  (void)block_max;
+  fh->bytes = ip;
+  return ZS_OK;
+}
 
-  uint32_t rep[3] = {1, 4, 8};
+struct LitHdr {
+  int ltype;         // 0 raw, 1 RLE, 2 Huffman with a table, 3 Huffman with the previous table
+  int lh, streams;   // header bytes, Huffman streams (1 / 4)
+  int64_t regen, lcomp;  // regenerated size; compressed size incl. the table (Huffman types)
+};
+// Literals section header of a compressed block b[0, bsize) (RFC 8878 3.1.1.3.1.1), bounds included.
+ZS_HD int literals_header(const uint8_t* b, int64_t bsize, LitHdr* h) {
+  const int ltype = b[0] & 3, sf = (b[0] >> 2) & 3;
+  h->ltype = ltype;
+  h->streams = 1;
+  h->lcomp = 0;
+  if (ltype < 2) {  // raw / RLE
+    if (sf == 0 || sf == 2) { h->lh = 1; h->regen = b[0] >> 3; }
+    else if (sf == 1) { h->lh = 2; if (bsize < 2) return ZS_FAIL(); h->regen = (b[0] >> 4) + ((int64_t)b[1] << 4); }
+    else { h->lh = 3; if (bsize < 3) return ZS_FAIL(); h->regen = (b[0] >> 4) + ((int64_t)b[1] << 4) + ((int64_t)b[2] << 12); }
+    if (h->regen > kMaxBlock) return ZS_FAIL();
+    if (h->lh + (ltype == 0 ? h->regen : 1) > bsize) return ZS_FAIL();
+    return ZS_OK;
+  }
+  if (sf == 0 || sf == 1) {
+    h->lh = 3; if (bsize < 3) return ZS_FAIL();
+    const uint32_t v = rd_le(b, 3);
+    h->regen = (v >> 4) & 0x3FF; h->lcomp = v >> 14;
+    h->streams = sf == 0 ? 1 : 4;
+  } else if (sf == 2) {
+    h->lh = 4; if (bsize < 4) return ZS_FAIL();
+    const uint32_t v = rd_le(b, 4);
+    h->regen = (v >> 4) & 0x3FFF; h->lcomp = v >> 18;
+    h->streams = 4;
+  } else {
+    h->lh = 5; if (bsize < 5) return ZS_FAIL();
+    const uint64_t v = (uint64_t)rd_le(b, 4) | ((uint64_t)b[4] << 32);
+    h->regen = (int64_t)((v >> 4) & 0x3FFFF); h->lcomp = (int64_t)(v >> 22);
+    h->streams = 4;
+  }
+  if (h->regen > kMaxBlock || h->lh + h->lcomp > bsize) return ZS_FAIL();
+  return ZS_OK;
+}
+
+// The Huffman-coded literals of one block: table (ltype 2) or the frame's previous one (3), then the streams - stream k on
+// lane k (device); the host walks them one after the other.  hp[0, hleft) = table description + streams.  Every lane
+// returns the same code.
+ZS_HD int block_literals(HufWork& h, const LitHdr& lh, const uint8_t* hp, int64_t hleft, uint8_t* lit_buf, Lanes L) {
+  if (lh.ltype == 2) {
+    const int used = read_huf_table(h, hp, hleft);
+    if (used < 0) return used;
+    hp += used;
+    hleft -= used;
+#ifdef S3S_ZSTD_DEVICE
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (the table is in LDS before lanes 0..3 read it)
+#endif
+  } else if (!h.have_huf) {
+    return ZS_FAIL();
+  }
+  const int64_t regen = lh.regen;
+  int rc = ZS_OK;
+  if (lh.streams == 1) {
+    if (L.lane == 0) rc = huf_decode_stream(h, hp, hleft, lit_buf, regen);
+  } else {
+    if (hleft < 6) return ZS_FAIL();
+    const int64_t s1 = rd_le(hp, 2), s2 = rd_le(hp + 2, 2), s3 = rd_le(hp + 4, 2);
+    const int64_t s4 = hleft - 6 - s1 - s2 - s3;
+    if (s4 < 0) return ZS_FAIL();
+    const int64_t q = (regen + 3) / 4;
+    const int64_t n4 = regen - 3 * q;
+    if (n4 < 0) return ZS_FAIL();
+    const uint8_t* sp = hp + 6;
+    for (int k = 0; k < 4; k++) {
+      const int64_t sz = k == 0 ? s1 : k == 1 ? s2 : k == 2 ? s3 : s4;
+      const int64_t off = k == 0 ? 0 : k == 1 ? s1 : k == 2 ? s1 + s2 : s1 + s2 + s3;
+      if (L.lane == k % L.n) {
+        const int r1 = huf_decode_stream(h, sp + off, sz, lit_buf + k * q, k == 3 ? n4 : q);
+        if (r1 != ZS_OK) rc = r1;
+      }
+    }
+  }
+#ifdef S3S_ZSTD_DEVICE
+  {  // the first failing lane's code, to every lane
+    const unsigned long long bad = __ballot(rc != ZS_OK);
+    if (bad) rc = __shfl(rc, __builtin_ctzll(bad));
+  }
+#endif
+  return rc;
+}
+
+// ---- hand-over between the two sides (device) ------------------------------------------------------------------------------------
+#ifdef S3S_ZSTD_DEVICE
+ZS_HD int32_t pipe_get(const int32_t* p) { return (int32_t)ZS_UNI32(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)); }
+ZS_HD void pipe_set(int32_t* p, int32_t v, Lanes L) {  // what this wavefront stored to memory before is visible to whoever sees v
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (L.lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// sequence side: the literals of Huffman block number `want - 1` are in their buffer (or the literal side has failed)
+ZS_HD int pipe_wait_ready(LitPipe& lp, int32_t want) {
+#ifdef ZS_T_NOWAIT
+  return ZS_OK;
+#endif
+  for (;;) {
+    if (pipe_get(&lp.ready) >= want) return ZS_OK;
+    const int32_t e = pipe_get(&lp.err);
+    if (e != ZS_OK) return pipe_get(&lp.ready) >= want ? ZS_OK : e;  // (err is set after the last ready)
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+#endif
+
+// Decodes (execute = true) or only sizes (execute = false) the frame at src[0, size).  dst = where this frame's output
+// starts (history never reaches in front of it), cap = bytes available there.  lit_buf: literal scratch — the host model
+// decodes a block's Huffman literals right here into lit_buf (kMaxBlock + 32 bytes, lit_stride 0); on the device they come
+// from the literal wavefront through lit_buf + (hblock & 1) * lit_stride.  hblock: Huffman-coded blocks of the partition so
+// far (runs on over the partition's frames; both sides count alike).
+ZS_HD int decode_frame(Work& w, LitPipe& lp, const uint8_t* src, int64_t size, uint8_t* dst, int64_t cap, bool execute,
+                       uint8_t* lit_buf, int64_t lit_stride, int32_t& hblock, Lanes L, FrameOut* out) {
+  FrameHdr fh;
+  {
+    const int rc = frame_header(src, size, &fh);
+    if (rc != ZS_OK) return rc;
+  }
+  if (fh.skippable) {
+    out->consumed = fh.bytes;
+    out->produced = 0;
+    out->lit_need = 0;
+    return ZS_OK;
+  }
+  int64_t ip = fh.bytes;
+  const int64_t fcs = fh.fcs;
+  const int has_check = fh.has_check;
+
+  uint32_t rep0 = 1, rep1 = 4, rep2 = 8;
   int64_t lit_need = 0;
-  w.have_huf = w.have_ll = w.have_ml = w.have_of = 0;
+#ifndef S3S_ZSTD_DEVICE
+  lp.h.have_huf = 0;
+#endif
+  w.have_ll = w.have_ml = w.have_of = 0;
   w.vals_ll = w.vals_ml = 0;
   int64_t op = 0;          // bytes produced in this frame
   int64_t visible = 0;     // bytes of this frame's output every lane may read (fence issued behind them)
@@ -599,88 +744,32 @@ ZS_HD int decode_frame(Work& w, const uint8_t* src, int64_t size, uint8_t* dst, 
       const uint8_t* b = src + ip;
       const uint8_t* const bend = b + bsize;
       // ---- literals section ----
-      const int ltype = b[0] & 3, sf = (b[0] >> 2) & 3;
-      int64_t regen = 0, lcomp = 0;
-      int lh, streams = 1;
+      LitHdr lh;
+      {
+        const int rc = literals_header(b, bsize, &lh);
+        if (rc != ZS_OK) return rc;
+      }
+      const int64_t regen = lh.regen;
       const uint8_t* lit = nullptr;   // where the regenerated literals are (raw: inside src)
       int lit_rle = -1;
-      if (ltype < 2) {  // raw / RLE
-        if (sf == 0 || sf == 2) { lh = 1; regen = b[0] >> 3; }
-        else if (sf == 1) { lh = 2; if (bsize < 2) return ZS_FAIL(); regen = (b[0] >> 4) + ((int64_t)b[1] << 4); }
-        else { lh = 3; if (bsize < 3) return ZS_FAIL(); regen = (b[0] >> 4) + ((int64_t)b[1] << 4) + ((int64_t)b[2] << 12); }
-        if (regen > kMaxBlock) return ZS_FAIL();
-        if (ltype == 0) {
-          if (lh + regen > bsize) return ZS_FAIL();
-          lit = b + lh;
-          b += lh + regen;
-        } else {
-          if (lh + 1 > bsize) return ZS_FAIL();
-          lit_rle = b[lh];
-          b += lh + 1;
-        }
+      const bool huf_block = lh.ltype >= 2;
+      if (lh.ltype == 0) {
+        lit = b + lh.lh;
+        b += lh.lh + regen;
+      } else if (lh.ltype == 1) {
+        lit_rle = b[lh.lh];
+        b += lh.lh + 1;
       } else {  // Huffman-compressed (2) / treeless (3)
-        if (sf == 0 || sf == 1) {
-          lh = 3; if (bsize < 3) return ZS_FAIL();
-          const uint32_t v = rd_le(b, 3);
-          regen = (v >> 4) & 0x3FF; lcomp = v >> 14;
-          streams = sf == 0 ? 1 : 4;
-        } else if (sf == 2) {
-          lh = 4; if (bsize < 4) return ZS_FAIL();
-          const uint32_t v = rd_le(b, 4);
-          regen = (v >> 4) & 0x3FFF; lcomp = v >> 18;
-          streams = 4;
-        } else {
-          lh = 5; if (bsize < 5) return ZS_FAIL();
-          const uint64_t v = (uint64_t)rd_le(b, 4) | ((uint64_t)b[4] << 32);
-          regen = (int64_t)((v >> 4) & 0x3FFFF); lcomp = (int64_t)(v >> 22);
-          streams = 4;
-        }
-        if (regen > kMaxBlock || lh + lcomp > bsize) return ZS_FAIL();
         lit_need = regen > lit_need ? regen : lit_need;
-        const uint8_t* hp = b + lh;
-        int64_t hleft = lcomp;
-        if (ltype == 2) {
-          const int used = read_huf_table(w, hp, hleft);
-          if (used < 0) return used;
-          hp += used;
-          hleft -= used;
-        } else if (!w.have_huf) {
-          return ZS_FAIL();
-        }
+        uint8_t* lb = lit_buf + (hblock & 1) * lit_stride;
+#ifndef S3S_ZSTD_DEVICE
         if (execute) {
-          int rc = ZS_OK;
-          if (streams == 1) {
-            if (L.lane == 0) rc = huf_decode_stream(w, hp, hleft, lit_buf, regen);
-          } else {
-            if (hleft < 6) return ZS_FAIL();
-            const int64_t s1 = rd_le(hp, 2), s2 = rd_le(hp + 2, 2), s3 = rd_le(hp + 4, 2);
-            const int64_t s4 = hleft - 6 - s1 - s2 - s3;
-            if (s4 < 0) return ZS_FAIL();
-            const int64_t q = (regen + 3) / 4;
-            const int64_t n4 = regen - 3 * q;
-            if (n4 < 0) return ZS_FAIL();
-            const uint8_t* sp = hp + 6;
-            // stream k -> lane k (device); the host walks them one after the other
-            for (int k = 0; k < 4; k++) {
-              const int64_t sz = k == 0 ? s1 : k == 1 ? s2 : k == 2 ? s3 : s4;
-              const int64_t off = k == 0 ? 0 : k == 1 ? s1 : k == 2 ? s1 + s2 : s1 + s2 + s3;
-              if (L.lane == k % L.n) {
-                const int r1 = huf_decode_stream(w, sp + off, sz, lit_buf + k * q, k == 3 ? n4 : q);
-                if (r1 != ZS_OK) rc = r1;
-              }
-            }
-          }
-#ifdef S3S_ZSTD_DEVICE
-          {  // the first failing lane's code, to every lane
-            const unsigned long long bad = __ballot(rc != ZS_OK);
-            if (bad) rc = __shfl(rc, __builtin_ctzll(bad));
-          }
-#endif
+          const int rc = block_literals(lp.h, lh, b + lh.lh, lh.lcomp, lb, L);
           if (rc != ZS_OK) return rc;
-          ZS_FENCE();  // the literals were written by lanes 0..3: everybody reads them below
         }
-        lit = lit_buf;
-        b += lh + lcomp;
+#endif
+        lit = lb;
+        b += lh.lh + lh.lcomp;
       }
       // ---- sequences section ----
       if (b >= bend) return ZS_FAIL();
@@ -749,8 +838,15 @@ ZS_HD int decode_frame(Work& w, const uint8_t* src, int64_t size, uint8_t* dst, 
           }
         w.vals_ll = w.vals_ml = 1;
 #ifdef S3S_ZSTD_DEVICE
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (lane-strided LDS fills above, read by every lane below)
-        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (lane-strided LDS fills above, read by every lane below: one
+                                                                // wavefront, its LDS accesses complete in order - no s_barrier, the
+                                                                // workgroup's other wavefront is the literal side and never comes)
+#endif
+#ifdef S3S_ZSTD_DEVICE
+        if (execute && huf_block) {  // the literal wavefront's hand-over, as late as possible: the tables above did not need it
+          const int rc = pipe_wait_ready(lp, hblock + 1);
+          if (rc != ZS_OK) return rc;
+        }
 #endif
         BitR r;
         if (!bitr_init(r, b, bend - b)) return ZS_FAIL();
@@ -821,23 +917,24 @@ ZS_HD int decode_frame(Work& w, const uint8_t* src, int64_t size, uint8_t* dst, 
           // whatever the container held.  Valid streams never get here, and damaged ones were stopped by the partition's
           // Adler32 / CRC32 before the decoder saw them.
           if (r.pos < 0) return ZS_FAIL();
-          // offset with the repeat history
+          // offset with the repeat history (three scalars on purpose: an array indexed by the repeat code lives in scratch
+          // memory on the device - a store and a load round trip on every sequence's critical path)
           uint64_t offset;
           if (oval > 3) {
             offset = oval - 3;
-            rep[2] = rep[1];
-            rep[1] = rep[0];
-            rep[0] = (uint32_t)offset;
+            rep2 = rep1;
+            rep1 = rep0;
+            rep0 = (uint32_t)offset;
           } else {
-            uint32_t idx = (uint32_t)oval - 1 + (llen == 0 ? 1u : 0u);  // 0..3
+            const uint32_t idx = (uint32_t)oval - 1 + (llen == 0 ? 1u : 0u);  // 0..3
             if (idx == 0) {
-              offset = rep[0];
+              offset = rep0;
             } else {
-              const uint32_t v = idx == 3 ? rep[0] - 1 : rep[idx];
+              const uint32_t v = idx == 1 ? rep1 : idx == 2 ? rep2 : rep0 - 1;
               if (v == 0) return ZS_FAIL();
-              if (idx != 1) rep[2] = rep[1];
-              rep[1] = rep[0];
-              rep[0] = v;
+              if (idx != 1) rep2 = rep1;
+              rep1 = rep0;
+              rep0 = v;
               offset = v;
             }
           }
@@ -868,8 +965,14 @@ ZS_HD int decode_frame(Work& w, const uint8_t* src, int64_t size, uint8_t* dst, 
           if (op - bop > kMaxBlock) return ZS_FAIL();
         }
         if (r.pos != 0) return ZS_FAIL();  // the sequence stream must be consumed exactly
-      } else if (b != bend) {
-        return ZS_FAIL();
+      } else {
+        if (b != bend) return ZS_FAIL();
+#ifdef S3S_ZSTD_DEVICE
+        if (execute && huf_block) {  // (a block of literals only)
+          const int rc = pipe_wait_ready(lp, hblock + 1);
+          if (rc != ZS_OK) return rc;
+        }
+#endif
       }
       // literals behind the last sequence
       const int64_t rest = regen - lit_pos;
@@ -883,8 +986,14 @@ ZS_HD int decode_frame(Work& w, const uint8_t* src, int64_t size, uint8_t* dst, 
       op += rest;
       if (op - bop > kMaxBlock) return ZS_FAIL();
       ip += bsize;
-      if (execute) ZS_FENCE();  // lit_buf is rewritten by the next block; its readers must be done
+      if (huf_block) {
+        hblock++;
+#ifdef S3S_ZSTD_DEVICE
+        if (execute) pipe_set(&lp.consumed, hblock, L);  // (a release: this block's reads of its literal buffer are done)
+#endif
+      }
       visible = execute ? op : 0;
+      if (execute) ZS_FENCE();
     }
     if (last) break;
   }
@@ -901,12 +1010,14 @@ ZS_HD int decode_frame(Work& w, const uint8_t* src, int64_t size, uint8_t* dst, 
 }
 
 // All frames of one partition (concatenated streams of a multi-spill map task).  *total = decoded bytes.
-ZS_HD int decode_partition(Work& w, const uint8_t* src, int64_t size, uint8_t* dst, int64_t cap, bool execute, uint8_t* lit_buf,
-                           Lanes L, int64_t* total, int64_t* lit_need = nullptr) {
+ZS_HD int decode_partition(Work& w, LitPipe& lp, const uint8_t* src, int64_t size, uint8_t* dst, int64_t cap, bool execute,
+                           uint8_t* lit_buf, int64_t lit_stride, Lanes L, int64_t* total, int64_t* lit_need = nullptr) {
   int64_t ip = 0, op = 0, need = 0;
+  int32_t hblock = 0;
   while (ip < size) {
     FrameOut fo;
-    const int rc = decode_frame(w, src + ip, size - ip, execute ? dst + op : dst, execute ? cap - op : 0, execute, lit_buf, L, &fo);
+    const int rc = decode_frame(w, lp, src + ip, size - ip, execute ? dst + op : dst, execute ? cap - op : 0, execute, lit_buf,
+                                lit_stride, hblock, L, &fo);
     if (rc != ZS_OK) return rc;
     ip += fo.consumed;
     op += fo.produced;
@@ -916,5 +1027,98 @@ ZS_HD int decode_partition(Work& w, const uint8_t* src, int64_t size, uint8_t* d
   if (lit_need) *lit_need = need;
   return ZS_OK;
 }
+
+#ifdef S3S_ZSTD_DEVICE
+// ---- the literal wavefront (device) ------------------------------------------------------------------------------------------
+// It walks the same frame and block headers as decode_partition, for each partition it serves, and regenerates the
+// Huffman-coded literals of block k into buffer k & 1, one block ahead of that partition's sequence wavefront.  A malformed
+// header simply ends a walk (the sequence side meets the same header and reports it); a bad table or stream is handed over
+// through `err`.  Every way out of a walk other than the end of the partition sets `err`, so nobody is left waiting.
+struct LitWalker {
+  const uint8_t* src;
+  int64_t size, ip;
+  uint8_t* lit_buf;
+  int64_t lit_stride;
+  int32_t hblock;
+  int in_frame, has_check;
+  int done;          // nothing more to do for this partition
+  int have;          // a Huffman block is waiting for its buffer: lh / hp describe it
+  LitHdr lh;
+  const uint8_t* hp;
+  int64_t bsize;
+};
+// to the next Huffman-coded literals section (have = 1) or the end of the partition (done = 1)
+ZS_HD void walker_advance(LitWalker& k, LitPipe& lp, Lanes L) {
+  for (;;) {
+    if (!k.in_frame) {
+      if (k.ip >= k.size) { k.done = 1; return; }
+      FrameHdr fh;
+      if (frame_header(k.src + k.ip, k.size - k.ip, &fh) != ZS_OK) break;
+      k.ip += fh.bytes;
+      if (fh.skippable) continue;
+      lp.h.have_huf = 0;
+      k.in_frame = 1;
+      k.has_check = fh.has_check;
+    }
+    if (k.ip + 3 > k.size) break;
+    const uint32_t bh = rd_le(k.src + k.ip, 3);
+    k.ip += 3;
+    const int last = (int)(bh & 1), type = (int)((bh >> 1) & 3);
+    const int64_t bsize = bh >> 3;
+    if (type == 3 || bsize > kMaxBlock) break;
+    if (last) {  // (what follows this block is the frame's end)
+      k.in_frame = 0;
+    }
+    if (type == 1) {
+      k.ip += 1;
+    } else {
+      if (k.ip + bsize > k.size) break;
+      if (type == 2) {
+        if (bsize < 2) break;
+        if (literals_header(k.src + k.ip, bsize, &k.lh) != ZS_OK) break;
+        if (k.lh.ltype >= 2) {
+          k.hp = k.src + k.ip + k.lh.lh;
+          k.have = 1;
+        }
+      }
+      k.ip += bsize;
+    }
+    if (last && k.has_check) k.ip += 4;
+    if (k.have) return;
+  }
+  pipe_set(&lp.err, ZS_BAD, L);
+  k.done = 1;
+}
+// n_parts (1 or 2) partitions of the workgroup: whichever has a block to regenerate and a free buffer goes next
+ZS_HD void literal_side(LitPipe* lps, LitWalker* ks, int n_parts, Lanes L) {
+  for (;;) {
+    bool any = false, progressed = false;
+    for (int t = 0; t < n_parts; t++) {
+      LitWalker& k = ks[t];
+      LitPipe& lp = lps[t];
+      if (k.done) continue;
+      if (!k.have) {
+        walker_advance(k, lp, L);
+        if (k.done) continue;
+      }
+      any = true;
+      if (pipe_get(&lp.quit)) { k.done = 1; continue; }            // its sequence side has left
+      if (pipe_get(&lp.consumed) < k.hblock - 1) continue;         // buffer hblock & 1 still holds block hblock - 2
+      const int rc = block_literals(lp.h, k.lh, k.hp, k.lh.lcomp, k.lit_buf + (k.hblock & 1) * k.lit_stride, L);
+      if (rc != ZS_OK) {
+        pipe_set(&lp.err, rc, L);
+        k.done = 1;
+        continue;
+      }
+      k.hblock++;
+      k.have = 0;
+      pipe_set(&lp.ready, k.hblock, L);
+      progressed = true;
+    }
+    if (!any) return;
+    if (!progressed) __builtin_amdgcn_s_sleep(8);
+  }
+}
+#endif
 
 }  // namespace s3s_zstd

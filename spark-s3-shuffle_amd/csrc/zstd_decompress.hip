@@ -1,7 +1,8 @@
 // zstd_decompress.hip — reduce side for spark.io.compression.codec=zstd: verify + decode the Zstandard
 // frames of fetched block ranges.  The decoder itself is zstd_decode_core.h (shared with its host model); this file
 // is the kernel around it and the orchestration behind s3s_decompress_range* / s3s_decompressed_size for
-// S3S_CODEC_ZSTD.  One wavefront per partition, two passes over the compressed bytes:
+// S3S_CODEC_ZSTD.  One sequence wavefront per partition plus a literal wavefront per two partitions (see the kernel), one pass
+// at guessed capacities (zstd_decompress_ranges) or, when a partition outgrows its guess, two passes over the compressed bytes:
 //   pass 1  sizes: headers, table descriptions and the sequence streams are decoded, nothing is written — a Spark
 //           writer's frames carry no content size (streaming API), and the partitions must land back to back in dst;
 //   pass 2  decode into dst + the partition's offset, Huffman literals through a per-partition scratch buffer sized
@@ -21,7 +22,8 @@ struct ZPart {       // one partition of one range
   int64_t size;
   uint8_t* dst;      // pass 2: where its decoded bytes go
   int64_t cap;       // pass 2: bytes available there
-  int64_t lit_off;   // pass 2: offset of its literals scratch
+  int64_t lit_off;   // pass 2: offset of its literals scratch: two buffers lit_stride apart (block k uses buffer k & 1)
+  int64_t lit_stride;
 };
 struct ZRes {
   int64_t total;     // decoded bytes
@@ -30,19 +32,56 @@ struct ZRes {
   int32_t pad;
 };
 
-__global__ __launch_bounds__(kWave) void zstd_partitions_kernel(const ZPart* __restrict__ parts, int32_t n, int execute,
-                                                               uint8_t* __restrict__ lit_base, ZRes* __restrict__ res) {
-  __shared__ s3s_zstd::Work w;
-  const int p = blockIdx.x;
+// Three wavefronts per workgroup, two partitions (round 4).  Wavefronts 0 and 1 are the SEQUENCE sides of partitions 2b and
+// 2b + 1: headers, FSE tables, the sequence loop and its copies.  Wavefront 2 is the LITERAL side of both: it walks the same
+// headers and regenerates the Huffman-coded literals of a partition's NEXT block while its sequence wavefront executes this
+// one (a level-1 TeraSort frame spent 8.5 of its 38 ms in Huffman streams on 4 of 64 lanes, and the rest never needed those
+// lanes' results before the next block; one literal wavefront keeps up with two sequence sides).  They meet through four
+// counters in LDS per partition (s3s_zstd::LitPipe) and two literal buffers per partition.  Registers: the sequence side
+// needs 186 VGPRs when left alone; three wavefronts per SIMD (12 per CU = 4 workgroups = 8 partitions in flight, what the
+// one-wavefront-per-partition kernel had) leave it 168.
+constexpr int kZstdThreads = 3 * kWave;
+__global__ __launch_bounds__(kZstdThreads, 3) void zstd_partitions_kernel(const ZPart* __restrict__ parts, int32_t n, int execute,
+                                                                         uint8_t* __restrict__ lit_base, ZRes* __restrict__ res) {
+  __shared__ s3s_zstd::Work w[2];
+  __shared__ s3s_zstd::LitPipe lp[2];
+  __shared__ s3s_zstd::LitWalker ks[2];  // (the literal wavefront's own state: indexed by partition, so not in registers)
+  const int p0 = 2 * (int)blockIdx.x;
+  if (p0 >= n) return;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  s3s_zstd::Lanes L{(int)(threadIdx.x & (kWave - 1)), kWave};
+  if (threadIdx.x < 2) lp[threadIdx.x].ready = lp[threadIdx.x].consumed = lp[threadIdx.x].err = lp[threadIdx.x].quit = 0;
+  __syncthreads();
+  if (wave == 2) {
+    if (execute == 0) return;
+#ifdef ZS_T_NO_LIT
+    return;
+#endif
+    const int np = n - p0 < 2 ? n - p0 : 2;
+    for (int t = 0; t < np; t++) {
+      const ZPart zp = parts[p0 + t];
+      ks[t].src = zp.src;
+      ks[t].size = zp.size;
+      ks[t].ip = 0;
+      ks[t].lit_buf = lit_base ? lit_base + zp.lit_off : nullptr;
+      ks[t].lit_stride = zp.lit_stride;
+      ks[t].hblock = 0;
+      ks[t].in_frame = ks[t].has_check = ks[t].have = 0;
+      ks[t].done = zp.size > 0 ? 0 : 1;
+    }
+    s3s_zstd::literal_side(lp, ks, np, L);
+    return;
+  }
+  const int p = p0 + wave;
   if (p >= n) return;
   const ZPart zp = parts[p];
-  s3s_zstd::Lanes L{(int)threadIdx.x, kWave};
   int64_t total = 0, need = 0;
   int rc = s3s_zstd::ZS_OK;
   if (zp.size > 0)
-    rc = s3s_zstd::decode_partition(w, zp.src, zp.size, zp.dst, zp.cap, execute != 0, lit_base ? lit_base + zp.lit_off : nullptr,
-                                    L, &total, &need);
-  if (threadIdx.x == 0) {
+    rc = s3s_zstd::decode_partition(w[wave], lp[wave], zp.src, zp.size, zp.dst, zp.cap, execute != 0,
+                                    lit_base ? lit_base + zp.lit_off : nullptr, zp.lit_stride, L, &total, &need);
+  s3s_zstd::pipe_set(&lp[wave].quit, 1, L);  // (a literal side still waiting for a buffer leaves)
+  if (L.lane == 0) {
     ZRes r;
     r.total = total;
     r.lit_need = need;
@@ -194,8 +233,9 @@ int zstd_decompress_ranges(s3s_ctx* ctx, int checksum_algo, s3s_fetch_range* R, 
           z.cap = z.size > 0 ? (int64_t)kGuess * z.size + 4096 : 0;
           z.dst = reinterpret_cast<uint8_t*>((uintptr_t)scr_total);  // (offset for now: the buffer may still move)
           z.lit_off = lit_total1;
+          z.lit_stride = s3s_zstd::kMaxBlock + 64;  // the largest regenerated literals section a block can have
           scr_total += (z.cap + 255) & ~int64_t(255);
-          if (z.size > 0) lit_total1 += s3s_zstd::kMaxBlock + 64;  // the largest regenerated literals section a block can have
+          if (z.size > 0) lit_total1 += 2 * z.lit_stride;
         }
     }
     if ((rc = ensure(ctx, B_ZSCRATCH, (size_t)scr_total + 256))) return rc;
@@ -205,7 +245,7 @@ int zstd_decompress_ranges(s3s_ctx* ctx, int checksum_algo, s3s_fetch_range* R, 
     uint8_t* scr = dev<uint8_t>(ctx, B_ZSCRATCH);
     for (int32_t q = 0; q < n_parts; q++) h_parts[q].dst = scr + (uintptr_t)h_parts[q].dst;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_RANGES].p, h_parts, sizeof(ZPart) * (size_t)n_parts, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(zstd_partitions_kernel, dim3((unsigned)n_parts), dim3(kWave), 0, ctx->stream, dev<ZPart>(ctx, B_RANGES),
+    hipLaunchKernelGGL(zstd_partitions_kernel, dim3((unsigned)((n_parts + 1) / 2)), dim3(kZstdThreads), 0, ctx->stream, dev<ZPart>(ctx, B_RANGES),
                        n_parts, 1, dev<uint8_t>(ctx, B_SLOTS), dev<ZRes>(ctx, B_FRAMES));
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(h_res, ctx->buf[B_FRAMES].p, sizeof(ZRes) * (size_t)n_parts, hipMemcpyDeviceToHost, ctx->stream));
@@ -302,12 +342,13 @@ int zstd_decompress_ranges(s3s_ctx* ctx, int checksum_algo, s3s_fetch_range* R, 
         z.dst = nullptr;
         z.cap = 0;
         z.lit_off = 0;
+        z.lit_stride = 0;
       }
   }
   if ((rc = ensure(ctx, B_RANGES, sizeof(ZPart) * (size_t)n_parts))) return rc;
   if ((rc = ensure(ctx, B_FRAMES, sizeof(ZRes) * (size_t)n_parts))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_RANGES].p, h_parts, sizeof(ZPart) * (size_t)n_parts, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(zstd_partitions_kernel, dim3((unsigned)n_parts), dim3(kWave), 0, ctx->stream, dev<ZPart>(ctx, B_RANGES),
+  hipLaunchKernelGGL(zstd_partitions_kernel, dim3((unsigned)((n_parts + 1) / 2)), dim3(kZstdThreads), 0, ctx->stream, dev<ZPart>(ctx, B_RANGES),
                      n_parts, 0, (uint8_t*)nullptr, dev<ZRes>(ctx, B_FRAMES));
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(h_res, ctx->buf[B_FRAMES].p, sizeof(ZRes) * (size_t)n_parts, hipMemcpyDeviceToHost, ctx->stream));
@@ -333,8 +374,9 @@ int zstd_decompress_ranges(s3s_ctx* ctx, int checksum_algo, s3s_fetch_range* R, 
         h_parts[pp].dst = k.d_dst ? k.d_dst + total : nullptr;
         h_parts[pp].cap = h_res[pp].total;
         h_parts[pp].lit_off = lit_total;
+        h_parts[pp].lit_stride = (h_res[pp].lit_need + 64 + 15) & ~int64_t(15);
         total += h_res[pp].total;
-        lit_total += (h_res[pp].lit_need + 64 + 15) & ~int64_t(15);
+        lit_total += 2 * h_parts[pp].lit_stride;
       }
       if (k.status == S3S_OK) {
         k.out_len = total;
@@ -357,7 +399,7 @@ int zstd_decompress_ranges(s3s_ctx* ctx, int checksum_algo, s3s_fetch_range* R, 
   // ---- pass 2: decode ------------------------------------------------------------------------------------------------------
   if ((rc = ensure(ctx, B_SLOTS, (size_t)lit_total + 64))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_RANGES].p, h_parts, sizeof(ZPart) * (size_t)n_parts, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(zstd_partitions_kernel, dim3((unsigned)n_parts), dim3(kWave), 0, ctx->stream, dev<ZPart>(ctx, B_RANGES),
+  hipLaunchKernelGGL(zstd_partitions_kernel, dim3((unsigned)((n_parts + 1) / 2)), dim3(kZstdThreads), 0, ctx->stream, dev<ZPart>(ctx, B_RANGES),
                      n_parts, 1, dev<uint8_t>(ctx, B_SLOTS), dev<ZRes>(ctx, B_FRAMES));
   HIP_TRY(ctx, hipGetLastError());
   record(ctx, 3);

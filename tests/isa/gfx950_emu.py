@@ -1282,10 +1282,17 @@ class Program:
 
     x_s_waitcnt = x_s_nop
     def x_s_barrier(self, w, i):
-        if getattr(w, "multi_wave_group", False):
+        g = getattr(w, "group", None)
+        if g is not None:
+            g.barrier(w.wave_in_group)
+        elif getattr(w, "multi_wave_group", False):
             raise EmuError("s_barrier in a multi-wavefront workgroup: the interpreter runs its wavefronts one after the other")
 
-    x_s_sleep = x_s_nop
+    def x_s_sleep(self, w, i):
+        g = getattr(w, "group", None)
+        if g is not None:  # a wavefront that polls for another one's progress lets the others run
+            g.sleep(w.wave_in_group)
+
     x_s_setprio = x_s_nop
     x_s_waitcnt_vscnt = x_s_nop
     x_s_waitcnt_depctr = x_s_nop
@@ -1807,8 +1814,98 @@ def new_wave(mem, lds_bytes, lds_order=None):
     return w
 
 
+class _WaveGroup:
+    """The wavefronts of ONE workgroup that talk to each other (shared LDS, s_barrier, polling with s_sleep): each runs in its
+    own thread, exactly one at a time (a baton); the baton moves at s_barrier, at s_sleep and when a wavefront ends."""
+
+    def __init__(self, n):
+        import threading
+        self.n = n
+        self.cv = threading.Condition()
+        self.turn = 0
+        self.alive = [True] * n
+        self.waiting = [False] * n  # at the barrier
+        self.error = None
+        self.sleeps = 0
+
+    def _pass(self, me):  # (cv held) the next wavefront that can run; a barrier everybody alive has reached opens
+        if all(self.waiting[k] for k in range(self.n) if self.alive[k]):
+            self.waiting = [False] * self.n
+        for d in range(1, self.n + 1):
+            k = (me + d) % self.n
+            if self.alive[k] and not self.waiting[k]:
+                self.turn = k
+                self.cv.notify_all()
+                return
+        if any(self.alive):
+            self.error = EmuError("workgroup deadlock: every live wavefront waits at s_barrier")
+            self.cv.notify_all()
+
+    def _wait_turn(self, me):
+        while not (self.turn == me and not self.waiting[me]):
+            if self.error is not None:
+                raise self.error
+            self.cv.wait(0.5)
+        if self.error is not None:
+            raise self.error
+
+    def start(self, me):
+        with self.cv:
+            self._wait_turn(me)
+
+    def barrier(self, me):
+        with self.cv:
+            self.waiting[me] = True
+            self._pass(me)
+            self._wait_turn(me)
+
+    def sleep(self, me):
+        with self.cv:
+            self.sleeps += 1
+            if self.sleeps > 2_000_000:
+                self.error = EmuError("workgroup livelock: wavefronts keep polling")
+                self.cv.notify_all()
+                raise self.error
+            self._pass(me)
+            self._wait_turn(me)
+
+    def end(self, me, exc=None):
+        with self.cv:
+            self.alive[me] = False
+            if exc is not None and self.error is None:
+                self.error = exc
+                self.cv.notify_all()
+                return
+            self._pass(me)
+
+
+def _launch_group(prog, entry, waves, profile, hooks):
+    import threading
+    g = _WaveGroup(len(waves))
+
+    def body(k, w):
+        try:
+            g.start(k)
+            run_wave(prog, w, entry, profile=profile, hooks=hooks)
+        except BaseException as e:  # noqa: BLE001 - handed to the launching thread
+            g.end(k, e)
+            return
+        g.end(k)
+
+    for k, w in enumerate(waves):
+        w.group, w.wave_in_group = g, k
+        w.lds = waves[0].lds
+    threads = [threading.Thread(target=body, args=(k, w), daemon=True) for k, w in enumerate(waves)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if g.error is not None:
+        raise g.error
+
+
 def launch(prog, entry, mem, kernarg, grid_x, lds_bytes, user_sgprs=2, block_x=64, profile=None, lds_order=None,
-           on_wave=None, hooks=None, objects=None):
+           on_wave=None, hooks=None, objects=None, cooperative=False):
     """One 64-thread workgroup per block id (the kernels here use single-wave workgroups).  ABI as hipcc emits it
     for these kernels: s[0:1] = kernarg segment, s2 = workgroup id x, v0 = thread id x."""
     if block_x % 64 != 0:
@@ -1820,6 +1917,21 @@ def launch(prog, entry, mem, kernarg, grid_x, lds_bytes, user_sgprs=2, block_x=6
                for name, data in (objects or {}).items()}
     stats = []
     for bx in (grid_x if not isinstance(grid_x, int) else range(grid_x)):
+        if cooperative and block_x > 64:  # wavefronts that share LDS and wait for each other: run together (see _WaveGroup)
+            waves = []
+            for wv in range(block_x // 64):
+                w = new_wave(mem, lds_bytes, lds_order)
+                w.symbols = symbols
+                w.s[0], w.s[1] = kbase & M32, kbase >> 32
+                w.s[user_sgprs] = bx
+                w.v[0] = np.arange(64, dtype=np.uint32) + np.uint32(64 * wv)
+                waves.append(w)
+            _launch_group(prog, entry, waves, profile, hooks)
+            for w in waves:
+                stats.append(w)
+                if on_wave:
+                    on_wave(bx, w)
+            continue
         for wv in range(block_x // 64):
             w = new_wave(mem, lds_bytes, lds_order)
             w.symbols = symbols

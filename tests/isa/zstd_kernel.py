@@ -45,12 +45,13 @@ def decode_partitions(parts, profile=None):
     a_res = mem.map(zres, "res")
     objs = dict(emu.parse_objects(text))  # constant tables of the decoder (predefined FSE distributions, code tables)
 
-    def zparts(lit_offs, live=None, caps=None):
+    def zparts(lit_offs, live=None, caps=None, lit_strides=None):
         b = bytearray()
         co = do = 0
         for k, (p, sz) in enumerate(parts):
             on = live is None or live[k]
-            b += struct.pack("<QqQqq", a_comp + co, len(p) if on else 0, a_dst + do, sz if caps is None else caps[k], lit_offs[k])
+            b += struct.pack("<QqQqqq", a_comp + co, len(p) if on else 0, a_dst + do, sz if caps is None else caps[k], lit_offs[k],
+                             lit_strides[k] if lit_strides else 0)
             co += len(p)
             do += sz
         return np.frombuffer(bytes(b), dtype=np.uint8).copy()
@@ -59,24 +60,25 @@ def decode_partitions(parts, profile=None):
     zp = zparts([0] * n)
     a_parts = mem.map(zp, "parts1", writable=False)
     kernarg = struct.pack("<QiiQQ", a_parts, n, 0, 0, a_res)
-    emu.launch(prog, entry, mem, kernarg, n, lds, objects=objs)
+    emu.launch(prog, entry, mem, kernarg, (n + 1) // 2, lds, objects=objs, block_x=192, cooperative=True)
     res1 = [struct.unpack("<qqii", bytes(zres[24 * k:24 * k + 24])) for k in range(n)]
     # the host's verdicts between the passes (zstd_decompress_ranges): a partition whose size pass failed, or whose decoded
     # size exceeds its destination, takes no part in pass 2 (size 0); the others decode with cap = what the size pass found
     # and a literal scratch of what it asked for
-    lit_offs, lit_total = [], 0
+    lit_offs, lit_strides, lit_total = [], [], 0
     live = [rc == 0 and tot <= parts[k][1] for k, (tot, need, rc, _) in enumerate(res1)]
     for k, (tot, need, rc, _) in enumerate(res1):
         lit_offs.append(lit_total)
+        lit_strides.append((need + 64 + 15) & ~15)  # two literal buffers per partition: block k of the literal wavefront -> k & 1
         if live[k]:
-            lit_total += (need + 64 + 15) & ~15
+            lit_total += 2 * lit_strides[k]
     sizes_ok = [rc == 0 and tot == parts[k][1] for k, (tot, need, rc, _) in enumerate(res1)]
     lit = np.zeros(lit_total + 64, dtype=np.uint8)
     a_lit = mem.map(lit, "lit")
-    zp2 = zparts(lit_offs, live, [res1[k][0] if live[k] else 0 for k in range(n)])
+    zp2 = zparts(lit_offs, live, [res1[k][0] if live[k] else 0 for k in range(n)], lit_strides)
     a_parts2 = mem.map(zp2, "parts2", writable=False)
     kernarg = struct.pack("<QiiQQ", a_parts2, n, 1, a_lit, a_res)
-    waves = emu.launch(prog, entry, mem, kernarg, n, lds, profile=profile, objects=objs)
+    waves = emu.launch(prog, entry, mem, kernarg, (n + 1) // 2, lds, profile=profile, objects=objs, block_x=192, cooperative=True)
     out, rcs, do = [], [], 0
     for k, (p, sz) in enumerate(parts):
         tot, need, rc, _ = struct.unpack("<qqii", bytes(zres[24 * k:24 * k + 24]))

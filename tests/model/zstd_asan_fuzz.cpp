@@ -43,6 +43,7 @@ int main(int argc, char** argv) {
   const long max_mut = argc > 4 ? atol(argv[4]) : -1;
   auto R = [&](uint64_t n) { return n ? rng() % n : 0; };
   static Work w_size, w_dec;
+  static LitPipe lp_size, lp_dec;
   std::vector<uint8_t> lit(kMaxBlock + 64);
   long n_mut = 0, n_ok = 0, n_refused = 0, n_same = 0;
   const auto t0 = std::chrono::steady_clock::now();
@@ -70,9 +71,9 @@ int main(int argc, char** argv) {
     std::unique_ptr<uint8_t[]> dst(new uint8_t[cap ? cap : 1]);
     Lanes L{0, 1};
     int64_t total = -1, total2 = -1;
-    const int rc0 = decode_partition(w_size, comp.get(), (int64_t)m.size(), nullptr, 0, false, nullptr, L, &total);
+    const int rc0 = decode_partition(w_size, lp_size, comp.get(), (int64_t)m.size(), nullptr, 0, false, nullptr, 0, L, &total);
     if (rc0 != 0) { n_refused++; continue; }
-    const int rc = decode_partition(w_dec, comp.get(), (int64_t)m.size(), dst.get(), cap, true, lit.data(), L, &total2);
+    const int rc = decode_partition(w_dec, lp_dec, comp.get(), (int64_t)m.size(), dst.get(), cap, true, lit.data(), 0, L, &total2);
     if (rc != 0) { n_refused++; continue; }
     if (total2 != total || total2 > cap) { printf("size pass %lld, decode pass %lld, capacity %lld\n", (long long)total, (long long)total2, (long long)cap); return 1; }
     n_ok++;

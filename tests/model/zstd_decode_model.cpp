@@ -10,13 +10,15 @@ using namespace s3s_zstd;
 extern "C" {
 int zs_decoded_size(const uint8_t* src, int64_t size, int64_t* total) {
   static thread_local Work w;
+  static thread_local LitPipe lp;
   Lanes L{0, 1};
-  return decode_partition(w, src, size, nullptr, 0, false, nullptr, L, total);
+  return decode_partition(w, lp, src, size, nullptr, 0, false, nullptr, 0, L, total);
 }
 int zs_decode(const uint8_t* src, int64_t size, uint8_t* dst, int64_t cap, int64_t* total) {
   static thread_local Work w;
+  static thread_local LitPipe lp;  // (one thread does both sides, block by block)
   std::vector<uint8_t> lit(kMaxBlock + 64);
   Lanes L{0, 1};
-  return decode_partition(w, src, size, dst, cap, true, lit.data(), L, total);
+  return decode_partition(w, lp, src, size, dst, cap, true, lit.data(), 0, L, total);
 }
 }
