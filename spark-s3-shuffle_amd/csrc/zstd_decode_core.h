@@ -82,7 +82,6 @@ struct Work {
   // global memory (a global source would need the stores of the sequences before it to have completed: ~1 us each)
   uint8_t ring[kRing];
   uint8_t litw[kLitW];             // window over the block's literals, refilled 1 KiB at a time
-  int64_t litw_base;               // literal position of litw[0] (-1: nothing loaded)
 };
 
 struct Lanes {  // who am I in the wavefront (host: lane 0 of 1)
@@ -435,20 +434,17 @@ ZS_HD int huf_decode_stream(const HufWork& w, const uint8_t* p, int64_t size, ui
 }
 
 // ---- cooperative copies ---------------------------------------------------------------------------------------------------------
-// Every output byte goes to global memory AND into the ring.  out = the frame's output base, q = position in the frame.
-// (32-bit lane arithmetic on purpose: the runs are tens of bytes, 64-bit index math per lane was half of the decode pass)
-ZS_HD void put_plain(Work& w, uint8_t* out, int64_t q, const uint8_t* src, int64_t n64, Lanes L) {  // src: global, not the output
-  uint8_t* o = out + q;
-  const uint32_t rq = (uint32_t)q, n = (uint32_t)n64;  // (a block's output is at most 128 KiB)
+// Every output byte goes to global memory AND into the ring.  o = where byte 0 of the run goes, rq = its position in the frame
+// (32 bits of it: the ring index).  32-bit lane arithmetic on purpose: the runs are tens of bytes, 64-bit index math per lane
+// was half of the decode pass.
+ZS_HD void put_plain(Work& w, uint8_t* o, uint32_t rq, const uint8_t* src, uint32_t n, Lanes L) {  // src: global, not the output
   for (uint32_t i = (uint32_t)L.lane; i < n; i += (uint32_t)L.n) {
     const uint8_t v = src[i];
     w.ring[(rq + i) & (kRing - 1)] = v;
     o[i] = v;
   }
 }
-ZS_HD void put_fill(Work& w, uint8_t* out, int64_t q, uint8_t v, int64_t n64, Lanes L) {
-  uint8_t* o = out + q;
-  const uint32_t rq = (uint32_t)q, n = (uint32_t)n64;
+ZS_HD void put_fill(Work& w, uint8_t* o, uint32_t rq, uint8_t v, uint32_t n, Lanes L) {
   for (uint32_t i = (uint32_t)L.lane; i < n; i += (uint32_t)L.n) {
     w.ring[(rq + i) & (kRing - 1)] = v;
     o[i] = v;
@@ -456,40 +452,37 @@ ZS_HD void put_fill(Work& w, uint8_t* out, int64_t q, uint8_t v, int64_t n64, La
 }
 // literals [lp, lp + n) of the block: through the LDS window when the run fits it (one coalesced refill per 1 KiB of
 // literals instead of a global round trip per sequence)
-ZS_HD void put_literals(Work& w, uint8_t* out, int64_t q, const uint8_t* lit, int64_t lit_total, int64_t lp64, int64_t n64, Lanes L) {
-  if (n64 > kLitW) {
-    put_plain(w, out, q, lit + lp64, n64, L);
+// litw_base: literal position of litw[0] (-1: nothing loaded) - the caller's register, not LDS: it is read per sequence
+ZS_HD void put_literals(Work& w, uint8_t* o, uint32_t rq, const uint8_t* lit, uint32_t lit_total, uint32_t lp, uint32_t n, Lanes L,
+                        int32_t& litw_base) {
+  if (n > (uint32_t)kLitW) {
+    put_plain(w, o, rq, lit + lp, n, L);
     return;
   }
-  const int32_t lp = (int32_t)lp64, n = (int32_t)n64;
-  int32_t base = (int32_t)w.litw_base;
-  if (base < 0 || lp < base || lp + n > base + kLitW) {
-    const int32_t left = (int32_t)lit_total - lp;
+  int32_t base = litw_base;
+  if (base < 0 || (int32_t)lp < base || (int32_t)(lp + n) > base + kLitW) {
+    const int32_t left = (int32_t)(lit_total - lp);
     const int32_t m = left < kLitW ? left : kLitW;
     for (int32_t i = L.lane; i < m; i += L.n) w.litw[i] = lit[lp + i];
-    w.litw_base = lp;
-    base = lp;
+    litw_base = (int32_t)lp;
+    base = (int32_t)lp;
 #ifdef S3S_ZSTD_DEVICE
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 #endif
   }
-  uint8_t* o = out + q;
-  const uint32_t rq = (uint32_t)q;
-  const uint8_t* wsrc = w.litw + (lp - base);
-  for (uint32_t i = (uint32_t)L.lane; i < (uint32_t)n; i += (uint32_t)L.n) {
+  const uint8_t* wsrc = w.litw + ((int32_t)lp - base);
+  for (uint32_t i = (uint32_t)L.lane; i < n; i += (uint32_t)L.n) {
     const uint8_t v = wsrc[i];
     w.ring[(rq + i) & (kRing - 1)] = v;
     o[i] = v;
   }
 }
-// match: out[q + i] = out[q + i - offset], i in [0, n); with offset < n the source repeats with period `offset`, and every
+// match: o[i] = o[i - offset], i in [0, n); with offset < n the source repeats with period `offset`, and every
 // byte of the period was written BEFORE this copy started, so no lane depends on another lane's store.  near = the
 // source is still in the ring (offset + n <= kRing: this copy does not overwrite what it reads).
-ZS_HD void put_match(Work& w, uint8_t* out, int64_t q, int64_t offset64, int64_t n64, bool near, Lanes L) {
-  uint8_t* o = out + q;
-  const uint32_t rq = (uint32_t)q, n = (uint32_t)n64;
+ZS_HD void put_match(Work& w, uint8_t* o, uint32_t rq, uint32_t off, uint32_t n, bool near, Lanes L) {
   if (near) {
-    const uint32_t off = (uint32_t)offset64, rs = rq - off;
+    const uint32_t rs = rq - off;
     if (off >= n) {
       for (uint32_t i = (uint32_t)L.lane; i < n; i += (uint32_t)L.n) {
         const uint8_t v = w.ring[(rs + i) & (kRing - 1)];
@@ -511,15 +504,14 @@ ZS_HD void put_match(Work& w, uint8_t* out, int64_t q, int64_t offset64, int64_t
     }
     return;
   }
-  const uint8_t* pat = o - offset64;
-  if (offset64 >= n64) {
+  const uint8_t* pat = o - (int64_t)off;
+  if (off >= n) {
     for (uint32_t i = (uint32_t)L.lane; i < n; i += (uint32_t)L.n) {
       const uint8_t v = pat[i];
       w.ring[(rq + i) & (kRing - 1)] = v;
       o[i] = v;
     }
   } else {  // (offset + n > kRing and offset < n: a long run, rare)
-    const uint32_t off = (uint32_t)offset64;
     for (uint32_t i = (uint32_t)L.lane; i < n; i += (uint32_t)L.n) {
       const uint8_t v = pat[i % off];
       w.ring[(rq + i) & (kRing - 1)] = v;
@@ -673,9 +665,6 @@ ZS_HD void pipe_set(int32_t* p, int32_t v, Lanes L) {  // what this wavefront st
 }
 // sequence side: the literals of Huffman block number `want - 1` are in their buffer (or the literal side has failed)
 ZS_HD int pipe_wait_ready(LitPipe& lp, int32_t want) {
-#ifdef ZS_T_NOWAIT
-  return ZS_OK;
-#endif
   for (;;) {
     if (pipe_get(&lp.ready) >= want) return ZS_OK;
     const int32_t e = pipe_get(&lp.err);
@@ -727,7 +716,7 @@ ZS_HD int decode_frame(Work& w, LitPipe& lp, const uint8_t* src, int64_t size, u
       if (bsize > kMaxBlock || ip + bsize > size) return ZS_FAIL();
       if (execute) {
         if (op + bsize > cap) return ZS_CAPACITY;
-        put_plain(w, dst, op, src + ip, bsize, L);
+        put_plain(w, dst + op, (uint32_t)op, src + ip, (uint32_t)bsize, L);
       }
       ip += bsize;
       op += bsize;
@@ -735,7 +724,7 @@ ZS_HD int decode_frame(Work& w, LitPipe& lp, const uint8_t* src, int64_t size, u
       if (bsize > kMaxBlock || ip + 1 > size) return ZS_FAIL();
       if (execute) {
         if (op + bsize > cap) return ZS_CAPACITY;
-        put_fill(w, dst, op, src[ip], bsize, L);
+        put_fill(w, dst + op, (uint32_t)op, src[ip], (uint32_t)bsize, L);
       }
       ip += 1;
       op += bsize;
@@ -787,9 +776,15 @@ ZS_HD int decode_frame(Work& w, LitPipe& lp, const uint8_t* src, int64_t size, u
         nseq = (int64_t)b[1] + ((int64_t)b[2] << 8) + 0x7F00;
         b += 3;
       }
-      int64_t lit_pos = 0;
-      int64_t bop = op;  // output position at the start of the block
-      w.litw_base = -1;
+      // Inside a block everything is 32 bits and relative to the block (round 4: 64-bit positions per sequence were a tenth
+      // of the loop): bout = bytes this block has produced, lit_pos = literals it has used.
+      const int64_t bop = op;  // output position at the start of the block
+      uint8_t* const bdst = dst + bop;
+      const uint32_t rq0 = (uint32_t)bop;
+      const uint32_t regen32 = (uint32_t)regen;
+      const uint32_t bcap = !execute ? 0u : (cap - bop > 0x7fffffffll ? 0x7fffffffu : (uint32_t)(cap - bop));
+      uint32_t bout = 0, lit_pos = 0;
+      int32_t litw_base = -1;
       if (nseq > 0) {
         if (b >= bend) return ZS_FAIL();
         const int modes = b[0];
@@ -858,7 +853,7 @@ ZS_HD int decode_frame(Work& w, LitPipe& lp, const uint8_t* src, int64_t size, u
           const int co = (int)(eo >> 24);
           if (co > 31) return ZS_FAIL();
           uint32_t ov;
-          int64_t mlen, llen;
+          uint32_t mlen, llen;  // (at most 131 074 + 65 535 and 65 536 + 65 535)
           // (round 4, measured +8.5 % on TeraSort frames, profiles/r04a_first_call.txt) All fields of a sequence — offset, match-length and literal-length extra bits,
           // then the three state updates — from ONE window: a refill puts at least 57 bits below the cursor into the
           // cache, and a sequence of a level-1 stream needs far fewer; the six reads become shifts of one register.
@@ -885,8 +880,8 @@ ZS_HD int decode_frame(Work& w, LitPipe& lp, const uint8_t* src, int64_t size, u
               return (uint32_t)((bits >> rem) & ((1ull << n) - 1));
             };
             ov = take(co);
-            mlen = (int64_t)(vm & 0xFFFFFFu) + take(bm);
-            llen = (int64_t)(vl & 0xFFFFFFu) + take(bl);
+            mlen = (vm & 0xFFFFFFu) + take(bm);
+            llen = (vl & 0xFFFFFFu) + take(bl);
             if (more) {
               sl = (el & 0xFFFFu) + take(nl);
               sm = (em & 0xFFFFu) + take(nm);
@@ -902,8 +897,8 @@ ZS_HD int decode_frame(Work& w, LitPipe& lp, const uint8_t* src, int64_t size, u
           } else {
             ov = bitr_read(r, co);
           }
-          mlen = (int64_t)(vm & 0xFFFFFFu) + bitr_read(r, (int)(vm >> 24));
-          llen = (int64_t)(vl & 0xFFFFFFu) + bitr_read(r, (int)(vl >> 24));
+          mlen = (vm & 0xFFFFFFu) + bitr_read(r, (int)(vm >> 24));
+          llen = (vl & 0xFFFFFFu) + bitr_read(r, (int)(vl >> 24));
           if (i + 1 < nseq) {  // state updates: LL, ML, OF
             sl = (el & 0xFFFFu) + bitr_read(r, (int)((el >> 16) & 0xff));
             sm = (em & 0xFFFFu) + bitr_read(r, (int)((em >> 16) & 0xff));
@@ -919,12 +914,12 @@ ZS_HD int decode_frame(Work& w, LitPipe& lp, const uint8_t* src, int64_t size, u
           if (r.pos < 0) return ZS_FAIL();
           // offset with the repeat history (three scalars on purpose: an array indexed by the repeat code lives in scratch
           // memory on the device - a store and a load round trip on every sequence's critical path)
-          uint64_t offset;
+          uint32_t offset;  // (oval < 2^32: the offset code is at most 31)
           if (oval > 3) {
-            offset = oval - 3;
+            offset = (uint32_t)(oval - 3);
             rep2 = rep1;
             rep1 = rep0;
-            rep0 = (uint32_t)offset;
+            rep0 = offset;
           } else {
             const uint32_t idx = (uint32_t)oval - 1 + (llen == 0 ? 1u : 0u);  // 0..3
             if (idx == 0) {
@@ -938,31 +933,33 @@ ZS_HD int decode_frame(Work& w, LitPipe& lp, const uint8_t* src, int64_t size, u
               offset = v;
             }
           }
-          if (lit_pos + llen > regen) return ZS_FAIL();
-          if ((int64_t)offset > op + llen || offset == 0) return ZS_FAIL();  // (no dictionary: history starts with the frame)
+          if (lit_pos + llen > regen32) return ZS_FAIL();
+          const uint32_t reach = bout + llen;  // bytes of this block in front of the match
+          // (no dictionary: history starts with the frame)
+          if (offset == 0 || (offset > reach && (int64_t)(offset - reach) > bop)) return ZS_FAIL();
 #ifdef ZS_STATS_HOOK
-          ZS_STATS_HOOK((int64_t)offset, mlen, llen);
+          ZS_STATS_HOOK((int64_t)offset, (int64_t)mlen, (int64_t)llen);
 #endif
           if (execute) {
-            if (op + llen + mlen > cap) return ZS_CAPACITY;
+            if (reach + mlen > bcap) return ZS_CAPACITY;
             if (llen) {
-              if (lit_rle >= 0) put_fill(w, dst, op, (uint8_t)lit_rle, llen, L);
-              else put_literals(w, dst, op, lit, regen, lit_pos, llen, L);
+              if (lit_rle >= 0) put_fill(w, bdst + bout, rq0 + bout, (uint8_t)lit_rle, llen, L);
+              else put_literals(w, bdst + bout, rq0 + bout, lit, regen32, lit_pos, llen, L, litw_base);
             }
-            const bool near = (int64_t)offset + mlen <= kRing;
+            const bool near = offset <= (uint32_t)kRing && offset + mlen <= (uint32_t)kRing;
             if (!near) {  // a far source comes from global memory: what was stored since the last fence must have landed
-              const int64_t mstart = op + llen - (int64_t)offset;
-              const int64_t mend = (int64_t)offset >= mlen ? mstart + mlen : op + llen;
+              const int64_t mstart = bop + reach - (int64_t)offset;
+              const int64_t mend = offset >= mlen ? mstart + mlen : bop + reach;
               if (mend > visible) {
                 ZS_FENCE();
-                visible = op + llen;
+                visible = bop + reach;
               }
             }
-            put_match(w, dst, op + llen, (int64_t)offset, mlen, near, L);
+            put_match(w, bdst + reach, rq0 + reach, offset, mlen, near, L);
           }
           lit_pos += llen;
-          op += llen + mlen;
-          if (op - bop > kMaxBlock) return ZS_FAIL();
+          bout = reach + mlen;
+          if (bout > (uint32_t)kMaxBlock) return ZS_FAIL();
         }
         if (r.pos != 0) return ZS_FAIL();  // the sequence stream must be consumed exactly
       } else {
@@ -975,16 +972,17 @@ ZS_HD int decode_frame(Work& w, LitPipe& lp, const uint8_t* src, int64_t size, u
 #endif
       }
       // literals behind the last sequence
-      const int64_t rest = regen - lit_pos;
+      const uint32_t rest = regen32 - lit_pos;
       if (execute) {
-        if (op + rest > cap) return ZS_CAPACITY;
+        if (bout + rest > bcap) return ZS_CAPACITY;
         if (rest) {
-          if (lit_rle >= 0) put_fill(w, dst, op, (uint8_t)lit_rle, rest, L);
-          else put_literals(w, dst, op, lit, regen, lit_pos, rest, L);
+          if (lit_rle >= 0) put_fill(w, bdst + bout, rq0 + bout, (uint8_t)lit_rle, rest, L);
+          else put_literals(w, bdst + bout, rq0 + bout, lit, regen32, lit_pos, rest, L, litw_base);
         }
       }
-      op += rest;
-      if (op - bop > kMaxBlock) return ZS_FAIL();
+      bout += rest;
+      if (bout > (uint32_t)kMaxBlock) return ZS_FAIL();
+      op = bop + bout;
       ip += bsize;
       if (huf_block) {
         hblock++;

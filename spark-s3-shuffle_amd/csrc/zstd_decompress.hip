@@ -54,9 +54,6 @@ __global__ __launch_bounds__(kZstdThreads, 3) void zstd_partitions_kernel(const 
   __syncthreads();
   if (wave == 2) {
     if (execute == 0) return;
-#ifdef ZS_T_NO_LIT
-    return;
-#endif
     const int np = n - p0 < 2 ? n - p0 : 2;
     for (int t = 0; t < np; t++) {
       const ZPart zp = parts[p0 + t];
