@@ -686,7 +686,7 @@ def run_workload(args, rank: int, local_rank: int, world: int, dist):
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": ("zstd decode pass (one wavefront per partition frame, serial entropy stages)" if codec_name == "zstd" else
+                "kernel": ("zstd decode pass (a sequence wavefront per partition frame + a literal wavefront per two, serial entropy stages)" if codec_name == "zstd" else
                            "%s batch decoder (one wavefront per frame, one sequence per lane)" % codec_name if decompress
                            else "%s_compress (one wavefront per 32 KiB block)" % codec_name),
                 "achieved": round(achieved, 3),
