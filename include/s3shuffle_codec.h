@@ -66,14 +66,15 @@
 extern "C" {
 #endif
 
-#define S3S_ABI_VERSION 7 /* 2: + segments entry points, page-locked staging, tuning options 6, 7;
+#define S3S_ABI_VERSION 8 /* 2: + segments entry points, page-locked staging, tuning options 6, 7;
                              3: + s3s_compress_map_outputs_batch_device;
                              4: + s3s_decompress_ranges_batch_device; decode variants {3, 4}, LZ4 parses {1, 9, 10};
                              5: + s3s_compress_map_outputs_batch / s3s_decompress_ranges_batch (host buffers),
                                 S3S_CODEC_ZSTD on the reduce side;
                              6: S3S_STATUS_NOT_RUN in the per-entry status of the batched calls (a call-level failure is told
                                 apart from an entry's own verdict);
-                             7: + S3S_CODEC_LZF on the reduce side; LZ4Block frames above 32 KiB through the batch decoder */
+                             7: + S3S_CODEC_LZF on the reduce side; LZ4Block frames above 32 KiB through the batch decoder;
+                             8: + S3S_CHECKSUM_CRC32C */
 
 /* spark.io.compression.codec (only when spark.shuffle.compress=true) */
 enum { S3S_CODEC_NONE = 0, S3S_CODEC_LZ4 = 1, S3S_CODEC_SNAPPY = 2,
@@ -84,7 +85,8 @@ enum { S3S_CODEC_NONE = 0, S3S_CODEC_LZ4 = 1, S3S_CODEC_SNAPPY = 2,
                              ZStdCompressionCodec / zstd-jni write them, one per non-empty partition; the compress
                              entry points answer S3S_E_UNSUPPORTED (the codec stays on the JVM) */ };
 /* spark.shuffle.checksum.algorithm (NONE when spark.shuffle.checksum.enabled=false) */
-enum { S3S_CHECKSUM_NONE = 0, S3S_CHECKSUM_ADLER32 = 1, S3S_CHECKSUM_CRC32 = 2 };
+enum { S3S_CHECKSUM_NONE = 0, S3S_CHECKSUM_ADLER32 = 1, S3S_CHECKSUM_CRC32 = 2,
+       S3S_CHECKSUM_CRC32C = 3 /* ABI 8: java.util.zip.CRC32C (Castagnoli), Spark 4's third spark.shuffle.checksum.algorithm */ };
 
 enum {
   S3S_OK = 0,

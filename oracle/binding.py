@@ -17,7 +17,7 @@ _LIB = None
 
 CODEC_NONE, CODEC_LZ4, CODEC_SNAPPY = 0, 1, 2
 CODEC_LZF = 4  # the oracle writes LZF streams with its own greedy encoder (test data); the GPU path only decodes them
-CHECKSUM_NONE, CHECKSUM_ADLER32, CHECKSUM_CRC32 = 0, 1, 2
+CHECKSUM_NONE, CHECKSUM_ADLER32, CHECKSUM_CRC32, CHECKSUM_CRC32C = 0, 1, 2, 3
 E_INVALID, E_CAPACITY, E_BAD_FRAME, E_CHECKSUM, E_UNSUPPORTED = -1, -2, -3, -4, -6
 
 
@@ -88,6 +88,9 @@ def lib() -> ctypes.CDLL:
     L.s3o_mt_decode_libsnappy.argtypes = [vp, i64, vp, i64]
     L.s3o_crc32_fast.restype = u32
     L.s3o_crc32_fast.argtypes = [u32, vp, ctypes.c_size_t]
+    for f in (L.s3o_crc32c, L.s3o_crc32c_hw):
+        f.restype = u32
+        f.argtypes = [u32, vp, ctypes.c_size_t]
     L.s3o_adler32_fast.restype = u32
     L.s3o_adler32_fast.argtypes = [u32, vp, ctypes.c_size_t]
     L.s3o_checksum_fast.restype = i64
@@ -121,8 +124,18 @@ def checksum_fast(algo: int, data, init: Optional[int] = None) -> int:
     d = _u8(data)
     if init is None:
         return int(lib().s3o_checksum_fast(algo, d.ctypes.data, d.size))
-    f = lib().s3o_adler32_fast if algo == CHECKSUM_ADLER32 else lib().s3o_crc32_fast
+    f = {CHECKSUM_ADLER32: lib().s3o_adler32_fast, CHECKSUM_CRC32: lib().s3o_crc32_fast, CHECKSUM_CRC32C: lib().s3o_crc32c_hw}[algo]
     return int(f(init, d.ctypes.data, d.size))
+
+
+def crc32c(data, init: int = 0, hw: bool = False) -> int:
+    """java.util.zip.CRC32C restated (table form) or, hw=True, through the x86 crc32 instruction"""
+    d = _u8(data)
+    return int((lib().s3o_crc32c_hw if hw else lib().s3o_crc32c)(init, d.ctypes.data, d.size))
+
+
+def crc32c_hw_available() -> bool:
+    return bool(lib().s3o_crc32c_hw_available())
 
 
 def simd_crc_constants():

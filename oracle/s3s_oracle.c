@@ -128,6 +128,42 @@ uint32_t s3o_crc32(uint32_t crc, const void* data, size_t len) {
 }
 
 /* ------------------------------------------------------------------------------------ */
+/* [EXT] java.util.zip.CRC32C (Castagnoli, reflected 0x82F63B78: RFC 3720 B.4) — the     */
+/* third spark.shuffle.checksum.algorithm of Spark 4 (the reference's own                */
+/* createChecksumAlgorithm, S3ShuffleHelper.scala:94-103, knows ADLER32 and CRC32).      */
+/* Bitwise-table restatement; pinned against the RFC's vectors and the x86 crc32          */
+/* instruction (s3o_crc32c_hw, s3s_oracle_simd.c) by tests/test_oracle_pins.py.           */
+/* ------------------------------------------------------------------------------------ */
+static uint32_t crcc_tab[8][256];
+static int crcc_tab_ready = 0;
+static void crcc_init(void) {
+  for (uint32_t i = 0; i < 256; i++) {
+    uint32_t c = i;
+    for (int k = 0; k < 8; k++) c = (c & 1) ? (0x82F63B78u ^ (c >> 1)) : (c >> 1);
+    crcc_tab[0][i] = c;
+  }
+  for (uint32_t i = 0; i < 256; i++)
+    for (int t = 1; t < 8; t++)
+      crcc_tab[t][i] = (crcc_tab[t - 1][i] >> 8) ^ crcc_tab[0][crcc_tab[t - 1][i] & 0xFF];
+  crcc_tab_ready = 1;
+}
+uint32_t s3o_crc32c(uint32_t crc, const void* data, size_t len) {
+  if (!crcc_tab_ready) crcc_init();
+  const uint8_t* p = (const uint8_t*)data;
+  uint32_t c = ~crc;
+  while (len >= 8) {
+    uint32_t a = rd32le(p) ^ c, b = rd32le(p + 4);
+    c = crcc_tab[7][a & 0xFF] ^ crcc_tab[6][(a >> 8) & 0xFF] ^ crcc_tab[5][(a >> 16) & 0xFF] ^
+        crcc_tab[4][a >> 24] ^ crcc_tab[3][b & 0xFF] ^ crcc_tab[2][(b >> 8) & 0xFF] ^
+        crcc_tab[1][(b >> 16) & 0xFF] ^ crcc_tab[0][b >> 24];
+    p += 8;
+    len -= 8;
+  }
+  while (len--) c = crcc_tab[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+  return ~c;
+}
+
+/* ------------------------------------------------------------------------------------ */
 /* [EXT] java.util.zip.Adler32 (RFC 1950)                                               */
 /* ------------------------------------------------------------------------------------ */
 uint32_t s3o_adler32(uint32_t adler, const void* data, size_t len) {
@@ -152,6 +188,8 @@ int64_t s3o_checksum(int algo, const void* data, size_t len) {
       return (int64_t)s3o_adler32(1u, data, len);
     case S3O_CHECKSUM_CRC32:
       return (int64_t)s3o_crc32(0u, data, len);
+    case S3O_CHECKSUM_CRC32C:
+      return (int64_t)s3o_crc32c(0u, data, len);
     default:
       return 0;
   }

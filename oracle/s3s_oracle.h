@@ -45,7 +45,7 @@ extern "C" {
 /* codec / checksum selectors — same numeric values as include/s3shuffle_codec.h */
 enum { S3O_CODEC_NONE = 0, S3O_CODEC_LZ4 = 1, S3O_CODEC_SNAPPY = 2,
        S3O_CODEC_LZF = 4 /* reduce side only on the GPU; the oracle also WRITES such streams (test data, s3s_oracle_lzf.c) */ };
-enum { S3O_CHECKSUM_NONE = 0, S3O_CHECKSUM_ADLER32 = 1, S3O_CHECKSUM_CRC32 = 2 };
+enum { S3O_CHECKSUM_NONE = 0, S3O_CHECKSUM_ADLER32 = 1, S3O_CHECKSUM_CRC32 = 2, S3O_CHECKSUM_CRC32C = 3 };
 
 /* error codes — same numeric values as include/s3shuffle_codec.h */
 enum {
@@ -61,6 +61,9 @@ enum {
 uint32_t s3o_xxh32(const void* data, size_t len, uint32_t seed);
 /* zlib conventions: start value 0 for crc32, 1 for adler32; both incremental. */
 uint32_t s3o_crc32(uint32_t crc, const void* data, size_t len);
+uint32_t s3o_crc32c(uint32_t crc, const void* data, size_t len); /* java.util.zip.CRC32C */
+uint32_t s3o_crc32c_hw(uint32_t crc, const void* data, size_t len); /* the x86 crc32 instruction (SSE4.2), what HotSpot's intrinsic runs; 0xFFFFFFFF-free fallback: the table form */
+int s3o_crc32c_hw_available(void);
 uint32_t s3o_adler32(uint32_t adler, const void* data, size_t len);
 /* the value java.util.zip.{Adler32,CRC32}.getValue() would return over data[0,len) */
 int64_t s3o_checksum(int algo, const void* data, size_t len);

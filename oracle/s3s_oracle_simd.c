@@ -172,6 +172,7 @@ __attribute__((target("ssse3"))) static void adler32_blocks(uint32_t* pa, uint32
 static int cpu_has(const char* what) {
   __builtin_cpu_init();
   if (!strcmp(what, "pclmul")) return __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1");
+  if (!strcmp(what, "sse4.2")) return __builtin_cpu_supports("sse4.2");
   return __builtin_cpu_supports("ssse3");
 }
 #else
@@ -212,12 +213,46 @@ uint32_t s3o_adler32_fast(uint32_t adler, const void* data, size_t len) {
   return s3o_adler32(adler, data, len);
 }
 
+/* ---- CRC32C: the processor's own instruction (SSE4.2 crc32 r64, r/m64 computes exactly this polynomial) --------------- */
+#if defined(__x86_64__)
+__attribute__((target("sse4.2"))) static uint32_t crc32c_insn(uint32_t c, const uint8_t* p, size_t len) {
+  uint64_t c64 = c;
+  while (len >= 8) {
+    uint64_t v;
+    memcpy(&v, p, 8);
+    c64 = __builtin_ia32_crc32di(c64, v);
+    p += 8;
+    len -= 8;
+  }
+  c = (uint32_t)c64;
+  while (len--) c = __builtin_ia32_crc32qi(c, *p++);
+  return c;
+}
+#endif
+int s3o_crc32c_hw_available(void) {
+#if defined(__x86_64__)
+  static int ok = -1;
+  if (ok < 0) ok = cpu_has("sse4.2");
+  return ok;
+#else
+  return 0;
+#endif
+}
+uint32_t s3o_crc32c_hw(uint32_t crc, const void* data, size_t len) {
+#if defined(__x86_64__)
+  if (s3o_crc32c_hw_available()) return ~crc32c_insn(~crc, (const uint8_t*)data, len);
+#endif
+  return s3o_crc32c(crc, data, len);
+}
+
 int64_t s3o_checksum_fast(int algo, const void* data, size_t len) {
   switch (algo) {
     case S3O_CHECKSUM_ADLER32:
       return (int64_t)s3o_adler32_fast(1u, data, len);
     case S3O_CHECKSUM_CRC32:
       return (int64_t)s3o_crc32_fast(0u, data, len);
+    case S3O_CHECKSUM_CRC32C:
+      return (int64_t)s3o_crc32c_hw(0u, data, len);
     default:
       return 0;
   }

@@ -135,7 +135,7 @@ class S3GpuMapOutput(shuffleId: Int, mapId: Long, numPartitions: Int, createBloc
         val continues = i == n - 1 && !endOfPartition // more bytes of p follow this flush
         val piece = continues || (i == 0 && running != null) // p is written in more than one piece
         if (piece && running == null && algo != S3SCodec.CHECKSUM_NONE)
-          running = if (algo == S3SCodec.CHECKSUM_CRC32) new CRC32() else new Adler32()
+          running = S3GpuMapOutput.newChecksum(algo)
         if (len > 0) {
           if (stream == null) stream = createBlock()
           S3GpuBuffers.writeTo(stream, out, index(i), len, if (piece) running else null)
@@ -168,7 +168,7 @@ class S3GpuMapOutput(shuffleId: Int, mapId: Long, numPartitions: Int, createBloc
       val from = groupOffsets(i)
       val len = groupOffsets(i + 1) - from
       val sum: Checksum =
-        if (algo == S3SCodec.CHECKSUM_CRC32) new CRC32() else if (algo == S3SCodec.CHECKSUM_ADLER32) new Adler32() else null
+        S3GpuMapOutput.newChecksum(algo)
       if (len > 0) { // (an empty partition is 0 bytes in the object, like S3ShuffleMapOutputWriter's untouched partition writer)
         if (stream == null) stream = createBlock()
         val counted = new S3GpuBuffers.CountingStream(stream, sum) // (close() stops at it: the data block stays open)
@@ -211,6 +211,16 @@ class S3GpuMapOutput(shuffleId: Int, mapId: Long, numPartitions: Int, createBloc
 
 /** Process-wide cache of page-locked direct buffers (pinning pages costs ~100 ms per GiB: never per task).  Bounded:
   * what does not fit under spark.shuffle.s3.gpu.pinnedPoolBytes goes back to the driver (s3s_host_free). */
+object S3GpuMapOutput {
+  /** The JVM twin of the library's checksum (a partition written in more than one flush; the JVM-codec fallback). */
+  def newChecksum(algo: Int): Checksum = algo match {
+    case S3SCodec.CHECKSUM_ADLER32 => new Adler32()
+    case S3SCodec.CHECKSUM_CRC32 => new CRC32()
+    case S3SCodec.CHECKSUM_CRC32C => new java.util.zip.CRC32C() // (Java 9+; Spark 4 requires 17)
+    case _ => null
+  }
+}
+
 object S3GpuBuffers {
   val MaxBuffer: Long = 1L << 30 // one direct ByteBuffer: Int positions
   @volatile var lastMapOutputSize: Long = 8L << 20 // first guess = the reference's 8 MiB write buffer (S3ShuffleDispatcher.scala:55)

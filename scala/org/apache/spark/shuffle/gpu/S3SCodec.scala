@@ -25,11 +25,11 @@ object S3SCodec {
   val CODEC_NONE = 0; val CODEC_LZ4 = 1; val CODEC_SNAPPY = 2
   val CODEC_ZSTD = 3 // reduce side only (decompressRange*, decompressedSize): S3GpuBlockDecoder takes ranges of many small frames, INTEGRATION.md
   val CODEC_LZF = 4 // reduce side only: LZFCompressionCodec streams (compress-lzf chunks around liblzf blocks)
-  val CHECKSUM_NONE = 0; val CHECKSUM_ADLER32 = 1; val CHECKSUM_CRC32 = 2
+  val CHECKSUM_NONE = 0; val CHECKSUM_ADLER32 = 1; val CHECKSUM_CRC32 = 2; val CHECKSUM_CRC32C = 3
   val OK = 0; val E_INVALID = -1; val E_CAPACITY = -2; val E_BAD_FRAME = -3; val E_CHECKSUM = -4; val E_HIP = -5
   val STATUS_NOT_RUN = -100 // per-entry status of a batch call that failed before this entry had a verdict: the call's return code is its error
   val OPT_LZ4_BLOCK_SIZE = 1; val OPT_SNAPPY_BLOCK_SIZE = 2
-  val ABI_VERSION = 7
+  val ABI_VERSION = 8
 
   // ---- native entry points (jni/s3s_jni.c, one line each) -------------------------------------------------------
   @native def abiVersion(): Int
@@ -174,6 +174,9 @@ object S3SCodec {
     else algorithm.toUpperCase match {
       case "ADLER32" => CHECKSUM_ADLER32
       case "CRC32" => CHECKSUM_CRC32
+      // Spark 4's third algorithm (java.util.zip.CRC32C).  The reference's own createChecksumAlgorithm knows the two above
+      // only, so with this name its JVM-side validation stream still refuses; the GPU path validates it in the library.
+      case "CRC32C" => CHECKSUM_CRC32C
       // S3ShuffleHelper.createChecksumAlgorithm (S3ShuffleHelper.scala:94-103) rejects everything else too
       case other => throw new UnsupportedOperationException(s"Unsupported shuffle checksum algorithm: $other")
     }

@@ -26,28 +26,30 @@ constexpr int kPiece = 64;
 static_assert(kChecksumSegBytes == kThreads * kPiece, "segment = one piece per thread");
 constexpr uint32_t kAdlerMod = 65521u;
 
-struct Tables {             // built on the host once per context (codec_api.hip)
-  uint32_t slice[4][256];   // CRC-32 slice-by-4 tables (reflected 0xEDB88320)
+struct Tables {             // built on the host once per context (codec_api.hip): one set per CRC polynomial
+  uint32_t slice[4][256];   // slice-by-4 tables of the reflected polynomial
   uint32_t pow_piece[256];  // x^(8*64*k) mod P
   uint32_t x2n[32];         // x^(2^k) mod P
+  uint32_t poly, pad[3];    // 0xEDB88320 (CRC-32, IEEE 802.3: java.util.zip.CRC32) / 0x82F63B78 (CRC-32C, Castagnoli: java.util.zip.CRC32C)
 };
+constexpr uint32_t kPolyIeee = 0xEDB88320u, kPolyCastagnoli = 0x82F63B78u;
 
 // a(x) * b(x) mod P in the reflected representation (zlib multmodp), branch-free
-__device__ __forceinline__ uint32_t multmodp(uint32_t a, uint32_t b) {
+__device__ __forceinline__ uint32_t multmodp(uint32_t a, uint32_t b, uint32_t poly) {
   uint32_t p = 0;
 #pragma unroll
   for (int i = 0; i < 32; i++) {
     p ^= (a & (0x80000000u >> i)) ? b : 0u;
-    b = (b >> 1) ^ (0xEDB88320u & (0u - (b & 1u)));
+    b = (b >> 1) ^ (poly & (0u - (b & 1u)));
   }
   return p;
 }
 
 // x^(8n) mod P
-__device__ __forceinline__ uint32_t x8n(const uint32_t* x2n, uint64_t n) {
+__device__ __forceinline__ uint32_t x8n(const uint32_t* x2n, uint64_t n, uint32_t poly) {
   uint32_t p = 0x80000000u;
   for (int k = 3; n; n >>= 1, k++)
-    if (n & 1) p = multmodp(x2n[k & 31], p);
+    if (n & 1) p = multmodp(x2n[k & 31], p, poly);
   return p;
 }
 
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(kThreads) void checksum_segments_kernel(
       c = on ? cn : c;
     }
     c = ~c;
-    v0 = mine ? multmodp(tabs->pow_piece[T - 1 - tid], c) : 0u;  // shift by the bytes after this piece
+    v0 = mine ? multmodp(tabs->pow_piece[T - 1 - tid], c, tabs->poly) : 0u;  // shift by the bytes after this piece
   } else if (tid < T) {
     const int end = seg_len - kPiece * (T - 1 - tid);
     const int beg = end - kPiece > 0 ? end - kPiece : 0;
@@ -239,18 +241,19 @@ __global__ __launch_bounds__(kThreads) void checksum_combine_kernel(
     // one wavefront per partition, no LDS (see checksum_segments_kernel): lane j folds a contiguous run of segments
     // Horner-style, shifts the run to the end of the partition, the runs are xor-ed across the wave
     const uint32_t* x2n = tabs->x2n;
+    const uint32_t poly = tabs->poly;
     const int64_t run = (nseg + kWave - 1) / kWave;
     const int64_t s0 = (int64_t)tid * run, s1 = (s0 + run) < nseg ? (s0 + run) : nseg;
     uint32_t c = 0;
     int64_t end = 0;
     if (s0 < s1) {
-      const uint32_t xseg = x8n(x2n, kChecksumSegBytes);
+      const uint32_t xseg = x8n(x2n, kChecksumSegBytes, poly);
       for (int64_t s = s0; s < s1; s++) {
         const uint32_t len = part[4 * s + 2];
-        c = multmodp(c, len == (uint32_t)kChecksumSegBytes ? xseg : x8n(x2n, len)) ^ part[4 * s];
+        c = multmodp(c, len == (uint32_t)kChecksumSegBytes ? xseg : x8n(x2n, len, poly), poly) ^ part[4 * s];
         end = s * kChecksumSegBytes + len;
       }
-      c = multmodp(c, x8n(x2n, (uint64_t)(plen - end)));
+      c = multmodp(c, x8n(x2n, (uint64_t)(plen - end), poly), poly);
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) c ^= __shfl_xor(c, d);
@@ -260,33 +263,38 @@ __global__ __launch_bounds__(kThreads) void checksum_combine_kernel(
 
 }  // namespace
 
-size_t checksum_tables_bytes() { return sizeof(Tables); }
+size_t checksum_tables_bytes() { return 2 * sizeof(Tables); }  // [0] CRC-32, [1] CRC-32C
 
 // host-side construction of the constant tables (uploaded once per context)
 void checksum_tables_build(void* host_buf) {
-  Tables* t = static_cast<Tables*>(host_buf);
-  for (uint32_t i = 0; i < 256; i++) {
-    uint32_t c = i;
-    for (int k = 0; k < 8; k++) c = (c & 1) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
-    t->slice[0][i] = c;
-  }
-  for (uint32_t i = 0; i < 256; i++)
-    for (int s = 1; s < 4; s++)
-      t->slice[s][i] = (t->slice[s - 1][i] >> 8) ^ t->slice[0][t->slice[s - 1][i] & 0xff];
-  auto mul = [](uint32_t a, uint32_t b) {
-    uint32_t p = 0;
-    for (int i = 0; i < 32; i++) {
-      if (a & (0x80000000u >> i)) p ^= b;
-      b = (b >> 1) ^ (0xEDB88320u & (0u - (b & 1u)));
+  for (int which = 0; which < 2; which++) {
+    Tables* t = static_cast<Tables*>(host_buf) + which;
+    const uint32_t poly = which == 0 ? kPolyIeee : kPolyCastagnoli;
+    t->poly = poly;
+    t->pad[0] = t->pad[1] = t->pad[2] = 0;
+    for (uint32_t i = 0; i < 256; i++) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; k++) c = (c & 1) ? (poly ^ (c >> 1)) : (c >> 1);
+      t->slice[0][i] = c;
     }
-    return p;
-  };
-  t->x2n[0] = 0x40000000u;  // x^1
-  for (int k = 1; k < 32; k++) t->x2n[k] = mul(t->x2n[k - 1], t->x2n[k - 1]);
-  // x^(8*64) = x^(2^9)
-  const uint32_t xp = t->x2n[9];
-  t->pow_piece[0] = 0x80000000u;  // 1
-  for (int k = 1; k < 256; k++) t->pow_piece[k] = mul(t->pow_piece[k - 1], xp);
+    for (uint32_t i = 0; i < 256; i++)
+      for (int s = 1; s < 4; s++)
+        t->slice[s][i] = (t->slice[s - 1][i] >> 8) ^ t->slice[0][t->slice[s - 1][i] & 0xff];
+    auto mul = [poly](uint32_t a, uint32_t b) {
+      uint32_t p = 0;
+      for (int i = 0; i < 32; i++) {
+        if (a & (0x80000000u >> i)) p ^= b;
+        b = (b >> 1) ^ (poly & (0u - (b & 1u)));
+      }
+      return p;
+    };
+    t->x2n[0] = 0x40000000u;  // x^1
+    for (int k = 1; k < 32; k++) t->x2n[k] = mul(t->x2n[k - 1], t->x2n[k - 1]);
+    // x^(8*64) = x^(2^9)
+    const uint32_t xp = t->x2n[9];
+    t->pow_piece[0] = 0x80000000u;  // 1
+    for (int k = 1; k < 256; k++) t->pow_piece[k] = mul(t->pow_piece[k - 1], xp);
+  }
 }
 
 void launch_checksum_with_tables(int algo, const uint8_t* d_data, const int64_t* d_offsets,
@@ -294,7 +302,7 @@ void launch_checksum_with_tables(int algo, const uint8_t* d_data, const int64_t*
                                  const void* d_tables, uint32_t* d_partial, int64_t* d_out,
                                  int64_t data_len, hipStream_t st) {
   if (n <= 0) return;
-  const Tables* tabs = static_cast<const Tables*>(d_tables);
+  const Tables* tabs = static_cast<const Tables*>(d_tables) + (algo == S3S_CHECKSUM_CRC32C ? 1 : 0);  // (the CRC kernels are the polynomial's tables away from each other)
   if (algo == S3S_CHECKSUM_ADLER32) {
     if (total_segs > 0) {
       (void)hipMemsetAsync(d_partial, 0, 16 * (size_t)total_segs, st);  // wavefront sums are added atomically

@@ -223,8 +223,8 @@ static int compress_core(s3s_ctx* ctx, int codec, int checksum_algo, const uint8
     return fail(ctx, S3S_E_UNSUPPORTED, "%s compression stays on the JVM codec (decode only: s3s_decompress_range*)", codec == S3S_CODEC_LZF ? "lzf" : "zstd");
   if (codec != S3S_CODEC_NONE && codec != S3S_CODEC_LZ4 && codec != S3S_CODEC_SNAPPY)
     return fail(ctx, S3S_E_INVALID, "unknown codec %d", codec);
-  if (checksum_algo != S3S_CHECKSUM_NONE && checksum_algo != S3S_CHECKSUM_ADLER32 &&
-      checksum_algo != S3S_CHECKSUM_CRC32)
+  if (checksum_algo != S3S_CHECKSUM_NONE && checksum_algo != S3S_CHECKSUM_ADLER32 && checksum_algo != S3S_CHECKSUM_CRC32 &&
+      checksum_algo != S3S_CHECKSUM_CRC32C)
     return fail(ctx, S3S_E_INVALID, "unknown checksum algorithm %d", checksum_algo);
   if (checksum_algo != S3S_CHECKSUM_NONE && !out_checksums)
     return fail(ctx, S3S_E_INVALID, "out_checksums is null but a checksum algorithm is selected");
@@ -483,8 +483,8 @@ int s3s_compress_map_outputs_batch_device(s3s_ctx* ctx, int codec, int checksum_
     return fail(ctx, S3S_E_UNSUPPORTED, "%s compression stays on the JVM codec (decode only: s3s_decompress_range*)", codec == S3S_CODEC_LZF ? "lzf" : "zstd");
   if (codec != S3S_CODEC_NONE && codec != S3S_CODEC_LZ4 && codec != S3S_CODEC_SNAPPY)
     return fail(ctx, S3S_E_INVALID, "unknown codec %d", codec);
-  if (checksum_algo != S3S_CHECKSUM_NONE && checksum_algo != S3S_CHECKSUM_ADLER32 &&
-      checksum_algo != S3S_CHECKSUM_CRC32)
+  if (checksum_algo != S3S_CHECKSUM_NONE && checksum_algo != S3S_CHECKSUM_ADLER32 && checksum_algo != S3S_CHECKSUM_CRC32 &&
+      checksum_algo != S3S_CHECKSUM_CRC32C)
     return fail(ctx, S3S_E_INVALID, "unknown checksum algorithm %d", checksum_algo);
   if (codec == S3S_CODEC_SNAPPY && !snappy_compress_available())
     return fail(ctx, S3S_E_UNSUPPORTED, "snappy compression is not available in this build");
@@ -777,7 +777,7 @@ int s3s_checksum_ranges_device(s3s_ctx* ctx, int algo, const uint8_t* d_data,
   if (!ctx) return S3S_E_INVALID;
   ctx->err[0] = 0;
   if (n < 0 || !offsets || (n > 0 && !out)) return fail(ctx, S3S_E_INVALID, "null offsets/out or negative count");
-  if (algo != S3S_CHECKSUM_ADLER32 && algo != S3S_CHECKSUM_CRC32)
+  if (algo != S3S_CHECKSUM_ADLER32 && algo != S3S_CHECKSUM_CRC32 && algo != S3S_CHECKSUM_CRC32C)
     return fail(ctx, S3S_E_INVALID, "Unsupported shuffle checksum algorithm: %d", algo);
   if (n == 0) return S3S_OK;
   for (int32_t p = 0; p < n; p++)

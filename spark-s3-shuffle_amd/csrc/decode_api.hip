@@ -148,8 +148,8 @@ int s3s_decompress_range_device(s3s_ctx* ctx, int codec, int checksum_algo, cons
     return fail(ctx, S3S_E_INVALID, "null/invalid argument");
   if (codec != S3S_CODEC_NONE && codec != S3S_CODEC_LZ4 && codec != S3S_CODEC_SNAPPY && codec != S3S_CODEC_ZSTD && codec != S3S_CODEC_LZF)
     return fail(ctx, S3S_E_INVALID, "unknown codec %d", codec);
-  if (checksum_algo != S3S_CHECKSUM_NONE && checksum_algo != S3S_CHECKSUM_ADLER32 &&
-      checksum_algo != S3S_CHECKSUM_CRC32)
+  if (checksum_algo != S3S_CHECKSUM_NONE && checksum_algo != S3S_CHECKSUM_ADLER32 && checksum_algo != S3S_CHECKSUM_CRC32 &&
+      checksum_algo != S3S_CHECKSUM_CRC32C)
     return fail(ctx, S3S_E_INVALID, "Unsupported shuffle checksum algorithm: %d", checksum_algo);
   if (part_offsets[0] != 0 || part_offsets[nparts] != comp_len)
     return fail(ctx, S3S_E_INVALID, "part_offsets must span [0, comp_len]");
@@ -438,7 +438,8 @@ extern "C" int s3s_decompress_ranges_batch_device(s3s_ctx* ctx, int codec, int c
   if (n_ranges < 0 || (n_ranges > 0 && !R)) return fail(ctx, S3S_E_INVALID, "null range array or negative count");
   if (codec != S3S_CODEC_NONE && codec != S3S_CODEC_LZ4 && codec != S3S_CODEC_SNAPPY && codec != S3S_CODEC_ZSTD && codec != S3S_CODEC_LZF)
     return fail(ctx, S3S_E_INVALID, "unknown codec %d", codec);
-  if (checksum_algo != S3S_CHECKSUM_NONE && checksum_algo != S3S_CHECKSUM_ADLER32 && checksum_algo != S3S_CHECKSUM_CRC32)
+  if (checksum_algo != S3S_CHECKSUM_NONE && checksum_algo != S3S_CHECKSUM_ADLER32 && checksum_algo != S3S_CHECKSUM_CRC32 &&
+      checksum_algo != S3S_CHECKSUM_CRC32C)
     return fail(ctx, S3S_E_INVALID, "Unsupported shuffle checksum algorithm: %d", checksum_algo);
   auto single = [&](s3s_fetch_range& r) {
     r.status = s3s_decompress_range_device(ctx, codec, checksum_algo, r.d_comp, r.comp_len, r.part_offsets,

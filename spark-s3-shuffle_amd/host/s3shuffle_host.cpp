@@ -172,7 +172,8 @@ int S3ShuffleDispatcher::checksumId() const {
   if (!conf_.checksumEnabled) return S3S_CHECKSUM_NONE;
   if (conf_.checksumAlgorithm == "ADLER32") return S3S_CHECKSUM_ADLER32;
   if (conf_.checksumAlgorithm == "CRC32") return S3S_CHECKSUM_CRC32;
-  // S3ShuffleHelper.createChecksumAlgorithm (:94-103)
+  if (conf_.checksumAlgorithm == "CRC32C") return S3S_CHECKSUM_CRC32C;  // (Spark 4's third algorithm; the library computes it)
+  // S3ShuffleHelper.createChecksumAlgorithm (:94-103) knows the first two
   throw std::invalid_argument("Unsupported shuffle checksum algorithm: " + conf_.checksumAlgorithm + ".");
 }
 int S3ShuffleDispatcher::deviceForMap(int64_t mapId) const { return (int)(mapId % ngpu_); }

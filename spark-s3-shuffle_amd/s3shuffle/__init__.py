@@ -9,6 +9,7 @@ library or without a HIP device raises.
 from .codec import (  # noqa: F401
     CHECKSUM_ADLER32,
     CHECKSUM_CRC32,
+    CHECKSUM_CRC32C,
     CHECKSUM_NONE,
     CODEC_LZ4,
     CODEC_LZF,

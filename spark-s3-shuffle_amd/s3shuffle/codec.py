@@ -10,7 +10,7 @@ import numpy as np
 CODEC_NONE, CODEC_LZ4, CODEC_SNAPPY = 0, 1, 2
 CODEC_ZSTD = 3  # reduce side only: decode of Zstandard frames (the compress entry points refuse it)
 CODEC_LZF = 4  # reduce side only: LZFCompressionCodec streams (compress-lzf chunks around liblzf blocks)
-CHECKSUM_NONE, CHECKSUM_ADLER32, CHECKSUM_CRC32 = 0, 1, 2
+CHECKSUM_NONE, CHECKSUM_ADLER32, CHECKSUM_CRC32, CHECKSUM_CRC32C = 0, 1, 2, 3
 
 OPT_LZ4_BLOCK_SIZE, OPT_SNAPPY_BLOCK_SIZE, OPT_PROFILE = 1, 2, 3
 STAGE_TOTAL, STAGE_CODEC, STAGE_ASSEMBLE, STAGE_CHECKSUM, STAGE_DISCOVER, STAGE_HASH = 0, 1, 2, 3, 4, 5

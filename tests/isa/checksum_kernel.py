@@ -18,33 +18,34 @@ SEG = 16384  # kChecksumSegBytes
 _PROG = {}
 
 
-def _mul(a, b):
+def _mul(a, b, poly=0xEDB88320):
     p = 0
     for i in range(32):
         if a & (0x80000000 >> i):
             p ^= b
-        b = (b >> 1) ^ (0xEDB88320 if b & 1 else 0)
+        b = (b >> 1) ^ (poly if b & 1 else 0)
     return p
 
 
-def tables():
-    """struct Tables of checksum.hip as checksum_tables_build fills it"""
+def tables(poly=0xEDB88320):
+    """struct Tables of checksum.hip as checksum_tables_build fills it (one set per polynomial: CRC-32 / CRC-32C)"""
     sl = np.zeros((4, 256), np.uint32)
     for i in range(256):
         c = i
         for _ in range(8):
-            c = (0xEDB88320 ^ (c >> 1)) if c & 1 else c >> 1
+            c = (poly ^ (c >> 1)) if c & 1 else c >> 1
         sl[0, i] = c
     for s in range(1, 4):
         for i in range(256):
             sl[s, i] = (int(sl[s - 1, i]) >> 8) ^ int(sl[0, int(sl[s - 1, i]) & 0xFF])
     x2n = [0x40000000]
     for _ in range(31):
-        x2n.append(_mul(x2n[-1], x2n[-1]))
+        x2n.append(_mul(x2n[-1], x2n[-1], poly))
     pw = [0x80000000]
     for _ in range(255):
-        pw.append(_mul(pw[-1], x2n[9]))
-    return np.concatenate([sl.reshape(-1), np.array(pw, np.uint32), np.array(x2n, np.uint32)]).astype(np.uint32)
+        pw.append(_mul(pw[-1], x2n[9], poly))
+    return np.concatenate([sl.reshape(-1), np.array(pw, np.uint32), np.array(x2n, np.uint32),
+                           np.array([poly, 0, 0, 0], np.uint32)]).astype(np.uint32)
 
 
 def _program(needle):
@@ -58,7 +59,8 @@ def _program(needle):
 
 
 def checksum_ranges(algo, data: bytes, offsets, data_len=None):
-    """algo 1 = Adler32, 2 = CRC32; offsets: n + 1 ascending positions into data.  -> list of n checksums"""
+    """algo 1 = Adler32, 2 = CRC32, 3 = CRC32C (the CRC32 kernels on the other polynomial's tables, as
+    launch_checksum_with_tables picks them); offsets: n + 1 ascending positions into data.  -> list of n checksums"""
     offsets = np.asarray(offsets, np.int64)
     n = len(offsets) - 1
     seg_start = np.zeros(n + 1, np.int32)
@@ -69,7 +71,8 @@ def checksum_ranges(algo, data: bytes, offsets, data_len=None):
     a_data = mem.map(np.frombuffer(bytearray(data) or bytearray(1), dtype=np.uint8), "data", writable=False)
     a_off = mem.map(offsets, "offsets", writable=False)
     a_seg = mem.map(seg_start, "seg_start", writable=False)
-    a_tab = mem.map(tables(), "tables", writable=False)
+    a_tab = mem.map(tables(0x82F63B78 if algo == 3 else 0xEDB88320), "tables", writable=False)
+    algo = 2 if algo == 3 else algo
     partial = np.zeros(max(4 * total, 4), np.uint32)[: 4 * total] if total else np.zeros(0, np.uint32)
     a_par = mem.map(partial if total else np.zeros(1, np.uint32), "partial")
     out = np.full(n, -1, np.int64)

@@ -8,7 +8,7 @@ import corpus
 pytestmark = pytest.mark.gpu
 
 LZ4, SNAPPY, NONE = 1, 2, 0
-ADLER, CRC = 1, 2
+ADLER, CRC, CRC32C = 1, 2, 3
 
 
 import os
@@ -68,7 +68,7 @@ def test_lz4_single_partition_edge_lengths(gpu_codec, oracle, kind):
         _check(gpu_codec, oracle, LZ4, ADLER, data, [0, n])
 
 
-@pytest.mark.parametrize("algo", [ADLER, CRC, 0])
+@pytest.mark.parametrize("algo", [ADLER, CRC, CRC32C, 0])
 def test_lz4_ragged_partitions(gpu_codec, oracle, algo):
     rng = np.random.default_rng(7 + algo)
     for it in range(6):
@@ -112,7 +112,7 @@ def test_codec_none(gpu_codec, oracle):
         _check(gpu_codec, oracle, NONE, algo, data, offsets)
 
 
-@pytest.mark.parametrize("algo", [ADLER, CRC])
+@pytest.mark.parametrize("algo", [ADLER, CRC, CRC32C])
 def test_checksum_ranges(gpu_codec, oracle, algo):
     rng = np.random.default_rng(3)
     data = rng.integers(0, 256, 3_000_000, dtype=np.uint8)
@@ -126,6 +126,10 @@ def test_checksum_ranges(gpu_codec, oracle, algo):
     # known-answer vectors
     assert gpu_codec.checksum_ranges(CRC, np.frombuffer(b"123456789", np.uint8), [0, 9])[0] == 0xCBF43926
     assert gpu_codec.checksum_ranges(ADLER, np.frombuffer(b"Wikipedia", np.uint8), [0, 9])[0] == 0x11E60398
+    # CRC32C (java.util.zip.CRC32C, ABI 8): the check value and RFC 3720 B.4's vectors
+    assert gpu_codec.checksum_ranges(CRC32C, np.frombuffer(b"123456789", np.uint8), [0, 9])[0] == 0xE3069283
+    rfc = np.concatenate([np.zeros(32, np.uint8), np.full(32, 255, np.uint8), np.arange(32, dtype=np.uint8), np.arange(31, -1, -1, dtype=np.uint8)])
+    assert [int(x) for x in gpu_codec.checksum_ranges(CRC32C, rfc, [0, 32, 64, 96, 128])] == [0x8A9136AA, 0x62A8AB43, 0x46DD794E, 0x113FDB5C]
 
 
 def test_capacity_error(gpu_codec):

@@ -31,7 +31,7 @@ def _oracle_image(oracle, codec, algo, data, offsets, block_size=32768):
     return oracle.compress_map_output(codec, algo, data, offsets, block_size)
 
 
-@pytest.mark.parametrize("algo", [ADLER, CRC, 0])
+@pytest.mark.parametrize("algo", [ADLER, CRC, 3, 0])
 def test_decode_oracle_streams(gpu_codec, oracle, algo):
     rng = np.random.default_rng(31 + algo)
     for it in range(5):

@@ -175,3 +175,32 @@ def test_single_pass_and_its_fallback(gpu_codec):
         assert res[0][0] == -2 and res[0][1] == plain.size and res[1][0] == 0
     finally:
         dev.free()
+
+
+
+def test_many_huffman_blocks_per_partition(gpu_codec):
+    """The literal wavefront works one block ahead of its two sequence wavefronts through two literal buffers per partition
+    (zstd_partitions_kernel, LitPipe): partitions of ten and more Huffman-coded blocks exercise the hand-over and the buffer
+    reuse; an odd partition count leaves the last workgroup with one partition; an empty partition and a partition of stored
+    blocks (no Huffman literals at all) share workgroups with them.  Once in the single-pass form, once - a partition of
+    zeros outgrows its guess - through the size pass and the decode pass."""
+    from s3shuffle import datagen
+
+    tera, toffs = datagen.terasort_map_output(6 << 20, 5, seed=21)      # 1.2 MiB = 10 blocks per partition
+    wide, woffs = datagen.tpcds_wide_map_output(5 << 20, 3, seed=22)    # treeless blocks among them
+    rnd = np.random.default_rng(23).integers(0, 256, 400_000, dtype=np.uint8)
+    pieces = [tera[toffs[k]:toffs[k + 1]] for k in range(5)] + [wide[woffs[k]:woffs[k + 1]] for k in range(3)]
+    pieces += [np.zeros(0, np.uint8), rnd, pieces[0][:700_000]]  # 11 partitions
+    for extra in ([], [np.zeros(2_000_000, np.uint8)]):  # (the zeros: 2 MB from ~200 bytes, far beyond 8 x)
+        parts = pieces + extra
+        data = np.concatenate(parts)
+        offs = np.concatenate([[0], np.cumsum([p.size for p in parts])]).astype(np.int64)
+        for algo in (ADLER, 0):
+            img, index, sums = _image(algo, data, offs)
+            assert gpu_codec.decompressed_size(ZSTD, img) == data.size
+            out = gpu_codec.decompress_range(ZSTD, algo, img, index, sums, dst_capacity=data.size)
+            assert np.array_equal(out, data), (len(parts), algo)
+        # the same without its first partition: the other parity of partition pairs
+        sub = img[index[1]:]
+        out = gpu_codec.decompress_range(ZSTD, 0, sub, index[1:] - index[1], None, dst_capacity=int(data.size - offs[1]))
+        assert np.array_equal(out, data[offs[1]:])

@@ -543,8 +543,8 @@ def test_whole_lzf_reduce_side_call_through_the_compiled_kernels(oracle):
 
 
 # ---- the compiled checksum kernels under the interpreter ----------------------------------------------------------------------
-@pytest.mark.parametrize("algo", [1, 2], ids=["adler32", "crc32"])
-def test_compiled_checksum_kernels(algo):
+@pytest.mark.parametrize("algo", [1, 2, 3], ids=["adler32", "crc32", "crc32c"])
+def test_compiled_checksum_kernels(algo, oracle):
     """checksum_segments_kernel (256-thread workgroups, four wavefronts that do not talk to each other) + checksum_combine_kernel
     as hipcc compiles them, against zlib: ragged ranges at every alignment, empty ranges, ranges of several 16 KiB segments,
     one-byte ranges — the data buffer ends with its last byte.  And the capacity-overflow rule: offsets that point behind
@@ -553,7 +553,7 @@ def test_compiled_checksum_kernels(algo):
 
     import checksum_kernel as ck
 
-    f = zlib.adler32 if algo == 1 else zlib.crc32
+    f = zlib.adler32 if algo == 1 else zlib.crc32 if algo == 2 else (lambda b: oracle.crc32c(np.frombuffer(b, np.uint8)) if len(b) else 0)
     rng = np.random.default_rng(50 + algo)
     data = rng.integers(0, 256, 120_000, dtype=np.uint8).tobytes()
     cuts = sorted({0, 0, 1, 2, 63, 64, 65, 127, 4096, 16383, 16384, 16385, 16384 * 3 + 7, 70_001, 70_001, 119_999, 120_000})
@@ -672,3 +672,44 @@ def test_compiled_zstd_decoder(oracle):
     for bad in (good[:len(good) // 2], good[:40] + bytes([good[40] ^ 0x5A]) + good[41:]):
         out, rcs, _ = zk.decode_partitions([(bad, parts[0][1])])
         assert out[0] is None or out[0] == want[0]
+
+
+def test_compiled_zstd_literal_wavefront_over_several_blocks(oracle):
+    """Round 4: a workgroup of zstd_partitions_kernel is two sequence wavefronts and one literal wavefront that regenerates the
+    Huffman literals of each partition's NEXT block (LitPipe counters in LDS, two literal buffers per partition).  The
+    interpreter runs the three wavefronts as co-operating threads (gfx950_emu._WaveGroup: the baton moves at s_barrier, at
+    s_sleep and when a wavefront ends).  A partition of eight Huffman-coded blocks beside one of five: the literal side runs
+    ahead, waits for a buffer to be given back, and serves both partitions; then the same pair with a damaged Huffman stream in
+    the SECOND block of one partition - that partition is refused (or decodes to something of another size), its neighbour
+    still decodes, and nobody waits forever."""
+    import zstd_kernel as zk
+    from oracle import zstd_ref
+    from s3shuffle import datagen
+
+    tera, _ = datagen.terasort_map_output(1 << 20, 2, seed=31)
+    wide, _ = datagen.tpcds_wide_map_output(1 << 20, 2, seed=32)
+    # (window_log 12: libzstd cuts 4 KiB blocks, so a few dozen KB are many blocks and the interpreter stays quick)
+    a, b = tera[:30_000], wide[:17_000]
+    ca, cb = bytes(zstd_ref.compress_stream(a, level=1, window_log=12)), bytes(zstd_ref.compress_stream(b, level=1, window_log=12))
+    out, rcs, waves = zk.decode_partitions([(ca, a.size), (cb, b.size)])
+    assert rcs == [0, 0] and out[0] == a.tobytes() and out[1] == b.tobytes()
+    def blocks(c):  # (offset of the block content, size, literals type) of a single frame without dictionary id
+        fhd = c[4]
+        pos = 5 + (0 if fhd & 0x20 else 1) + [0, 1, 2, 4][fhd & 3] + ([1, 2, 4, 8][fhd >> 6] if (fhd >> 6) or (fhd & 0x20) else 0)
+        found = []
+        while True:
+            bh = int.from_bytes(c[pos:pos + 3], "little")
+            size = 1 if (bh >> 1) & 3 == 1 else bh >> 3
+            found.append((pos + 3, size, c[pos + 3] & 3 if (bh >> 1) & 3 == 2 else -1))
+            pos += 3 + size
+            if bh & 1:
+                return found
+
+    ba, bb = blocks(ca), blocks(cb)
+    assert sum(1 for _, _, t in ba if t >= 2) >= 5 and sum(1 for _, _, t in bb if t >= 2) >= 3  # Huffman-coded literals
+    second = [o for o, _, t in ba if t >= 2][1] - 3
+    hit = second + 3 + 40  # inside its literals section (table or first stream)
+    bad = ca[:hit] + bytes([ca[hit] ^ 0x77]) + ca[hit + 1:]
+    out, rcs, _ = zk.decode_partitions([(bad, a.size), (cb, b.size)])
+    assert out[1] == b.tobytes() and rcs[1] == 0
+    assert out[0] is None or out[0] == a.tobytes()

@@ -69,6 +69,29 @@ def test_crc32_adler32_known_answers_and_zlib(oracle):
     assert oracle.checksum(ADLER, ff) == zlib.adler32(ff.tobytes())
 
 
+def test_crc32c_rfc3720_vectors_and_the_processor_instruction(oracle):
+    """java.util.zip.CRC32C (Castagnoli; ABI 8's S3S_CHECKSUM_CRC32C).  No library of this image computes it from Python, so
+    the pins are: the check value, the four vectors of RFC 3720 B.4 (iSCSI), and the x86 crc32 instruction - the polynomial
+    in silicon, which is also what HotSpot's CRC32C intrinsic executes - on lengths around every boundary of both forms;
+    the running form (init = previous value) must chain."""
+    u8 = lambda b: np.frombuffer(b, np.uint8)  # noqa: E731
+    assert oracle.crc32c(u8(b"123456789")) == 0xE3069283
+    assert oracle.crc32c(np.zeros(32, np.uint8)) == 0x8A9136AA
+    assert oracle.crc32c(np.full(32, 255, np.uint8)) == 0x62A8AB43
+    assert oracle.crc32c(np.arange(32, dtype=np.uint8)) == 0x46DD794E
+    assert oracle.crc32c(np.arange(31, -1, -1, dtype=np.uint8)) == 0x113FDB5C
+    assert oracle.checksum(3, np.zeros(0, np.uint8)) == 0
+    if not oracle.crc32c_hw_available():
+        pytest.skip("no SSE4.2 on this host: the instruction pin cannot run")
+    rng = np.random.default_rng(12)
+    for n in [1, 2, 3, 7, 8, 9, 15, 16, 17, 63, 64, 65, 4095, 4096, 4097, 65521, 1 << 20, 3_000_001]:
+        d = rng.integers(0, 256, n, dtype=np.uint8)
+        want = oracle.crc32c(d, hw=True)
+        assert oracle.crc32c(d) == want and oracle.checksum(3, d) == want and oracle.checksum_fast(3, d) == want, n
+        cut = int(rng.integers(0, n + 1))
+        assert oracle.crc32c(d[cut:], init=oracle.crc32c(d[:cut])) == want
+
+
 # ---- raw LZ4 block: byte-exact with liblz4 1.9.3 -------------------------------------------------
 @pytest.mark.parametrize("kind", range(corpus.N_KINDS))
 def test_lz4_block_bit_exact_with_liblz4(oracle, kind):
