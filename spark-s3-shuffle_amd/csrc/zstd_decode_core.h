@@ -863,8 +863,7 @@ ZS_HD int decode_frame(Work& w, LitPipe& lp, const uint8_t* src, int64_t size, u
                     no = more ? (int)((eo >> 16) & 0xff) : 0;
           const int nb = co + bm + bl + nl + nm + no;
           if (nb <= 57) {
-            (void)bitr_peek(r, 1);  // make the cache cover the cursor: afterwards cache holds bits [cbase, cbase + 64), cbase <= pos - 57
-            if (!(r.pos - nb >= r.cbase && r.pos <= r.cbase + 64)) {
+            if (!(r.pos - nb >= r.cbase && r.pos <= r.cbase + 64)) {  // the window whose top byte holds the cursor: >= 57 bits below it
               const int32_t top = (r.pos - 1) >> 3;
               r.cbase = (top - 7) * 8;
               r.cache = load_bits64(r.p, r.size, top - 7);
@@ -877,16 +876,14 @@ ZS_HD int decode_frame(Work& w, LitPipe& lp, const uint8_t* src, int64_t size, u
             int rem = nb;
             auto take = [&](int n) -> uint32_t {
               rem -= n;
-              return (uint32_t)((bits >> rem) & ((1ull << n) - 1));
+              return (uint32_t)(bits >> rem) & ((1u << n) - 1u);  // (every field is at most 31 bits)
             };
             ov = take(co);
             mlen = (vm & 0xFFFFFFu) + take(bm);
             llen = (vl & 0xFFFFFFu) + take(bl);
-            if (more) {
-              sl = (el & 0xFFFFu) + take(nl);
-              sm = (em & 0xFFFFu) + take(nm);
-              so = (eo & 0xFFFFu) + take(no);
-            }
+            sl = (el & 0xFFFFu) + take(nl);  // (after the last sequence: 0 bits each, states nobody reads)
+            sm = (em & 0xFFFFu) + take(nm);
+            so = (eo & 0xFFFFu) + take(no);
             r.pos -= nb;
           } else
           {
@@ -905,43 +902,41 @@ ZS_HD int decode_frame(Work& w, LitPipe& lp, const uint8_t* src, int64_t size, u
             so = (eo & 0xFFFFu) + bitr_read(r, (int)((eo >> 16) & 0xff));
           }
           }
-          const uint64_t oval = (1ull << co) + ov;
+          const uint32_t oval = (1u << co) + ov;  // (co <= 31 and ov < 2^co: fits)
           // Strict (RFC 8878 §3.1.1.3.2.1.2: the stream ends exactly at its first bit): libzstd >= 1.4.5 lets a damaged
           // stream read below its start — what it returns there depends on its 64-bit container's state — and only demands
           // that no bits are left over; such streams are refused here ("Stream is corrupted") instead of decoded to
           // whatever the container held.  Valid streams never get here, and damaged ones were stopped by the partition's
           // Adler32 / CRC32 before the decoder saw them.
-          if (r.pos < 0) return ZS_FAIL();
-          // offset with the repeat history (three scalars on purpose: an array indexed by the repeat code lives in scratch
-          // memory on the device - a store and a load round trip on every sequence's critical path)
-          uint32_t offset;  // (oval < 2^32: the offset code is at most 31)
-          if (oval > 3) {
-            offset = (uint32_t)(oval - 3);
-            rep2 = rep1;
-            rep1 = rep0;
-            rep0 = offset;
-          } else {
-            const uint32_t idx = (uint32_t)oval - 1 + (llen == 0 ? 1u : 0u);  // 0..3
-            if (idx == 0) {
-              offset = rep0;
-            } else {
-              const uint32_t v = idx == 1 ? rep1 : idx == 2 ? rep2 : rep0 - 1;
-              if (v == 0) return ZS_FAIL();
-              if (idx != 1) rep2 = rep1;
-              rep1 = rep0;
-              rep0 = v;
-              offset = v;
-            }
-          }
-          if (lit_pos + llen > regen32) return ZS_FAIL();
+          uint32_t bad = r.pos < 0 ? 1u : 0u;
+          // offset with the repeat history.  Three scalars on purpose: an array indexed by the repeat code lives in scratch
+          // memory on the device - a store and a load round trip on every sequence's critical path.  Selects instead of
+          // branches, and ONE exit for everything that can be wrong with a sequence: a branch costs this loop an exec-mask
+          // save, a jump and a restore, and there were seven of them per sequence.
+          //   new offset (oval > 3):   rep = {offset, rep0, rep1}
+          //   repeat code idx 0:       unchanged;   idx 1: {rep1, rep0, rep2};   idx 2: {rep2, rep0, rep1};   idx 3: {rep0 - 1, rep0, rep1}
+          const bool is_rep = oval <= 3;
+          const uint32_t idx = oval - 1 + (llen == 0 ? 1u : 0u);  // 0..3 (meaningful when is_rep)
+          const uint32_t rv = idx == 0 ? rep0 : idx == 1 ? rep1 : idx == 2 ? rep2 : rep0 - 1;
+          const uint32_t offset = is_rep ? rv : oval - 3;  // (oval < 2^32: the offset code is at most 31)
+          const bool change = !is_rep || idx != 0, deep = !is_rep || idx >= 2;
+          rep2 = deep ? rep1 : rep2;
+          rep1 = change ? rep0 : rep1;
+          rep0 = change ? offset : rep0;
           const uint32_t reach = bout + llen;  // bytes of this block in front of the match
-          // (no dictionary: history starts with the frame)
-          if (offset == 0 || (offset > reach && (int64_t)(offset - reach) > bop)) return ZS_FAIL();
+          const uint32_t nbout = reach + mlen;
+          // (no dictionary: history starts with the frame; offset 0 is also what repeat code 3 gives when rep0 is 1)
+          bad |= (offset == 0 ? 1u : 0u) | (lit_pos + llen > regen32 ? 1u : 0u) | (nbout > (uint32_t)kMaxBlock ? 1u : 0u) |
+                 ((offset > reach ? 1u : 0u) & ((uint64_t)(offset - reach) > (uint64_t)bop ? 1u : 0u));
+          const bool over = execute && nbout > bcap;
+          if (bad | (over ? 1u : 0u)) {
+            if (bad) return ZS_FAIL();
+            return ZS_CAPACITY;
+          }
 #ifdef ZS_STATS_HOOK
           ZS_STATS_HOOK((int64_t)offset, (int64_t)mlen, (int64_t)llen);
 #endif
           if (execute) {
-            if (reach + mlen > bcap) return ZS_CAPACITY;
             if (llen) {
               if (lit_rle >= 0) put_fill(w, bdst + bout, rq0 + bout, (uint8_t)lit_rle, llen, L);
               else put_literals(w, bdst + bout, rq0 + bout, lit, regen32, lit_pos, llen, L, litw_base);
@@ -958,8 +953,7 @@ ZS_HD int decode_frame(Work& w, LitPipe& lp, const uint8_t* src, int64_t size, u
             put_match(w, bdst + reach, rq0 + reach, offset, mlen, near, L);
           }
           lit_pos += llen;
-          bout = reach + mlen;
-          if (bout > (uint32_t)kMaxBlock) return ZS_FAIL();
+          bout = nbout;
         }
         if (r.pos != 0) return ZS_FAIL();  // the sequence stream must be consumed exactly
       } else {

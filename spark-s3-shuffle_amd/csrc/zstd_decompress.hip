@@ -71,6 +71,7 @@ __global__ __launch_bounds__(kZstdThreads, 3) void zstd_partitions_kernel(const 
   }
   const int p = p0 + wave;
   if (p >= n) return;
+  __builtin_amdgcn_s_setprio(3);  // (the sequence side is the partition's critical path, the literal wavefront has slack: + 4.7 %)
   const ZPart zp = parts[p];
   int64_t total = 0, need = 0;
   int rc = s3s_zstd::ZS_OK;
