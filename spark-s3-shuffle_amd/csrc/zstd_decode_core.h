@@ -704,7 +704,6 @@ ZS_HD int decode_frame(Work& w, LitPipe& lp, const uint8_t* src, int64_t size, u
   w.have_ll = w.have_ml = w.have_of = 0;
   w.vals_ll = w.vals_ml = 0;
   int64_t op = 0;          // bytes produced in this frame
-  int64_t visible = 0;     // bytes of this frame's output every lane may read (fence issued behind them)
   for (;;) {
     if (ip + 3 > size) return ZS_FAIL();
     const uint32_t bh = rd_le(src + ip, 3);
@@ -717,6 +716,7 @@ ZS_HD int decode_frame(Work& w, LitPipe& lp, const uint8_t* src, int64_t size, u
       if (execute) {
         if (op + bsize > cap) return ZS_CAPACITY;
         put_plain(w, dst + op, (uint32_t)op, src + ip, (uint32_t)bsize, L);
+        ZS_FENCE();  // (every block ends with one: a later block's far match may read this output from memory)
       }
       ip += bsize;
       op += bsize;
@@ -725,6 +725,7 @@ ZS_HD int decode_frame(Work& w, LitPipe& lp, const uint8_t* src, int64_t size, u
       if (execute) {
         if (op + bsize > cap) return ZS_CAPACITY;
         put_fill(w, dst + op, (uint32_t)op, src[ip], (uint32_t)bsize, L);
+        ZS_FENCE();
       }
       ip += 1;
       op += bsize;
@@ -784,6 +785,7 @@ ZS_HD int decode_frame(Work& w, LitPipe& lp, const uint8_t* src, int64_t size, u
       const uint32_t regen32 = (uint32_t)regen;
       const uint32_t bcap = !execute ? 0u : (cap - bop > 0x7fffffffll ? 0x7fffffffu : (uint32_t)(cap - bop));
       uint32_t bout = 0, lit_pos = 0;
+      uint32_t visible = 0;  // (a fence follows every block: at its start everything before it is readable)
       int32_t litw_base = -1;
       if (nseq > 0) {
         if (b >= bend) return ZS_FAIL();
@@ -917,7 +919,10 @@ ZS_HD int decode_frame(Work& w, LitPipe& lp, const uint8_t* src, int64_t size, u
           //   repeat code idx 0:       unchanged;   idx 1: {rep1, rep0, rep2};   idx 2: {rep2, rep0, rep1};   idx 3: {rep0 - 1, rep0, rep1}
           const bool is_rep = oval <= 3;
           const uint32_t idx = oval - 1 + (llen == 0 ? 1u : 0u);  // 0..3 (meaningful when is_rep)
-          const uint32_t rv = idx == 0 ? rep0 : idx == 1 ? rep1 : idx == 2 ? rep2 : rep0 - 1;
+          uint32_t rv = rep0;
+          rv = idx == 1 ? rep1 : rv;
+          rv = idx == 2 ? rep2 : rv;
+          rv = idx == 3 ? rep0 - 1 : rv;
           const uint32_t offset = is_rep ? rv : oval - 3;  // (oval < 2^32: the offset code is at most 31)
           const bool change = !is_rep || idx != 0, deep = !is_rep || idx >= 2;
           rep2 = deep ? rep1 : rep2;
@@ -943,11 +948,12 @@ ZS_HD int decode_frame(Work& w, LitPipe& lp, const uint8_t* src, int64_t size, u
             }
             const bool near = offset <= (uint32_t)kRing && offset + mlen <= (uint32_t)kRing;
             if (!near) {  // a far source comes from global memory: what was stored since the last fence must have landed
-              const int64_t mstart = bop + reach - (int64_t)offset;
-              const int64_t mend = offset >= mlen ? mstart + mlen : bop + reach;
-              if (mend > visible) {
+              // (the source ends at reach - offset + mlen, or at reach when it overlaps its own output; everything in front of
+              //  `visible` - bytes of this block behind which a fence has been issued, 0 = the block's start - is readable)
+              const bool fence = offset >= mlen ? offset < nbout - visible : reach > visible;
+              if (fence) {
                 ZS_FENCE();
-                visible = bop + reach;
+                visible = reach;
               }
             }
             put_match(w, bdst + reach, rq0 + reach, offset, mlen, near, L);
@@ -984,7 +990,6 @@ ZS_HD int decode_frame(Work& w, LitPipe& lp, const uint8_t* src, int64_t size, u
         if (execute) pipe_set(&lp.consumed, hblock, L);  // (a release: this block's reads of its literal buffer are done)
 #endif
       }
-      visible = execute ? op : 0;
       if (execute) ZS_FENCE();
     }
     if (last) break;
