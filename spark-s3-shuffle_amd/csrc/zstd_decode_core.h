@@ -664,13 +664,17 @@ ZS_HD void pipe_set(int32_t* p, int32_t v, Lanes L) {  // what this wavefront st
   if (L.lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // sequence side: the literals of Huffman block number `want - 1` are in their buffer (or the literal side has failed)
+// kPipeSpins: a waiter gives up after this many polls (~0.2 us each: seconds, where a block's literals take a millisecond or
+// two) - the two sides cannot wait for each other forever by construction, and this makes a hang impossible by arithmetic too.
+constexpr int32_t kPipeSpins = 1 << 23;
 ZS_HD int pipe_wait_ready(LitPipe& lp, int32_t want) {
-  for (;;) {
+  for (int32_t spins = 0; spins < kPipeSpins; spins++) {
     if (pipe_get(&lp.ready) >= want) return ZS_OK;
     const int32_t e = pipe_get(&lp.err);
     if (e != ZS_OK) return pipe_get(&lp.ready) >= want ? ZS_OK : e;  // (err is set after the last ready)
     __builtin_amdgcn_s_sleep(8);
   }
+  return ZS_FAIL();
 }
 #endif
 
@@ -1088,6 +1092,7 @@ ZS_HD void walker_advance(LitWalker& k, LitPipe& lp, Lanes L) {
 }
 // n_parts (1 or 2) partitions of the workgroup: whichever has a block to regenerate and a free buffer goes next
 ZS_HD void literal_side(LitPipe* lps, LitWalker* ks, int n_parts, Lanes L) {
+  int32_t idle = 0;
   for (;;) {
     bool any = false, progressed = false;
     for (int t = 0; t < n_parts; t++) {
@@ -1113,7 +1118,16 @@ ZS_HD void literal_side(LitPipe* lps, LitWalker* ks, int n_parts, Lanes L) {
       progressed = true;
     }
     if (!any) return;
-    if (!progressed) __builtin_amdgcn_s_sleep(8);
+    if (progressed) {
+      idle = 0;
+    } else {
+      if (++idle >= kPipeSpins) {  // (see kPipeSpins: never in a working machine)
+        for (int t = 0; t < n_parts; t++)
+          if (!ks[t].done) pipe_set(&lps[t].err, ZS_BAD, L);
+        return;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
   }
 }
 #endif

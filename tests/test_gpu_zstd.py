@@ -204,3 +204,42 @@ def test_many_huffman_blocks_per_partition(gpu_codec):
         sub = img[index[1]:]
         out = gpu_codec.decompress_range(ZSTD, 0, sub, index[1:] - index[1], None, dst_capacity=int(data.size - offs[1]))
         assert np.array_equal(out, data[offs[1]:])
+
+
+def test_damaged_multi_block_partitions_end_on_both_sides(gpu_codec):
+    """Damage anywhere in partitions of ten Huffman-coded blocks: in a literals section the LITERAL wavefront meets it first
+    (its `err` reaches a sequence side that is waiting), in a sequence section the sequence side does (its `quit` releases the
+    literal side).  Every call must come back: refused with "bad frame" (or, rarely, a capacity / size verdict), or decoded
+    to exactly what libzstd makes of the same bytes (a Spark writer's frames carry no content checksum, so most single-bit
+    damage decodes - to other bytes - in both); and its undamaged neighbours in the same workgroups decode."""
+    import s3shuffle
+    from oracle import zstd_ref as z
+    from s3shuffle import datagen
+
+    data, offs = datagen.terasort_map_output(7 << 20, 6, seed=41)  # 1.2 MiB = 10 blocks per partition
+    img, index, _ = _image(0, data, offs)
+    rng = np.random.default_rng(42)
+    refused = same = 0
+    for it in range(48):
+        m = img.copy()
+        victim = int(rng.integers(0, 6))
+        lo, hi = int(index[victim]), int(index[victim + 1])
+        at = lo + int(rng.integers(16 if it % 3 else 100_000, hi - lo))  # (it % 3 == 0: well behind the first block)
+        if it % 4 == 3:  # eight random bytes: tables and headers rarely survive that
+            m[at:at + 8] = rng.integers(0, 256, min(8, hi - at), dtype=np.uint8)
+        else:
+            m[at] ^= 1 << int(rng.integers(0, 8))
+        ref = z.decompress(m[lo:hi], int(offs[victim + 1] - offs[victim]) + 4096)
+        try:
+            out = gpu_codec.decompress_range(ZSTD, 0, m, index, None, dst_capacity=data.size + 4096)
+        except s3shuffle.CodecError as e:
+            assert e.code in (-3, -2), (it, e.code)
+            refused += 1
+            continue
+        assert ref is not None, it  # what the GPU decodes, libzstd decodes
+        want = np.concatenate([data[:offs[victim]], ref, data[offs[victim + 1]:]])
+        assert np.array_equal(out, want), it
+        same += 1
+    assert refused >= 5 and same >= 10, (refused, same)  # (a flipped bit in a Huffman stream is just other literals: no frame checksum)
+    # and the call after all that is a clean one
+    assert np.array_equal(gpu_codec.decompress_range(ZSTD, 0, img, index, None, dst_capacity=data.size), data)
