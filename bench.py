@@ -49,6 +49,7 @@ WORKLOADS = {
     "terasort-100g-2000p-lz4-crc32": ("terasort", 2000, "lz4", "crc32"),  # configs[3]
     "skew-1part-lz4": ("skew", 1, "lz4", "adler32"),                  # configs[4] (use --direction decompress)
     "terasort-10g-200p-zstd": ("terasort", 200, "zstd", "adler32"),   # reduce side only (--direction decompress)
+    "tpcds-wide-100g-200p-zstd": ("tpcds", 200, "zstd", "adler32"),   # the same for wide rows (more sequences per byte, treeless blocks)
     # objects of a JVM writer with spark.io.compression.lz4.blockSize=256k (S3ShuffleReader.scala:57-59): reduce side only
     "terasort-10g-200p-lz4-256k": ("terasort", 200, "lz4", "adler32"),
 }
