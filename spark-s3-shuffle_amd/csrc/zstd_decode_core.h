@@ -23,11 +23,13 @@
 
 #ifdef S3S_ZSTD_DEVICE
 #define ZS_HD __device__ __forceinline__
+#define ZS_RARE __device__ __attribute__((noinline))
 #define ZS_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
 // every lane holds the same value: say so (the value moves to a scalar register, what depends on it runs on the scalar unit)
 #define ZS_UNI32(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 #else
 #define ZS_HD static inline
+#define ZS_RARE static
 #define ZS_FENCE() ((void)0)
 #define ZS_UNI32(x) ((uint32_t)(x))
 #endif
@@ -520,6 +522,74 @@ ZS_HD void put_match(Work& w, uint8_t* o, uint32_t rq, uint32_t off, uint32_t n,
   }
 }
 
+// ---- XXH64 of a frame's content (RFC 8878 3.1.1: the optional Content_Checksum is its low 32 bits, seed 0) --------------------------
+// xxHash's published algorithm restated (third party: Cyan4973/xxHash, the code libzstd calls; pinned through libzstd itself -
+// every checksummed frame libzstd writes must verify, a damaged one must not).  A Spark writer's frames carry no checksum
+// (zstd-jni's default), so this runs for foreign frames only.  Device: the four accumulators of a 32-byte stripe are lanes
+// 0..3; the host walks them one after the other.  p[0, n) is the frame's output in global memory, fenced by the caller.
+ZS_HD uint64_t xxh64_rotl(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+ZS_HD uint64_t xxh64_rd64(const uint8_t* p) {
+  uint64_t v;
+  memcpy(&v, p, 8);
+  return v;
+}
+// (not inlined on the device: a rare path whose 64-bit multiplies must not cost the sequence loop its registers)
+ZS_RARE uint64_t xxh64_content(const uint8_t* p, int64_t n, Lanes L) {
+  const uint64_t P1 = 0x9E3779B185EBCA87ull, P2 = 0xC2B2AE3D27D4EB4Full, P3 = 0x165667B19E3779F9ull, P4 = 0x85EBCA77C2B2AE63ull,
+                 P5 = 0x27D4EB2F165667C5ull;
+  uint64_t h;
+  int64_t at = 0;
+  if (n >= 32) {
+    const int64_t stripes = n >> 5;
+    uint64_t v0 = P1 + P2, v1 = P2, v2 = 0, v3 = 0ull - P1;  // (four scalars: an indexed array would live in scratch memory)
+#ifdef S3S_ZSTD_DEVICE
+    {
+      const int k = L.lane & 3;
+      uint64_t acc = k == 0 ? v0 : k == 1 ? v1 : k == 2 ? v2 : v3;
+      const uint8_t* q = p + 8 * k;
+      for (int64_t t = 0; t < stripes; t++) acc = xxh64_rotl(acc + xxh64_rd64(q + 32 * t) * P2, 31) * P1;
+      const int lo = (int)(uint32_t)acc, hi = (int)(uint32_t)(acc >> 32);  // (lanes 0..3 hold v1..v4: to everybody)
+      v0 = ((uint64_t)(uint32_t)__shfl(hi, 0) << 32) | (uint32_t)__shfl(lo, 0);
+      v1 = ((uint64_t)(uint32_t)__shfl(hi, 1) << 32) | (uint32_t)__shfl(lo, 1);
+      v2 = ((uint64_t)(uint32_t)__shfl(hi, 2) << 32) | (uint32_t)__shfl(lo, 2);
+      v3 = ((uint64_t)(uint32_t)__shfl(hi, 3) << 32) | (uint32_t)__shfl(lo, 3);
+    }
+#else
+    (void)L;
+    for (int64_t t = 0; t < stripes; t++) {
+      const uint8_t* q = p + 32 * t;
+      v0 = xxh64_rotl(v0 + xxh64_rd64(q) * P2, 31) * P1;
+      v1 = xxh64_rotl(v1 + xxh64_rd64(q + 8) * P2, 31) * P1;
+      v2 = xxh64_rotl(v2 + xxh64_rd64(q + 16) * P2, 31) * P1;
+      v3 = xxh64_rotl(v3 + xxh64_rd64(q + 24) * P2, 31) * P1;
+    }
+#endif
+    h = xxh64_rotl(v0, 1) + xxh64_rotl(v1, 7) + xxh64_rotl(v2, 12) + xxh64_rotl(v3, 18);
+    h = (h ^ (xxh64_rotl(v0 * P2, 31) * P1)) * P1 + P4;
+    h = (h ^ (xxh64_rotl(v1 * P2, 31) * P1)) * P1 + P4;
+    h = (h ^ (xxh64_rotl(v2 * P2, 31) * P1)) * P1 + P4;
+    h = (h ^ (xxh64_rotl(v3 * P2, 31) * P1)) * P1 + P4;
+    at = stripes << 5;
+  } else {
+    h = P5;
+  }
+  h += (uint64_t)n;
+  for (; at + 8 <= n; at += 8) h = xxh64_rotl(h ^ (xxh64_rotl(xxh64_rd64(p + at) * P2, 31) * P1), 27) * P1 + P4;
+  if (at + 4 <= n) {
+    uint32_t w4;
+    memcpy(&w4, p + at, 4);
+    h = xxh64_rotl(h ^ ((uint64_t)w4 * P1), 23) * P2 + P3;
+    at += 4;
+  }
+  for (; at < n; at++) h = xxh64_rotl(h ^ ((uint64_t)p[at] * P5), 11) * P1;
+  h ^= h >> 33;
+  h *= P2;
+  h ^= h >> 29;
+  h *= P3;
+  h ^= h >> 32;
+  return h;
+}
+
 // ---- one frame ------------------------------------------------------------------------------------------------------------------
 struct FrameOut {
   int64_t consumed;  // bytes of src this frame occupied
@@ -1000,8 +1070,11 @@ ZS_HD int decode_frame(Work& w, LitPipe& lp, const uint8_t* src, int64_t size, u
   }
   if (has_check) {
     if (ip + 4 > size) return ZS_FAIL();
-    ip += 4;  // XXH64 of the content (low 32 bits): not re-verified here — the partition's Adler32 / CRC32 over the
-              // compressed bytes has been checked by the caller before decoding (S3ChecksumValidationStream's role)
+    // Content_Checksum: the low 32 bits of XXH64 over the decoded frame (round 4: verified like libzstd does - without it a
+    // frame of a checksumming writer that was damaged where it still decodes went through whenever the shuffle checksums
+    // were off; the size pass has no bytes to hash, the decode pass of the same call does)
+    if (execute && rd_le(src + ip, 4) != (uint32_t)xxh64_content(dst, op, L)) return ZS_FAIL();
+    ip += 4;
   }
   if (fcs >= 0 && fcs != op) return ZS_FAIL();
   out->consumed = ip;

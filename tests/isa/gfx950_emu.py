@@ -667,9 +667,22 @@ def _lit64(o, w):
     return w.rs64(o)
 
 
+CODE_BASE = 0x7C0DE000_0000  # where the interpreter pretends the code lives: instruction k is at CODE_BASE + 4 k
+
+
 class Program:
-    def __init__(self, text, entry=None):
+    def __init__(self, text, entry=None, callees=()):
+        """callees: device functions the kernel CALLS (s_getpc_b64 + sym@rel32 + s_swappc_b64; hipcc keeps a rare path out
+        of line): their instructions are appended behind the kernel's, their names become code addresses (code_symbols)."""
         self.insts, self.labels = parse_program(text, entry)
+        self.code_symbols = {}
+        for name in callees:
+            more, labels = parse_program(text, name)
+            base = len(self.insts)
+            self.insts += more
+            for k, v in labels.items():
+                self.labels[k] = base + v
+            self.code_symbols[name] = CODE_BASE + 4 * self.labels[name]
         for i in self.insts:
             self._bind(i)
 
@@ -1724,6 +1737,14 @@ def run_wave(prog, w, entry=None, max_inst=50_000_000, profile=None, hooks=None)
             continue
         if op == "s_endpgm":
             break
+        if op == "s_swappc_b64" or op == "s_setpc_b64":  # call / return (see Program.callees)
+            dst = w.rs64(i.ops[-1])
+            if op == "s_swappc_b64":
+                w.ws64(i.ops[0], CODE_BASE + 4 * (pc + 1))
+            if dst < CODE_BASE or (dst - CODE_BASE) % 4 or (dst - CODE_BASE) // 4 >= len(insts):
+                raise EmuError("jump to %#x, which is not code: %s" % (dst, i.text))
+            pc = (dst - CODE_BASE) // 4
+            continue
         if i.fn is None:
             raise EmuError("opcode not modelled (line %d): %s" % (i.line, i.text))
         try:
@@ -1915,6 +1936,7 @@ def launch(prog, entry, mem, kernarg, grid_x, lds_bytes, user_sgprs=2, block_x=6
     kbase = mem.map(np.frombuffer(bytearray(kernarg), dtype=np.uint8), "kernarg", writable=False)
     symbols = {name: mem.map(np.frombuffer(bytearray(data), dtype=np.uint8), name, writable=False)
                for name, data in (objects or {}).items()}
+    symbols.update(getattr(prog, "code_symbols", {}))
     stats = []
     for bx in (grid_x if not isinstance(grid_x, int) else range(grid_x)):
         if cooperative and block_x > 64:  # wavefronts that share LDS and wait for each other: run together (see _WaveGroup)

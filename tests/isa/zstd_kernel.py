@@ -26,7 +26,9 @@ def program():
         for line in text.splitlines():
             if ".amdhsa_group_segment_fixed_size" in line:
                 lds = max(lds, int(line.split()[-1]))
-        _PROG = (emu.Program(text, entry), entry, text, lds)
+        # (the frame checksum's hash is a rare path hipcc is told to keep out of line: zstd_decode_core.h ZS_RARE)
+        callees = [ln.split(':')[0] for ln in text.splitlines() if ln.startswith('_ZN8s3s_zstd13xxh64_content') and ':' in ln]
+        _PROG = (emu.Program(text, entry, callees=callees), entry, text, lds)
     return _PROG
 
 

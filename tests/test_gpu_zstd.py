@@ -129,6 +129,18 @@ def test_checksum_mismatch_corruption_and_capacity(gpu_codec):
     with pytest.raises(s3shuffle.CodecError) as ei:
         gpu_codec.decompress_range(ZSTD, 0, img[:-3], np.append(index[:-1], index[-1] - 3), None, dst_capacity=data.size)
     assert ei.value.code == -3
+    # a frame WITH a content checksum (not what Spark writes; foreign writers do): damage that still decodes - a byte of a stored
+    # block - is caught by the XXH64 the decoder computes over what it decoded, as libzstd catches it
+    rnd = np.random.default_rng(5).integers(0, 256, 300_000, dtype=np.uint8)
+    comp = z.compress_stream(rnd, 1, checksum=True)
+    idx = np.array([0, comp.size], np.int64)
+    assert np.array_equal(gpu_codec.decompress_range(ZSTD, 0, comp, idx, None, dst_capacity=rnd.size), rnd)
+    bad = comp.copy()
+    bad[comp.size // 2] ^= 0x40
+    assert z.decompress(bad, rnd.size + 64) is None
+    with pytest.raises(s3shuffle.CodecError) as ei:
+        gpu_codec.decompress_range(ZSTD, 0, bad, idx, None, dst_capacity=rnd.size)
+    assert ei.value.code == -3
 
 
 def test_compression_with_zstd_is_refused(gpu_codec):

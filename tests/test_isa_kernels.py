@@ -674,6 +674,28 @@ def test_compiled_zstd_decoder(oracle):
         assert out[0] is None or out[0] == want[0]
 
 
+def test_compiled_zstd_content_checksum(oracle):
+    """Round 4: frames written with a content checksum end with XXH64's low 32 bits; the compiled decoder hashes what it
+    decoded - an out-of-line device function (hipcc: s_getpc_b64 + rel32 + s_swappc_b64; the interpreter appends the callee's
+    instructions, Program.callees) whose four accumulators run on lanes 0..3 - and refuses a frame whose content was damaged
+    where it still decodes (a byte of a stored block), as libzstd does."""
+    import zstd_kernel as zk
+    from oracle import zstd_ref
+    from s3shuffle import datagen
+
+    rng = np.random.default_rng(4)
+    tera, _ = datagen.terasort_map_output(1 << 20, 2, seed=3)
+    cases = [tera[:5000], rng.integers(0, 256, 3000, dtype=np.uint8), tera[:37], np.zeros(0, np.uint8), tera[:20], tera[:64]]
+    parts = [(bytes(zstd_ref.compress_stream(d, level=1, checksum=True)), d.size) for d in cases]
+    out, rcs, _ = zk.decode_partitions(parts)
+    assert rcs == [0] * len(cases) and out == [d.tobytes() for d in cases]
+    bad = bytearray(parts[1][0])
+    bad[len(bad) // 2] ^= 0x40
+    assert zstd_ref.decompress(np.frombuffer(bytes(bad), np.uint8), 4096) is None
+    out, rcs, _ = zk.decode_partitions([(bytes(bad), 3000), parts[0]])
+    assert rcs[0] == -3 and out[0] is None and out[1] == cases[0].tobytes()
+
+
 def test_compiled_zstd_literal_wavefront_over_several_blocks(oracle):
     """Round 4: a workgroup of zstd_partitions_kernel is two sequence wavefronts and one literal wavefront that regenerates the
     Huffman literals of each partition's NEXT block (LitPipe counters in LDS, two literal buffers per partition).  The

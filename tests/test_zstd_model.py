@@ -96,6 +96,36 @@ def test_concatenated_and_skippable_frames(model):
     assert rc == -2
 
 
+def test_content_checksum_is_verified_like_libzstd_does(model):
+    """Round 4: a frame written with ZSTD_c_checksumFlag ends with the low 32 bits of XXH64 over its content; the decoder hashes
+    what it decoded (xxh64_content: the published algorithm restated, pinned here through libzstd's own frames) and refuses a
+    mismatch - every content length around the 32-byte stripes and the 8 / 4 / 1-byte tail, then damage that still DECODES:
+    a flipped byte inside a stored (raw) block and a flipped bit of the checksum itself.  libzstd refuses both."""
+    from oracle import zstd_ref as z
+
+    rng = np.random.default_rng(3)
+    for n in list(range(0, 75)) + [95, 96, 97, 127, 128, 129, 1000, 4096, 65537, 300_001]:
+        for data in (rng.integers(0, 256, n, dtype=np.uint8), (np.arange(n) % 7).astype(np.uint8)):
+            comp = z.compress_stream(data, 1, checksum=True)
+            rc, out = _decode(model, comp, n + 64)
+            assert rc == 0 and np.array_equal(out, data), n
+    data = rng.integers(0, 256, 50_000, dtype=np.uint8)  # incompressible: one stored block
+    comp = z.compress_stream(data, 1, checksum=True)
+    assert _decode(model, comp, data.size)[0] == 0
+    for at in (comp.size // 2, comp.size - 1, comp.size - 4):  # a content byte, two bytes of the checksum
+        bad = comp.copy()
+        bad[at] ^= 0x40
+        assert z.decompress(bad, data.size + 64) is None
+        assert _decode(model, bad, data.size + 64)[0] == -3, at
+    # the same content byte without a checksum decodes (to other bytes) in both: the refusal above is the checksum's
+    plain = z.compress_stream(data, 1, checksum=False)
+    bad = plain.copy()
+    bad[plain.size // 2] ^= 0x40
+    ref = z.decompress(bad, data.size + 64)
+    rc, out = _decode(model, bad, data.size + 64)
+    assert ref is not None and rc == 0 and np.array_equal(out, ref) and not np.array_equal(out, data)
+
+
 def test_mutated_streams_behave_like_libzstd(model):
     """every mutation either fails in both decoders or decodes to the same bytes in both"""
     from oracle import zstd_ref as z
