@@ -106,7 +106,9 @@ enum {
 /* option keys for s3s_set_option / s3s_get_option */
 enum {
   S3S_OPT_LZ4_BLOCK_SIZE = 1,    /* spark.io.compression.lz4.blockSize, default 32768;
-                                    supported 64..32768 */
+                                    map side: 64..65536 (liblz4's 16-bit-table parse; larger blocks are its 32-bit-table
+                                    parse: S3S_E_UNSUPPORTED, the JVM codec writes them); the reduce side decodes frames
+                                    of ANY block size whatever this option says */
   S3S_OPT_SNAPPY_BLOCK_SIZE = 2, /* spark.io.compression.snappy.blockSize, default 32768;
                                     supported 1024..32768 (snappy-java raises smaller values
                                     to 1024) */

@@ -122,10 +122,11 @@ int s3s_set_option(s3s_ctx* ctx, int key, int64_t value) {
   if (!ctx) return S3S_E_INVALID;
   switch (key) {
     case S3S_OPT_LZ4_BLOCK_SIZE:
-      // LZ4BlockOutputStream accepts 64 .. 32 MiB; the LDS-resident kernel takes <= 32 KiB
+      // LZ4BlockOutputStream accepts 64 .. 32 MiB; the map side takes what liblz4 parses with its 16-bit table (kLz4MaxBlock);
+      // the reduce side decodes frames of any block size whatever this option says
       if (value < 64) return fail(ctx, S3S_E_INVALID, "lz4 blockSize must be >= 64, got %lld", (long long)value);
-      if (value > kMaxBlock)
-        return fail(ctx, S3S_E_UNSUPPORTED, "lz4 blockSize %lld > %d not supported", (long long)value, kMaxBlock);
+      if (value > kLz4MaxBlock)
+        return fail(ctx, S3S_E_UNSUPPORTED, "lz4 blockSize %lld > %d not supported", (long long)value, kLz4MaxBlock);
       ctx->lz4_block = value;
       return S3S_OK;
     case S3S_OPT_SNAPPY_BLOCK_SIZE:
@@ -324,7 +325,7 @@ static int compress_core(s3s_ctx* ctx, int codec, int checksum_algo, const uint8
     // snappy block can grow to MaxCompressedLength(chunk)
     const int64_t slot_stride = codec == S3S_CODEC_SNAPPY
                                     ? (int64_t)kSlotHeader + ((snappy_max_len(bs) + 15) & ~int64_t(15))
-                                    : (int64_t)kSlotBytes;
+                                    : (int64_t)kSlotHeader + ((bs + 15) & ~int64_t(15));
     if ((rc = ensure(ctx, B_SLOTS, (size_t)slot_stride * (size_t)(n_chunks > 0 ? n_chunks : 1)))) return rc;
     if ((rc = ensure(ctx, B_ITEM_SIZE, sizeof(uint32_t) * (size_t)(n_items + 1)))) return rc;
     if ((rc = ensure(ctx, B_ITEM_OFF, sizeof(int64_t) * (size_t)(n_items + 1)))) return rc;
@@ -358,7 +359,7 @@ static int compress_core(s3s_ctx* ctx, int codec, int checksum_algo, const uint8
       if (i1 <= i0) return;
       if (codec == S3S_CODEC_LZ4)
         launch_lz4_compress(d_src, dev<Item>(ctx, B_ITEMS) + i0, i1 - i0, dev<uint32_t>(ctx, B_ITEM_CHECK) + i0,
-                            dev<uint8_t>(ctx, B_SLOTS), dev<uint32_t>(ctx, B_ITEM_SIZE) + i0, dev<uint32_t>(ctx, B_WORK),
+                            dev<uint8_t>(ctx, B_SLOTS), (int32_t)slot_stride, dev<uint32_t>(ctx, B_ITEM_SIZE) + i0, dev<uint32_t>(ctx, B_WORK),
                             lz4_resident_waves(ctx), lz4_variant_run, ctx->stream,
                             ctx->profile && i1 == n_items ? ctx->ev_hash : nullptr);
       else
@@ -581,7 +582,7 @@ int s3s_compress_map_outputs_batch_device(s3s_ctx* ctx, int codec, int checksum_
   const int32_t total_segs = first_seg[(size_t)n_tasks];
   const int64_t slot_stride = codec == S3S_CODEC_SNAPPY
                                   ? (int64_t)kSlotHeader + ((snappy_max_len(bs) + 15) & ~int64_t(15))
-                                  : (int64_t)kSlotBytes;
+                                  : (int64_t)kSlotHeader + ((bs + 15) & ~int64_t(15));
   if ((rc = ensure(ctx, B_ITEMS, items_bytes + 16))) return rc;
   if ((rc = ensure(ctx, B_PART_FIRST, 4 * np1))) return rc;
   if ((rc = ensure(ctx, B_SEG_START, 4 * np1))) return rc;
@@ -607,7 +608,7 @@ int s3s_compress_map_outputs_batch_device(s3s_ctx* ctx, int codec, int checksum_
     const int variant = ctx->lz4_variant == 9 ? 10 : ctx->lz4_variant;
     ctx->lz4_variant_used = variant;
     launch_lz4_compress(base, dev<Item>(ctx, B_ITEMS), n_items, dev<uint32_t>(ctx, B_ITEM_CHECK),
-                        dev<uint8_t>(ctx, B_SLOTS), dev<uint32_t>(ctx, B_ITEM_SIZE), dev<uint32_t>(ctx, B_WORK), lz4_resident_waves(ctx),
+                        dev<uint8_t>(ctx, B_SLOTS), (int32_t)slot_stride, dev<uint32_t>(ctx, B_ITEM_SIZE), dev<uint32_t>(ctx, B_WORK), lz4_resident_waves(ctx),
                         variant, ctx->stream,
                         ctx->profile ? ctx->ev_hash : nullptr);
   } else {

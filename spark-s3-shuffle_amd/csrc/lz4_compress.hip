@@ -769,7 +769,7 @@ __device__ __forceinline__ uint32_t xxh32_wave(const uint8_t* g, int len, uint32
 // ---- variant B: chunk read in place, only the table in LDS ----------------------------------
 template <bool kWindows>
 __global__ __launch_bounds__(kWave) void lz4_compress_l2_kernel(
-    const uint8_t* __restrict__ src_, const Item* __restrict__ items_, int32_t n_items_,
+    const uint8_t* __restrict__ src_, const Item* __restrict__ items_, int32_t n_items_, int32_t slot_stride_,
     const uint32_t* __restrict__ item_check_, uint8_t* __restrict__ slots_,
     uint32_t* __restrict__ item_size_, uint32_t* __restrict__ work_) {  // (read through the kernarg segment, see the loop)
 #ifdef S3S_ABL_LDS_PAD  // occupancy experiment: fewer wavefronts per CU (timing only)
@@ -788,7 +788,7 @@ __global__ __launch_bounds__(kWave) void lz4_compress_l2_kernel(
   struct KArgs {
     const uint8_t* src;
     const Item* items;
-    int32_t n_items, pad;
+    int32_t n_items, slot_stride;
     const uint32_t* item_check;
     uint8_t* slots;
     uint32_t* item_size;
@@ -844,7 +844,7 @@ __global__ __launch_bounds__(kWave) void lz4_compress_l2_kernel(
     }
     if (acc == 0x12345678u && item.len < 0) table[0] = 1;  // (never taken: keeps the loads)
   }
-  uint8_t* slot = slots + (size_t)item.chunk * kSlotBytes;
+  uint8_t* slot = slots + (size_t)item.chunk * (size_t)(uint32_t)ka->slot_stride;
   const uint32_t check = item_check[it];
   const int clen = lz4_compress_wave<SrcGlobal, kWindows>(SrcGlobal{src + item.src_off}, TabLds{(lds_u16*)table},
                                                       item.len, slot + kSlotHeader, lane);
@@ -901,7 +901,7 @@ __global__ __launch_bounds__(kWave) void xxh32_items_wave_kernel(
 }  // namespace
 
 void launch_lz4_compress(const uint8_t* d_src, const Item* d_items, int32_t n_items,
-                         uint32_t* d_item_check, uint8_t* d_slots, uint32_t* d_item_size, uint32_t* d_work, int resident_waves,
+                         uint32_t* d_item_check, uint8_t* d_slots, int32_t slot_stride, uint32_t* d_item_size, uint32_t* d_work, int resident_waves,
                          int variant, hipStream_t st, hipEvent_t after_hash) {
   if (n_items <= 0) {
     if (after_hash) hipEventRecord(after_hash, st);
@@ -942,7 +942,7 @@ void launch_lz4_compress(const uint8_t* d_src, const Item* d_items, int32_t n_it
       {
         (void)hipMemsetAsync(d_work, 0, sizeof(uint32_t), st);
         hipLaunchKernelGGL(lz4_compress_l2_kernel<true>, dim3((unsigned)std::min(n_items - n_g, resident_waves)), dim3(kWave), 0, st, d_src,
-                           d_items + n_g, n_items - n_g, d_item_check + n_g, d_slots, d_item_size + n_g, d_work);
+                           d_items + n_g, n_items - n_g, slot_stride, d_item_check + n_g, d_slots, d_item_size + n_g, d_work);
       }
       (void)hipEventRecord(ev_b, st2);
       (void)hipStreamWaitEvent(st, ev_b, 0);
@@ -957,10 +957,10 @@ void launch_lz4_compress(const uint8_t* d_src, const Item* d_items, int32_t n_it
   if (grid > n_items) grid = n_items;
   if (variant == 1)
     hipLaunchKernelGGL(lz4_compress_l2_kernel<false>, dim3((unsigned)grid), dim3(kWave), 0, st, d_src,
-                       d_items, n_items, d_item_check, d_slots, d_item_size, d_work);
+                       d_items, n_items, slot_stride, d_item_check, d_slots, d_item_size, d_work);
   else
     hipLaunchKernelGGL(lz4_compress_l2_kernel<true>, dim3((unsigned)grid), dim3(kWave), 0, st, d_src,
-                       d_items, n_items, d_item_check, d_slots, d_item_size, d_work);
+                       d_items, n_items, slot_stride, d_item_check, d_slots, d_item_size, d_work);
 }
 
 }  // namespace s3s

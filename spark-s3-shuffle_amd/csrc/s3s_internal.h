@@ -17,7 +17,11 @@
 namespace s3s {
 
 constexpr int kWave = 64;
-constexpr int kMaxBlock = 32768;          // largest codec chunk the LDS-resident kernels take
+constexpr int kMaxBlock = 32768;          // largest codec chunk the LDS-resident kernels take (Snappy; LZ4's default)
+constexpr int kLz4MaxBlock = 65536;       // largest LZ4 chunk of the map side (round 4): liblz4 parses inputs below 65 547 bytes
+                                          // with the SAME 8192 x u16 table (byU16) - positions just need all 16 bits - so the
+                                          // window engine takes them as it is; from 64 KiB + 11 on liblz4 switches to its
+                                          // 4096 x u32 table with a 5-byte hash: another parse, not built
 constexpr int kBatchMaxBlock = 1 << 25;   // largest LZ4Block frame the batch decoder takes (lz4-java's MAX_BLOCK_SIZE)
 constexpr int kSlotHeader = 32;           // bytes reserved in front of a slot's payload
 constexpr int kSlotBytes = kSlotHeader + kMaxBlock;
@@ -49,8 +53,9 @@ constexpr uint32_t kRawFlag = 0x80000000u;
 //   d_item_check: per-item xxHash32 workspace (written by the xxh32 pre-pass)
 //   variant 0: chunk staged in LDS (3 wavefronts/CU); 1: chunk read through L1/L2 (10/CU);
 //   2: as 1 plus the window-speculative parse (default)
+//   slot_stride: bytes between slots (kSlotHeader + the block size rounded up to 16)
 void launch_lz4_compress(const uint8_t* d_src, const Item* d_items, int32_t n_items,
-                         uint32_t* d_item_check, uint8_t* d_slots, uint32_t* d_item_size, uint32_t* d_work, int resident_waves,
+                         uint32_t* d_item_check, uint8_t* d_slots, int32_t slot_stride, uint32_t* d_item_size, uint32_t* d_work, int resident_waves,
                          int variant, hipStream_t st, hipEvent_t after_hash = nullptr);
 // Snappy: same for kItemSnappyChunk.
 bool snappy_compress_available();

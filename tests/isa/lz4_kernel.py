@@ -65,8 +65,8 @@ def program(windows=True, flags=()):
     return _PROGS[key]
 
 
-def compress_chunks(chunks, windows=True, flags=(), profile=None, lds_order=None, tail_guard=0, hooks=None):
-    """chunks: list of uint8 arrays (<= 32768 bytes each).  The source buffer ends exactly at the last chunk's
+def compress_chunks(chunks, windows=True, flags=(), profile=None, lds_order=None, tail_guard=0, hooks=None, block=32768):
+    """chunks: list of uint8 arrays (<= block bytes each; block <= 65536: the slot stride the host passes is 32 + block).  The source buffer ends exactly at the last chunk's
     last byte (+ tail_guard), so any read past a chunk that ends the allocation faults."""
     prog, entry = program(windows, flags)
     mem = emu.Memory()
@@ -77,6 +77,7 @@ def compress_chunks(chunks, windows=True, flags=(), profile=None, lds_order=None
     for k, c in enumerate(chunks):
         items += struct.pack("<qiiii", off, len(c), 0 | (5 << 8), k, 0)
         off += len(c)
+    K_SLOT_BYTES = K_SLOT_HEADER + ((block + 15) & ~15)
     slots = np.zeros(n * K_SLOT_BYTES, dtype=np.uint8)
     sizes = np.zeros(n, dtype=np.uint32)
     checks = np.arange(n, dtype=np.uint32) * np.uint32(0x01010101)
@@ -92,7 +93,7 @@ def compress_chunks(chunks, windows=True, flags=(), profile=None, lds_order=None
     waves = []
     for k in range(n):
         work[:] = 0
-        kernarg = struct.pack("<QQiiQQQQ", a_src, a_items + 24 * k, 1, 0, a_check + 4 * k, a_slots, a_sizes + 4 * k, a_work)
+        kernarg = struct.pack("<QQiiQQQQ", a_src, a_items + 24 * k, 1, K_SLOT_BYTES, a_check + 4 * k, a_slots, a_sizes + 4 * k, a_work)
         waves += emu.launch(prog, entry, mem, kernarg, 1, 16384, profile=profile, lds_order=lds_order, hooks=hooks)
         assert work[0] == 2, "the wavefront takes its block and then finds the counter exhausted"
     out = []

@@ -38,14 +38,16 @@ def _prog(src, needle):
     return _P[(src, needle)] + (_P[src][1],)
 
 
-def compress_map_output(parts, algo, dst_bytes, codec=1):
+def compress_map_output(parts, algo, dst_bytes, codec=1, block=None):
     """parts: list of bytes (one per partition, may be empty); dst_bytes: size of the destination (= dst_capacity);
     codec 1 = LZ4 (LZ4Block frames), 2 = Snappy (SnappyOutputStream chunks; snappy_compress_kernel, one workgroup per item).
     -> (status, image bytes, index list [n + 1], checksums list [n] or None)"""
     n = len(parts)
     snappy = codec == 2
+    BLOCK = block or globals()['BLOCK']  # (LZ4: up to 65536, spark.io.compression.lz4.blockSize; token level = ceil(log2) - 10)
+    LEVEL = max(0, (BLOCK - 1).bit_length() - 10)
     # a slot holds one chunk's codec output (codec_api.hip): kSlotBytes for LZ4, kSlotHeader + MaxCompressedLength rounded for Snappy
-    stride = 32 + ((32 + BLOCK + BLOCK // 6 + 15) & ~15) if snappy else lk.K_SLOT_BYTES
+    stride = 32 + ((32 + BLOCK + BLOCK // 6 + 15) & ~15) if snappy else 32 + ((BLOCK + 15) & ~15)
     src = np.frombuffer(b"".join(parts), dtype=np.uint8)
     items = bytearray()
     part_first = []
@@ -86,7 +88,7 @@ def compress_map_output(parts, algo, dst_bytes, codec=1):
         prog, entry, objs = _prog("lz4_compress.hip", "xxh32_items_wave_kernel")
         emu.launch(prog, entry, mem, struct.pack("<QQiIQ", a_src, a_items, n_items, SEED, a_check), n_items, 0, objects=objs)
         prog, entry, objs = _prog("lz4_compress.hip", "lz4_compress_l2_kernelILb1E")
-        emu.launch(prog, entry, mem, struct.pack("<QQiiQQQQ", a_src, a_items, n_items, 0, a_check, a_slots, a_size, a_work), 1, 16384,
+        emu.launch(prog, entry, mem, struct.pack("<QQiiQQQQ", a_src, a_items, n_items, stride, a_check, a_slots, a_size, a_work), 1, 16384,
                    objects=objs)
         assert int(work[0]) == n_items + 1
     prog, entry, objs = _prog("assemble.hip", "scan_items_kernel")

@@ -153,6 +153,32 @@ def test_block_size_option(gpu_codec, oracle):
             gpu_codec.set_option(1, 32768)
 
 
+def test_lz4_blocks_up_to_64k(gpu_codec, oracle):
+    """round 4: spark.io.compression.lz4.blockSize up to 64k on the map side (liblz4's 16-bit-table parse covers inputs below
+    65 547 bytes; the engine takes them as they are, the slot stride follows the block size): images, index and checksums equal
+    the oracle's at 40 000 / 49 152 / 65 536 bytes per block, they decode back (the batch decoder takes any block size), and
+    one byte more is S3S_E_UNSUPPORTED (liblz4's other parse: the JVM codec writes those)."""
+    import s3shuffle
+    from s3shuffle import datagen
+
+    rng = np.random.default_rng(65)
+    rag, roffs = corpus.ragged_map_output(rng, 11, 300_000)
+    tera, toffs = datagen.terasort_map_output(6 << 20, 7, seed=12)
+    wide, woffs = datagen.tpcds_wide_map_output(3 << 20, 5, seed=13)
+    try:
+        for bs in (40_000, 49_152, 65_536):
+            gpu_codec.set_option(1, bs)
+            for data, offs in ((rag, roffs), (tera, toffs), (wide, woffs)):
+                _check(gpu_codec, oracle, LZ4, CRC, data, offs, block_size=bs)
+            img, index, sums = gpu_codec.compress_map_output(LZ4, ADLER, tera, toffs)
+            assert np.array_equal(gpu_codec.decompress_range(LZ4, ADLER, img, index, sums), tera)
+        with pytest.raises(s3shuffle.CodecError) as ei:
+            gpu_codec.set_option(1, 65_537)
+        assert ei.value.code == -6
+    finally:
+        gpu_codec.set_option(1, 32768)
+
+
 def test_golden_fixtures(gpu_codec, oracle):
     """The committed fixtures (tests/golden/, assembled from liblz4 1.9.3 + zlib + xxhash without
     the oracle) must come out of the HIP path byte for byte: .data, .index and .checksum images."""

@@ -408,6 +408,39 @@ def test_whole_map_side_call_through_the_compiled_kernels(oracle):
     assert st == 0 and got == img.tobytes() and gs == [int(sums[0])]
 
 
+def test_lz4_blocks_up_to_64k_on_the_map_side(oracle):
+    """Round 4: spark.io.compression.lz4.blockSize up to 64k.  liblz4 parses every input below 65 547 bytes with the same
+    8192 x u16 table (byU16), so the compiled window engine and the general parse take 64 KiB blocks as they are - positions
+    use all 16 bits, the slot stride follows the block size (a kernel argument now).  Blocks of 65 536 / 60 000 / 40 000 bytes
+    through both parses against the oracle's restatement of LZ4_compress_default (pinned to liblz4 1.9.3 up to 65 536 bytes);
+    then a whole map-side call with 48 KiB and 64 KiB blocks (frames' token level 6, stored frames of incompressible blocks,
+    scan, gather, checksums) against the oracle's image."""
+    import lz4_kernel as lk
+    import map_side as ms
+
+    rng = np.random.default_rng(64)
+    from s3shuffle import datagen
+
+    tera, _ = datagen.terasort_map_output(1 << 20, 2, seed=3)
+    cases = [tera[:65536], tera[7:60007], corpus.chunk_corpus(3, 65536, rng), corpus.chunk_corpus(2, 40000, rng),
+             rng.integers(0, 256, 65536, dtype=np.uint8), np.zeros(65536, np.uint8), corpus.chunk_corpus(7, 65536, rng)]
+    for windows in (True, False):
+        got = lk.compress_chunks(cases, windows=windows, block=65536)
+        for c, (payload, hdr, _) in zip(cases, got):
+            want = oracle.lz4_compress_block(c)
+            if want.size >= c.size:
+                assert payload is None, (windows, c.size)  # stored frame
+            else:
+                assert payload is not None and payload.tobytes() == want.tobytes(), (windows, c.size, want.size)
+    parts = [tera[:150_000].tobytes(), b"", rng.integers(0, 256, 70_000, dtype=np.uint8).tobytes(), corpus.chunk_corpus(7, 65537, rng).tobytes()]
+    data = np.frombuffer(b"".join(parts), np.uint8)
+    offs = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int64)
+    for block in (49152, 65536):
+        img, idx, sums = oracle.compress_map_output(1, 1, data, offs, block)
+        st, image, gi, gs = ms.compress_map_output(parts, 1, img.size, codec=1, block=block)
+        assert st == 0 and image == img.tobytes() and gi == list(idx) and gs == [int(x) for x in sums], block
+
+
 def test_whole_reduce_side_call_through_the_compiled_kernels(oracle):
     """the other direction: the .data image of a map output (written by the oracle) as one fetched batch range — per-partition
     checksums (compiled checksum kernels) equal the stored ones, the compiled frame discovery finds every LZ4Block frame, the

@@ -82,7 +82,7 @@ def test_reduce_side_on_its_own_and_the_zstd_gate(patched_tree):
         assert needle in body, needle
     assert 'val gpuReadCodec: String = if (gpuEnabled) gpuCodec else conf.get("spark.io.compression.codec", "lz4")' in disp
     # the write-side gate is unchanged: blocks above 32k and zstd / lzf keep the JVM codecs there
-    assert "val blockSupported = blockSize >= 64 && blockSize <= 32768" in disp and 'val supported = gpuCodec == "lz4" || gpuCodec == "snappy"' in disp
+    assert 'val blockMax = if (gpuCodec == "lz4") 65536L else 32768L' in disp and "val blockSupported = blockSize >= 64 && blockSize <= blockMax" in disp and 'val supported = gpuCodec == "lz4" || gpuCodec == "snappy"' in disp
     dec = _read(SHIM, "S3GpuBlockDecoder.scala")
     assert "S3SCodec.decodeCodecId(dispatcher.gpuReadCodec)" in dec
     assert "r1 - r0 >= d.gpuZstdMinPartitions" in dec and "<= d.gpuZstdMaxFrameBytes" in dec

@@ -1,7 +1,7 @@
 #!/bin/bash
 mkdir -p gpurun_out/$1
-timeout 600 python -m pytest tests/test_gpu_zstd.py tests/test_gpu_hardening.py -x -q -m gpu > gpurun_out/$1/pytest.txt 2>&1
+timeout 900 python -m pytest tests/test_gpu_compress.py tests/test_gpu_batch.py tests/test_gpu_host_batch.py tests/test_gpu_fullsize.py -x -q -m gpu > gpurun_out/$1/pytest.txt 2>&1
 tail -5 gpurun_out/$1/pytest.txt
-python bench.py --workload terasort-10g-200p-zstd --direction decompress --maps-per-gpu 8 --steps 8 --warmup 3 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "
+for i in 1 2; do python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "
 import sys,json
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('zstd', d['value'], d['ms_per_step'])"
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('headline', d['value'], d['ms_per_step'])"; done
