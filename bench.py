@@ -766,6 +766,7 @@ SECONDARY = [
     ("skew-1gib-lz4:compress", "skew-1part-lz4", "compress", 1024, 1),
     ("skew-1gib-lz4:decompress", "skew-1part-lz4", "decompress", 1024, 1),
     ("terasort-200p-zstd:decompress", "terasort-10g-200p-zstd", "decompress", 128, 8),  # frames in flight are its throughput
+    ("tpcds-wide-zstd:decompress", "tpcds-wide-100g-200p-zstd", "decompress", 128, 8),  # 3.3 x the sequences per byte: the decoder's weak side, reported
     ("terasort-200p-lz4-256k-blocks:decompress", "terasort-10g-200p-lz4-256k", "decompress", 128, 4),  # round 4: frames above 32 KiB, batch decoder
 ]
 
