@@ -48,6 +48,7 @@ constexpr int kMaxBlock = 1 << 17;
 constexpr int kHufLogMax = 11;
 constexpr int kLLLogMax = 9, kMLLogMax = 9, kOFLogMax = 8;
 constexpr int kRing = 4096, kLitW = 1024;
+constexpr uint32_t kWaveLanes = 64;
 
 // The Huffman side of a partition (round 4: its own wavefront on the device, see literal_side): the literals table and the
 // scratch its description is read through.
@@ -84,6 +85,21 @@ struct Work {
   // global memory (a global source would need the stores of the sequences before it to have completed: ~1 us each)
   uint8_t ring[kRing];
   uint8_t litw[kLitW];             // window over the block's literals, refilled 1 KiB at a time
+#ifdef S3S_ZSTD_DEVICE
+  // what the compiled sequence loop hands to the lean one and gets back (seq_fast below)
+  struct Fast {
+    const uint8_t* bits;           // the block's sequence bit stream
+    uint8_t* bdst;                 // where the block's output starts
+    int32_t bits_size, pos, cbase;
+    uint32_t cache_lo, cache_hi;
+    uint32_t sl, so, sm, rep0, rep1, rep2;
+    uint32_t i, nseq;              // next sequence, sequences of the block
+    uint32_t lit_pos, bout, regen, bcap, rq0;
+    int32_t litw_base;
+    uint32_t visible;              // bytes of the block behind which a fence has been issued (far match sources)
+    uint32_t hist_lo, hist_hi;     // bytes of the frame in front of the block
+  } fast;
+#endif
 };
 
 struct Lanes {  // who am I in the wavefront (host: lane 0 of 1)
@@ -748,6 +764,146 @@ ZS_HD int pipe_wait_ready(LitPipe& lp, int32_t want) {
 }
 #endif
 
+#ifdef S3S_ZSTD_DEVICE
+// ---- the lean sequence loop (device, round 4) ------------------------------------------------------------------------------------
+// The sequence loop of decode_frame carries the whole frame's state, and hipcc - which cannot prove anything uniform that came
+// through a flat pointer - turns it into ~300 instructions per sequence, most of them vector instructions under exec masks; the
+// kernel is bound by instruction issue, so that IS its speed.  This function is the same loop for the common case only, out of
+// line (its own register allocation: nothing of the frame is live in it), with LDS and global pointers typed as such and every
+// loaded value declared uniform: the scalar unit does the decoding, the vector unit only the copies.  It takes sequences for as
+// long as they are plain - at most 57 bits, window inside the stream, literal run inside the literal window and at most 64
+// bytes, match source not overlapping its own output (in the ring or, fenced, in memory), nothing wrong with it - and stops IN FRONT of the
+// first one that is not (or of the block's last sequence): the compiled loop does that one, with all its checks, its error codes
+// and its slow paths, and calls again.  State is committed per sequence, so stopping costs nothing but the call.
+typedef __attribute__((address_space(3))) Work* WorkLds;
+typedef __attribute__((address_space(1))) const uint8_t* GlobalIn;
+typedef __attribute__((address_space(1))) uint8_t* GlobalOut;
+__device__ __attribute__((noinline)) void seq_fast(WorkLds w, int lane) {
+  const GlobalIn bits = (GlobalIn)w->fast.bits;
+  const GlobalOut bdst = (GlobalOut)w->fast.bdst;
+  const int32_t bits_size = (int32_t)ZS_UNI32(w->fast.bits_size);
+  int32_t pos = (int32_t)ZS_UNI32(w->fast.pos), cbase = (int32_t)ZS_UNI32(w->fast.cbase);
+  uint64_t cache = (uint64_t)ZS_UNI32(w->fast.cache_lo) | ((uint64_t)ZS_UNI32(w->fast.cache_hi) << 32);
+  uint32_t sl = ZS_UNI32(w->fast.sl), so = ZS_UNI32(w->fast.so), sm = ZS_UNI32(w->fast.sm);
+  uint32_t rep0 = w->fast.rep0, rep1 = w->fast.rep1, rep2 = w->fast.rep2;  // (vector registers: see the loop)
+  uint32_t i = ZS_UNI32(w->fast.i);
+  const uint32_t nseq = ZS_UNI32(w->fast.nseq);
+  uint32_t lit_pos = ZS_UNI32(w->fast.lit_pos), bout = ZS_UNI32(w->fast.bout);
+  const uint32_t regen = ZS_UNI32(w->fast.regen), bcap = ZS_UNI32(w->fast.bcap), rq0 = ZS_UNI32(w->fast.rq0);
+  const int32_t litw_base = (int32_t)ZS_UNI32(w->fast.litw_base);
+  const uint32_t litw_at = litw_base < 0 ? 0x40000000u : (uint32_t)litw_base;
+  uint32_t visible = ZS_UNI32(w->fast.visible);
+  const uint64_t hist = (uint64_t)ZS_UNI32(w->fast.hist_lo) | ((uint64_t)ZS_UNI32(w->fast.hist_hi) << 32);
+  const uint32_t hist30 = hist > 0x3fffffffull ? 0x3fffffffu : (uint32_t)hist;  // (history beyond 1 GiB: no offset reaches further)
+  while (i + 1 < nseq) {
+    const uint32_t el = w->ll[sl], eo = w->of[so], em = w->ml[sm];  // (uniform, but left in vector registers: the field
+    const uint32_t vl = w->llv[sl], vm = w->mlv[sm];                // arithmetic below then runs on the vector unit, the checks on the scalar one)
+    const uint32_t co = eo >> 24, bm = vm >> 24, bl = vl >> 24;
+    const uint32_t nl = (el >> 16) & 0xff, nm = (em >> 16) & 0xff, no = (eo >> 16) & 0xff;
+    const uint32_t nb = ZS_UNI32(co + bm + bl + nl + nm + no);
+    if (ZS_UNI32(co) > 31 || nb > 57) break;
+    if (!(pos - (int32_t)nb >= cbase && pos <= cbase + 64)) {  // the window whose top byte holds the cursor
+      const int32_t b0 = ((pos - 1) >> 3) - 7;
+      if (b0 < 0 || b0 + 8 > bits_size) break;  // (the stream's first and last bytes: the compiled loop's zero fill)
+      uint32_t lo, hi;
+      __builtin_memcpy(&lo, (const void*)(bits + b0), 4);
+      __builtin_memcpy(&hi, (const void*)(bits + b0 + 4), 4);
+      cache = (uint64_t)ZS_UNI32(lo) | ((uint64_t)ZS_UNI32(hi) << 32);
+      cbase = b0 * 8;
+    }
+    const int32_t npos = pos - (int32_t)nb;
+    if (npos < 0) break;
+    const uint32_t sh = (uint32_t)(npos - cbase);  // 0 .. 64
+    const uint64_t fb = sh < 64 ? cache >> sh : 0;
+    uint32_t rem = nb;
+    auto take = [&](uint32_t n) -> uint32_t {
+      rem -= n;
+      return (uint32_t)(fb >> rem) & ((1u << n) - 1u);
+    };
+    const uint32_t ov = take(co);
+    const uint32_t mlen = ZS_UNI32((vm & 0xFFFFFFu) + take(bm));
+    const uint32_t llen = ZS_UNI32((vl & 0xFFFFFFu) + take(bl));
+    const uint32_t nsl = ZS_UNI32((el & 0xFFFFu) + take(nl)), nsm = ZS_UNI32((em & 0xFFFFu) + take(nm)), nso = ZS_UNI32((eo & 0xFFFFu) + take(no));
+    const uint32_t oval = (1u << co) + ov;
+    // (the repeat-offset history too is vector arithmetic on values every lane holds: the two units share the work, and this
+    //  kernel is bound by what they can issue.  rep0..2 live in vector registers; the offset comes back to the scalar side.)
+    const bool is_rep = oval <= 3;
+    const uint32_t idx = oval - 1 + (llen == 0 ? 1u : 0u);
+    uint32_t rv = rep0;
+    rv = idx == 1 ? rep1 : rv;
+    rv = idx == 2 ? rep2 : rv;
+    rv = idx == 3 ? rep0 - 1 : rv;
+    const uint32_t offset_v = is_rep ? rv : oval - 3;
+    const bool change = !is_rep || idx != 0, deep = !is_rep || idx >= 2;
+    const uint32_t n2 = deep ? rep1 : rep2, n1 = change ? rep0 : rep1, n0 = change ? offset_v : rep0;
+    const uint32_t offset = ZS_UNI32(offset_v);
+    const uint32_t reach = bout + llen, nbout = reach + mlen;
+    // plain enough?  (anything wrong with the sequence is "not plain": the compiled loop names the error.)  Every condition is
+    // a difference whose sign bit says "no" - one OR chain and one branch instead of a compare, a select and a branch each; all
+    // quantities are below 2^30 here except an offset out of range, which then reads as "no" too.
+    const uint32_t lrel = lit_pos - litw_at;  // (no window loaded: litw_at is 2^30, lrel wraps to something huge)
+    const uint32_t lit_no = (64u - llen) | lrel | ((uint32_t)kLitW - (lrel + llen));
+    const uint32_t no_bits = (llen != 0 ? lit_no : 0u) | (offset - 1u) | (offset - mlen) | (regen - (lit_pos + llen)) |
+                             ((uint32_t)kMaxBlock - nbout) | (bcap - nbout) | (reach + hist30 - offset);
+    const bool plain = (int32_t)no_bits >= 0;
+    if (!plain) break;
+    const uint32_t rq = rq0 + bout;
+    if ((uint32_t)lane < llen) {
+      const uint8_t v = w->litw[lrel + (uint32_t)lane];
+      w->ring[(rq + (uint32_t)lane) & (kRing - 1)] = v;
+      bdst[bout + (uint32_t)lane] = v;
+    }
+    const uint32_t rqm = rq0 + reach;
+    if (offset <= (uint32_t)kRing && offset + mlen <= (uint32_t)kRing) {  // the source is still in the ring
+      const uint32_t rs = rqm - offset;
+      for (uint32_t j = (uint32_t)lane; j < mlen; j += kWaveLanes) {
+        const uint8_t v = w->ring[(rs + j) & (kRing - 1)];
+        w->ring[(rqm + j) & (kRing - 1)] = v;
+        bdst[reach + j] = v;
+      }
+    } else {  // from memory (two thirds of a level-1 TeraSort frame's matches): what was stored since the last fence must have landed
+      if (offset < nbout - visible) {  // (the source ends at reach - offset + mlen; it does not overlap its output here)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        visible = reach;
+      }
+      const GlobalIn from = (GlobalIn)bdst + ((int64_t)reach - (int64_t)offset);
+      for (uint32_t j = (uint32_t)lane; j < mlen; j += kWaveLanes) {
+        const uint8_t v = from[j];
+        w->ring[(rqm + j) & (kRing - 1)] = v;
+        bdst[reach + j] = v;
+      }
+    }
+    rep2 = n2;
+    rep1 = n1;
+    rep0 = n0;
+    sl = nsl;
+    sm = nsm;
+    so = nso;
+    pos = npos;
+    lit_pos += llen;
+    bout = nbout;
+    i++;
+  }
+  if (lane == 0) {
+    w->fast.pos = pos;
+    w->fast.cbase = cbase;
+    w->fast.cache_lo = (uint32_t)cache;
+    w->fast.cache_hi = (uint32_t)(cache >> 32);
+    w->fast.sl = sl;
+    w->fast.so = so;
+    w->fast.sm = sm;
+    w->fast.rep0 = rep0;
+    w->fast.rep1 = rep1;
+    w->fast.rep2 = rep2;
+    w->fast.i = i;
+    w->fast.lit_pos = lit_pos;
+    w->fast.bout = bout;
+    w->fast.visible = visible;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+}
+#endif
+
 // Decodes (execute = true) or only sizes (execute = false) the frame at src[0, size).  dst = where this frame's output
 // starts (history never reaches in front of it), cap = bytes available there.  lit_buf: literal scratch — the host model
 // decodes a block's Huffman literals right here into lit_buf (kMaxBlock + 32 bytes, lit_stride 0); on the device they come
@@ -923,7 +1079,63 @@ ZS_HD int decode_frame(Work& w, LitPipe& lp, const uint8_t* src, int64_t size, u
         if (!bitr_init(r, b, bend - b)) return ZS_FAIL();
         uint32_t sl = bitr_read(r, w.ll_log), so = bitr_read(r, w.of_log), sm = bitr_read(r, w.ml_log);
         if (r.pos < 0) return ZS_FAIL();
+#ifdef S3S_ZSTD_DEVICE
+        int fast_pause = 0;  // sequences to take here before the lean loop is tried again (it made no progress last time)
+#endif
         for (int64_t i = 0; i < nseq; i++) {
+#ifdef S3S_ZSTD_DEVICE
+          if (execute && lit_rle < 0 && i + 1 < nseq) {  // plain sequences: the lean loop (seq_fast), this one takes the rest
+            if (fast_pause > 0) {
+              fast_pause--;
+            } else {
+              Work::Fast& f = w.fast;
+              f.bits = r.p;
+              f.bdst = bdst;
+              f.bits_size = r.size;
+              f.pos = r.pos;
+              f.cbase = r.cbase;
+              f.cache_lo = (uint32_t)r.cache;
+              f.cache_hi = (uint32_t)(r.cache >> 32);
+              f.sl = sl;
+              f.so = so;
+              f.sm = sm;
+              f.rep0 = rep0;
+              f.rep1 = rep1;
+              f.rep2 = rep2;
+              f.i = (uint32_t)i;
+              f.nseq = (uint32_t)nseq;
+              f.lit_pos = lit_pos;
+              f.bout = bout;
+              f.regen = regen32;
+              f.bcap = bcap;
+              f.rq0 = rq0;
+              f.litw_base = litw_base;
+              f.visible = visible;
+              f.hist_lo = (uint32_t)(uint64_t)bop;
+              f.hist_hi = (uint32_t)((uint64_t)bop >> 32);
+              __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+              seq_fast((WorkLds)&w, L.lane);
+              const uint32_t ni = ZS_UNI32(f.i);
+              if (ni == (uint32_t)i) {
+                fast_pause = 3;
+              } else {
+                i = ni;
+                r.pos = (int32_t)ZS_UNI32(f.pos);
+                r.cbase = (int32_t)ZS_UNI32(f.cbase);
+                r.cache = (uint64_t)ZS_UNI32(f.cache_lo) | ((uint64_t)ZS_UNI32(f.cache_hi) << 32);
+                sl = ZS_UNI32(f.sl);
+                so = ZS_UNI32(f.so);
+                sm = ZS_UNI32(f.sm);
+                rep0 = ZS_UNI32(f.rep0);
+                rep1 = ZS_UNI32(f.rep1);
+                rep2 = ZS_UNI32(f.rep2);
+                lit_pos = ZS_UNI32(f.lit_pos);
+                bout = ZS_UNI32(f.bout);
+                visible = ZS_UNI32(f.visible);
+              }
+            }
+          }
+#endif
           const uint32_t el = ZS_UNI32(w.ll[sl]), eo = ZS_UNI32(w.of[so]), em = ZS_UNI32(w.ml[sm]);
           const uint32_t vl = ZS_UNI32(w.llv[sl]), vm = ZS_UNI32(w.mlv[sm]);
           const int co = (int)(eo >> 24);

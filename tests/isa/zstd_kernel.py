@@ -26,8 +26,9 @@ def program():
         for line in text.splitlines():
             if ".amdhsa_group_segment_fixed_size" in line:
                 lds = max(lds, int(line.split()[-1]))
-        # (the frame checksum's hash is a rare path hipcc is told to keep out of line: zstd_decode_core.h ZS_RARE)
-        callees = [ln.split(':')[0] for ln in text.splitlines() if ln.startswith('_ZN8s3s_zstd13xxh64_content') and ':' in ln]
+        # (device functions hipcc keeps out of line: the frame checksum's hash - a rare path, ZS_RARE - and the lean sequence loop seq_fast)
+        import re as _re
+        callees = [m.group(1) for m in _re.finditer(r'^\s*\.type\s+(_ZN8s3s_zstd\w+),@function', text, _re.M) if m.group(1) != entry]
         _PROG = (emu.Program(text, entry, callees=callees), entry, text, lds)
     return _PROG
 
