@@ -801,20 +801,21 @@ __device__ __attribute__((noinline)) void seq_fast(WorkLds w, int lane) {
     const uint32_t co = eo >> 24, bm = vm >> 24, bl = vl >> 24;
     const uint32_t nl = (el >> 16) & 0xff, nm = (em >> 16) & 0xff, no = (eo >> 16) & 0xff;
     const uint32_t nb = ZS_UNI32(co + bm + bl + nl + nm + no);
-    if (ZS_UNI32(co) > 31 || nb > 57) break;
-    if (!(pos - (int32_t)nb >= cbase && pos <= cbase + 64)) {  // the window whose top byte holds the cursor
+    // (conditions as sign bits of differences, see "plain" below)
+    if ((int32_t)((31u - ZS_UNI32(co)) | (57u - nb)) < 0) break;
+    const int32_t npos = pos - (int32_t)nb;
+    if (((npos - cbase) | (cbase + 64 - pos)) < 0) {  // the cursor's window is not the cached one: the window whose top byte holds it
       const int32_t b0 = ((pos - 1) >> 3) - 7;
-      if (b0 < 0 || b0 + 8 > bits_size) break;  // (the stream's first and last bytes: the compiled loop's zero fill)
+      if ((b0 | (bits_size - 8 - b0)) < 0) break;  // (the stream's first and last bytes: the compiled loop's zero fill)
       uint32_t lo, hi;
       __builtin_memcpy(&lo, (const void*)(bits + b0), 4);
       __builtin_memcpy(&hi, (const void*)(bits + b0 + 4), 4);
       cache = (uint64_t)ZS_UNI32(lo) | ((uint64_t)ZS_UNI32(hi) << 32);
       cbase = b0 * 8;
     }
-    const int32_t npos = pos - (int32_t)nb;
-    if (npos < 0) break;
-    const uint32_t sh = (uint32_t)(npos - cbase);  // 0 .. 64
-    const uint64_t fb = sh < 64 ? cache >> sh : 0;
+    // (npos < 0 - the stream read below its first bit - is one of the "no" bits below; the shift is 64 only when the sequence
+    //  has no bits at all, and then nothing is taken from fb)
+    const uint64_t fb = cache >> ((uint32_t)(npos - cbase) & 63u);
     uint32_t rem = nb;
     auto take = [&](uint32_t n) -> uint32_t {
       rem -= n;
@@ -843,7 +844,7 @@ __device__ __attribute__((noinline)) void seq_fast(WorkLds w, int lane) {
     // quantities are below 2^30 here except an offset out of range, which then reads as "no" too.
     const uint32_t lrel = lit_pos - litw_at;  // (no window loaded: litw_at is 2^30, lrel wraps to something huge)
     const uint32_t lit_no = (64u - llen) | lrel | ((uint32_t)kLitW - (lrel + llen));
-    const uint32_t no_bits = (llen != 0 ? lit_no : 0u) | (offset - 1u) | (offset - mlen) | (regen - (lit_pos + llen)) |
+    const uint32_t no_bits = (uint32_t)npos | (llen != 0 ? lit_no : 0u) | (offset - 1u) | (offset - mlen) | (regen - (lit_pos + llen)) |
                              ((uint32_t)kMaxBlock - nbout) | (bcap - nbout) | (reach + hist30 - offset);
     const bool plain = (int32_t)no_bits >= 0;
     if (!plain) break;
