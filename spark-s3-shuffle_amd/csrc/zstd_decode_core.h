@@ -422,22 +422,28 @@ ZS_HD int huf_decode_stream(const HufWork& w, const uint8_t* p, int64_t size, ui
   // table lookups, one 4-byte store - instead of a refill check and a byte store per symbol.  pos >= 64 keeps the window inside the
   // stream (no zero fill below its first byte); the last symbols of a stream take the loop below.
   {
-    const uint32_t mask = (1u << log) - 1u;
-    while (i + 4 <= n && r.pos >= 64) {
+    const int32_t n4 = (int32_t)n - 3;  // (a stream regenerates at most 128 KiB: 32-bit counters)
+    const int up = 32 - log;
+    int32_t i4 = 0;
+    while (i4 < n4 && r.pos >= 64) {
       const int32_t b0 = ((r.pos - 1) >> 3) - 7;
       uint64_t cache;
       memcpy(&cache, r.p + b0, 8);
-      int32_t rel = r.pos - b0 * 8;  // 57 .. 64 bits below the cursor
-      uint32_t out4 = 0;
+      const int32_t rel = r.pos - b0 * 8;  // 57 .. 64 bits below the cursor
+      uint64_t top = cache << (64 - rel);  // the unread bits, left-aligned: a code is the top `log` bits of the high word
+      uint32_t out4 = 0, used = 0;
       for (int k = 0; k < 4; k++) {  // (unrolled by both compilers)
-        const uint16_t e = w.huf[(uint32_t)(cache >> (rel - log)) & mask];
-        rel -= e & 0xff;
+        const uint16_t e = w.huf[(uint32_t)(top >> 32) >> up];
+        const uint32_t nbits = e & 0xff;
+        top <<= nbits;
+        used += nbits;
         out4 |= (uint32_t)(e >> 8) << (8 * k);
       }
-      r.pos = b0 * 8 + rel;
-      memcpy(dst + i, &out4, 4);
-      i += 4;
+      r.pos -= (int32_t)used;
+      memcpy(dst + i4, &out4, 4);
+      i4 += 4;
     }
+    i = i4;
     r.cbase = 1 << 30;  // (the per-symbol loop refills its own window)
   }
 #endif
