@@ -422,10 +422,10 @@ ZS_HD int huf_decode_stream(const HufWork& w, const uint8_t* p, int64_t size, ui
   // table lookups, one 4-byte store - instead of a refill check and a byte store per symbol.  pos >= 64 keeps the window inside the
   // stream (no zero fill below its first byte); the last symbols of a stream take the loop below.
   {
-    const int32_t n4 = (int32_t)n - 3;  // (a stream regenerates at most 128 KiB: 32-bit counters)
+    const int32_t n5 = (int32_t)n - 4;  // (a stream regenerates at most 128 KiB: 32-bit counters)
     const int up = 32 - log;
     int32_t i4 = 0;
-    while (i4 < n4 && r.pos >= 64) {
+    while (i4 < n5 && r.pos >= 64) {  // FIVE symbols per window: five codes take at most 55 of the >= 57 bits below the cursor
       const int32_t b0 = ((r.pos - 1) >> 3) - 7;
       uint64_t cache;
       memcpy(&cache, r.p + b0, 8);
@@ -439,9 +439,12 @@ ZS_HD int huf_decode_stream(const HufWork& w, const uint8_t* p, int64_t size, ui
         used += nbits;
         out4 |= (uint32_t)(e >> 8) << (8 * k);
       }
+      const uint16_t e5 = w.huf[(uint32_t)(top >> 32) >> up];
+      used += e5 & 0xff;
       r.pos -= (int32_t)used;
       memcpy(dst + i4, &out4, 4);
-      i4 += 4;
+      dst[i4 + 4] = (uint8_t)(e5 >> 8);
+      i4 += 5;
     }
     i = i4;
     r.cbase = 1 << 30;  // (the per-symbol loop refills its own window)
