@@ -50,6 +50,7 @@ WORKLOADS = {
     "skew-1part-lz4": ("skew", 1, "lz4", "adler32"),                  # configs[4] (use --direction decompress)
     "terasort-10g-200p-zstd": ("terasort", 200, "zstd", "adler32"),   # reduce side only (--direction decompress)
     "tpcds-wide-100g-200p-zstd": ("tpcds", 200, "zstd", "adler32"),   # the same for wide rows (more sequences per byte, treeless blocks)
+    "terasort-100g-2000p-zstd": ("terasort", 2000, "zstd", "adler32"),  # 64 KiB frames: one block each (the literal wavefront cannot run ahead)
     # objects of a JVM writer with spark.io.compression.lz4.blockSize=256k (S3ShuffleReader.scala:57-59): reduce side only
     "terasort-10g-200p-lz4-256k": ("terasort", 200, "lz4", "adler32"),
 }
