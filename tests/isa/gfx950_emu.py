@@ -1380,6 +1380,14 @@ class Program:
         hi = sh(half(b, sel_hi[1]), half(a, sel_hi[0]))
         w.wv32(i.ops[0], lo | (hi << np.uint32(16)))
 
+    def x_v_pk_mov_b32(self, w, i):
+        # D[0] = S0[op_sel[0]], D[1] = S1[op_sel_hi[1]] (dwords of the 64-bit sources; defaults op_sel [0,0], op_sel_hi [1,1])
+        sel_lo, sel_hi = self._pk_sel(i, "op_sel", [0, 0]), self._pk_sel(i, "op_sel_hi", [1, 1])
+        s0, s1 = w.rv64(i.ops[1]), w.rv64(i.ops[2])
+        lo = ((s0 >> np.uint64(32 * sel_lo[0])) & np.uint64(M32)).astype(np.uint64)
+        hi = ((s1 >> np.uint64(32 * sel_hi[1])) & np.uint64(M32)).astype(np.uint64)
+        w.wv64(i.ops[0], lo | (hi << np.uint64(32)))
+
     def x_v_pk_lshlrev_b16(self, w, i):
         self._pk_shift(w, i, True)
 
