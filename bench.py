@@ -54,6 +54,7 @@ WORKLOADS = {
     # objects of a JVM writer with spark.io.compression.lz4.blockSize=256k (S3ShuffleReader.scala:57-59): reduce side only
     "terasort-10g-200p-lz4-256k": ("terasort", 200, "lz4", "adler32"),
 }
+WORKLOADS["terasort-10g-200p-lzf"] = ("terasort", 200, "lzf", "adler32")  # spark.io.compression.codec=lzf: reduce side only
 JVM_LZ4_BLOCK = {"terasort-10g-200p-lz4-256k": 262144}  # workloads whose inputs are LZ4Block images written by liblz4 on the host
 
 
@@ -89,6 +90,51 @@ def jvm_lz4_map_output_image(data, offs, algo_name: str, block_size: int):
     index = np.concatenate([[0], np.cumsum([len(x) for x in streams])]).astype(np.int64)
     f = zlib.adler32 if algo_name == "adler32" else zlib.crc32
     return img, index, np.array([f(x) for x in streams], np.int64)
+
+
+def lzf_map_output_image(data, offs, algo_name: str):
+    """(.data image, index, checksums) of one map task under LZFCompressionCodec: what compress-lzf's LZFOutputStream writes per
+    partition (chunks of <= 65 535 bytes around liblzf blocks), built by liblzf 3.6 itself through the image's conda python3.9
+    (tests/golden/make_lzf_golden.py --streams) — third-party library as input generator, like libzstd above; decode only."""
+    import struct
+    import subprocess
+    import zlib
+
+    blob = b"".join(struct.pack("<Q", int(offs[p + 1] - offs[p])) + data[offs[p]:offs[p + 1]].tobytes() for p in range(len(offs) - 1))
+    r = subprocess.run(["/opt/conda/bin/python3.9", os.path.join(ROOT, "tests", "golden", "make_lzf_golden.py"), "--streams"],
+                       input=blob, capture_output=True, check=True).stdout
+    streams, pos = [], 0
+    while pos < len(r):
+        (n,) = struct.unpack_from("<Q", r, pos)
+        streams.append(r[pos + 8:pos + 8 + n])
+        pos += 8 + n
+    assert len(streams) == len(offs) - 1
+    img = np.frombuffer(b"".join(streams), np.uint8)
+    index = np.concatenate([[0], np.cumsum([len(x) for x in streams])]).astype(np.int64)
+    f = zlib.adler32 if algo_name == "adler32" else zlib.crc32
+    return img, index, np.array([f(x) for x in streams], np.int64)
+
+
+def cpu_baseline_lzf_decompress(workload: str, target_s: float, map_mib: int):
+    """The host beside the LZF line: per-partition Adler32 validation + the chunk walk + a plain C restatement of liblzf's
+    lzf_decompress (oracle/s3s_oracle_lzf.c: liblzf itself is reachable only through a python module here), one fetched
+    range per thread — kind "port"."""
+    from oracle import binding as oracle
+
+    gen, nparts, codec, algo = WORKLOADS[workload]
+    cores = usable_cores()
+    data, offs = make_map_output(workload, 0, min(map_mib, 256) << 20)
+    img, index, sums = lzf_map_output_image(data, offs, algo)
+    s1, n = oracle.mt_decompress_bench(oracle.CODEC_LZF, oracle.CHECKSUM_ADLER32, img, index, sums, data.size, cores, reps=1, use_liblz4=False)
+    if s1 < 0 or n != data.size:
+        return None
+    reps = max(1, min(2000, int(target_s / max(s1, 1e-3))))
+    s, _ = oracle.mt_decompress_bench(oracle.CODEC_LZF, oracle.CHECKSUM_ADLER32, img, index, sums, data.size, cores, reps=reps, use_liblz4=False)
+    t1, _ = oracle.mt_decompress_bench(oracle.CODEC_LZF, oracle.CHECKSUM_ADLER32, img, index, sums, data.size, 1, reps=2, use_liblz4=False)
+    return {"value": round(data.size * cores * reps / s / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
+            "sample": f"{cores} threads x {reps} reps x one whole {min(map_mib, 256)} MiB map task ({nparts} partitions), Adler32 validation + "
+                      f"compress-lzf chunk walk + C restatement of liblzf 3.6 lzf_decompress; os.cpu_count()={os.cpu_count()}, limit={cores}",
+            "single_thread_GBps": round(data.size * 2 / t1 / 1e9, 3), "wall_s": round(s, 2)}
 
 
 # ---- Zstandard inputs (reduce side only): the map outputs a JVM writer produces with spark.io.compression.codec=zstd ----
@@ -226,6 +272,7 @@ def parse_args():
                          "them as `secondary` to the JSON line (default: on for the plain N=1 headline command)")
     ap.add_argument("--no-secondary", dest="secondary", action="store_false")
     ap.add_argument("--host-path-only", action="store_true", help="run only the host-buffer leg (run_host_path) and print it")
+    ap.add_argument("--hbm-stages-only", action="store_true", help="run only the HBM-bound stage lines (run_hbm_stages) and print them")
     ap.add_argument("--dry-run", action="store_true",
                     help="no timing: every rank reports (rank, local rank, device, its map ids); rank 0 checks that "
                          "mapId %% nGPU covers every map task exactly once and prints the table as one JSON line "
@@ -417,10 +464,10 @@ def run_workload(args, rank: int, local_rank: int, world: int, dist):
     from s3shuffle import sharding
 
     gen, nparts, codec_name, algo_name = WORKLOADS[args.workload]
-    codec_id = {"lz4": s3shuffle.CODEC_LZ4, "snappy": s3shuffle.CODEC_SNAPPY, "zstd": s3shuffle.CODEC_ZSTD}[codec_name]
+    codec_id = {"lz4": s3shuffle.CODEC_LZ4, "snappy": s3shuffle.CODEC_SNAPPY, "zstd": s3shuffle.CODEC_ZSTD, "lzf": s3shuffle.CODEC_LZF}[codec_name]
     algo_id = {"adler32": s3shuffle.CHECKSUM_ADLER32, "crc32": s3shuffle.CHECKSUM_CRC32}[algo_name]
-    if codec_name == "zstd" and args.direction != "decompress":
-        raise SystemExit("zstd is decode-only on the GPU path (compression stays on the JVM codec): use --direction decompress")
+    if codec_name in ("zstd", "lzf") and args.direction != "decompress":
+        raise SystemExit("zstd / lzf are decode-only on the GPU path (compression stays on the JVM codec): use --direction decompress")
 
     # ---- this rank's shard: map tasks with mapId % nGPU == rank --------------------------------
     map_ids = sharding.map_ids_for_rank(rank, world, args.maps_per_gpu)
@@ -450,12 +497,14 @@ def run_workload(args, rank: int, local_rank: int, world: int, dist):
     jvm_block = JVM_LZ4_BLOCK.get(args.workload)
     if jvm_block and args.direction != "decompress":
         raise SystemExit("LZ4 blocks above 32 KiB are decoded, not written, by the GPU path: use --direction decompress")
-    if codec_name == "zstd" or jvm_block:  # the JVM-written objects: built on the host with libzstd / liblz4 (input generation, untimed)
+    if codec_name in ("zstd", "lzf") or jvm_block:  # the JVM-written objects: built on the host with libzstd / liblz4 (input generation, untimed)
         zstd_images = [None] * len(outputs)
 
         def _zimg(i):
             if jvm_block:
                 zstd_images[i] = jvm_lz4_map_output_image(outputs[i][0], outputs[i][1], algo_name, jvm_block)
+            elif codec_name == "lzf":
+                zstd_images[i] = lzf_map_output_image(outputs[i][0], outputs[i][1], algo_name)
             else:
                 zstd_images[i] = zstd_map_output_image(outputs[i][0], outputs[i][1], algo_name)
 
@@ -604,6 +653,14 @@ def run_workload(args, rank: int, local_rank: int, world: int, dist):
     if gc_was_on:
         gc.enable()
 
+    # reduce side: the timed calls check status and size only, and the per-partition checksum covers the COMPRESSED bytes —
+    # so every decoded map output is compared with its source, byte for byte, once, after the timed region (untimed)
+    bytes_verified = None
+    if decompress:
+        bytes_verified = all(bool(torch.equal(t["out"], t["src"])) for t in tasks)
+        if not bytes_verified:
+            raise SystemExit(f"{args.workload}: decoded bytes differ from the source")
+
     u_rank = sum(t["u"] for t in tasks)
     c_rank = sum(comp_bytes)
     elapsed_rank = elapsed
@@ -672,6 +729,7 @@ def run_workload(args, rank: int, local_rank: int, world: int, dist):
                 "codec": ("lz4 (decode only: LZ4Block frames of %d KiB blocks written by liblz4 1.9.3 on the host, as a JVM writer with that spark.io.compression.lz4.blockSize)" % (jvm_block >> 10)) if jvm_block
                          else "lz4 (LZ4Block frames, 32 KiB blocks; payload bit-exact with liblz4 1.9.3 LZ4_compress_default, framing restated from lz4-java 1.8.0)" if codec_name == "lz4"
                          else "snappy (SnappyOutputStream framing, 32 KiB blocks, byte-exact with snappy 1.1.8)" if codec_name == "snappy"
+                         else "lzf (decode only: LZFOutputStream chunks of <= 65 535 bytes around liblzf 3.6 blocks, as compress-lzf writes them)" if codec_name == "lzf"
                          else "zstd (decode only: libzstd 1.4.8 streaming frames, level 1, one per partition, as zstd-jni writes them)",
                 "checksum": algo_name,
                 "partitions_per_map_task": nparts,
@@ -708,9 +766,13 @@ def run_workload(args, rank: int, local_rank: int, world: int, dist):
             },
             "stages_ms_per_library_call": {k: round(stage[k] / launches, 4) for k in ("hash", "codec", "assemble", "checksum", "total")},
         }
+        if decompress:
+            out["bytes_verified"] = bool(bytes_verified)  # torch.equal(decoded, source) for every map task of the step, after the timed region
         if world == 1 and not args.no_cpu_baseline:
             if codec_name == "zstd":
                 cb = cpu_baseline_zstd_decompress(args.workload, args.cpu_seconds, args.map_mib)
+            elif codec_name == "lzf":
+                cb = cpu_baseline_lzf_decompress(args.workload, args.cpu_seconds, args.map_mib)
             else:
                 if decompress:
                     cb = cpu_baseline_decompress(args.workload, args.cpu_seconds, args.map_mib, JVM_LZ4_BLOCK.get(args.workload, 0))
@@ -723,7 +785,7 @@ def run_workload(args, rank: int, local_rank: int, world: int, dist):
         else:
             out["cpu_baseline"] = None
         # roofline.traffic = HBM bytes per launch of the dominant kernel from the PMC counters (2 x FETCH_SIZE + WRITE_SIZE KB,
-        # gfx950 correction as in tools/r3_report.py).  Counters cannot be collected inside a timed run (rocprofv3 serialises
+        # gfx950 correction as in tools/r4_report.py).  Counters cannot be collected inside a timed run (rocprofv3 serialises
         # the kernels), so the figure comes from the tracked PMC pass of the SAME kernels: profiles/traffic_latest.json names
         # the sha256 of the kernel sources each entry was taken with, and it is used only when that equals the stamp of the
         # sources this library was built from (tools/src_stamp.py); otherwise traffic stays null and the entry is only cited.
@@ -769,6 +831,8 @@ SECONDARY = [
     ("terasort-200p-zstd:decompress", "terasort-10g-200p-zstd", "decompress", 128, 8),  # frames in flight are its throughput
     ("tpcds-wide-zstd:decompress", "tpcds-wide-100g-200p-zstd", "decompress", 128, 8),  # 3.3 x the sequences per byte: the decoder's weak side, reported
     ("terasort-200p-lz4-256k-blocks:decompress", "terasort-10g-200p-lz4-256k", "decompress", 128, 4),  # round 4: frames above 32 KiB, batch decoder
+    ("terasort-2000p-zstd:decompress", "terasort-100g-2000p-zstd", "decompress", 128, 4),  # 64 KiB frames, one zstd block each
+    ("terasort-200p-lzf:decompress", "terasort-10g-200p-lzf", "decompress", 128, 4),  # LZFOutputStream chunks written by liblzf
 ]
 
 
@@ -803,12 +867,20 @@ def run_secondaries(args, rank: int, local_rank: int):
             "speedup_vs_cpu_all_cores": o.get("speedup_vs_cpu_all_cores"),
             "wall_s": round(time.perf_counter() - t0, 2),
         }
+        if "bytes_verified" in o:
+            res[label]["bytes_verified"] = o["bytes_verified"]
     t0 = time.perf_counter()
     try:
         res["block_size_sweep"] = run_block_size_sweep(args, rank, local_rank, res)
         res["block_size_sweep"]["wall_s"] = round(time.perf_counter() - t0, 2)
     except Exception as e:
         res["block_size_sweep"] = {"error": repr(e)}
+    t0 = time.perf_counter()
+    try:
+        res["hbm_bound_stages"] = run_hbm_stages(args, local_rank)
+        res["hbm_bound_stages"]["wall_s"] = round(time.perf_counter() - t0, 2)
+    except Exception as e:
+        res["hbm_bound_stages"] = {"error": repr(e)}
     _SKEW_CACHE.clear()
     t0 = time.perf_counter()
     try:
@@ -817,6 +889,74 @@ def run_secondaries(args, rank: int, local_rank: int):
     except Exception as e:
         res["host_path"] = {"error": repr(e)}
     res["wall_s_total"] = round(time.perf_counter() - t_all, 2)
+    return res
+
+
+def run_hbm_stages(args, local_rank: int):
+    """The path's HBM-bound stages on their own: per-partition checksums over a 1 GiB range — four times
+    the 256 MiB Infinity Cache, so the bytes come from HBM — and the xxHash32 pre-pass of the LZ4Block frames over a 1 GiB
+    single-partition block.  Reference: S3ChecksumValidationStream.scala:54-86 / S3ShuffleHelper.scala:94-103 (read side),
+    the checksums delivered at S3ShuffleMapOutputWriter.scala:91 (write side), LZ4BlockOutputStream's frame hash.
+    `value` = wall clock around whole library calls (s3s_checksum_ranges_device incl. its launch + stream sync);
+    `roofline.achieved` = range bytes / the HIP-event time of the kernels on the library's stream (algorithmic bytes = 1 B
+    read per byte)."""
+    import torch
+    import s3shuffle
+
+    dev = torch.device("cuda", local_rank)
+    n_bytes = 1 << 30
+    data, _ = make_map_output("skew-1part-lz4", 0, n_bytes)
+    d = torch.from_numpy(np.ascontiguousarray(data)).to(dev)
+    c = s3shuffle.Codec(local_rank)
+    c.set_option(s3shuffle.codec.OPT_PROFILE, 1)
+    res = {"what": "HBM-bound stages alone on a 1 GiB TeraSort block resident in HBM (4 x the 256 MiB Infinity Cache); 6 timed calls after 2 warm-up",
+           "unit": "GB/s", "range_bytes": n_bytes}
+    import zlib
+
+    for name, algo, ref in (("adler32", s3shuffle.CHECKSUM_ADLER32, lambda b: zlib.adler32(b) & 0xFFFFFFFF),
+                            ("crc32", s3shuffle.CHECKSUM_CRC32, lambda b: zlib.crc32(b) & 0xFFFFFFFF),
+                            ("crc32c", s3shuffle.CHECKSUM_CRC32C, None)):
+        for label, offs in (("1-range", np.array([0, n_bytes], np.int64)),
+                            ("2000-ranges", np.linspace(0, n_bytes, 2001).astype(np.int64))):
+            for _ in range(2):
+                sums = c.checksum_ranges_device(algo, d.data_ptr(), offs)
+            ev = []
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(6):
+                sums = c.checksum_ranges_device(algo, d.data_ptr(), offs)
+                ev.append(c.stage_ms(s3shuffle.codec.STAGE_CHECKSUM))
+            dt = (time.perf_counter() - t0) / 6
+            ms = sum(ev) / len(ev)
+            e = {"value": round(n_bytes / dt / 1e9, 1), "ms_per_call": round(dt * 1e3, 4),
+                 "roofline": {"bound": "hbm", "kernel": "checksum_segments_kernel + checksum_combine_kernel (%s)" % name,
+                              "achieved": round(n_bytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                              "frac": round(n_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                              "frac_of_copy_ceiling": round(n_bytes / (ms * 1e-3) / 1e9 / HBM_COPY_CEILING_GBPS, 4),
+                              "avg_kernels_ms": round(ms, 4), "algorithmic_bytes_per_launch": n_bytes, "traffic": None}}
+            if ref is not None and label == "1-range":  # the value itself, against zlib on the host (untimed)
+                e["matches_zlib"] = bool(int(sums[0]) == ref(data))
+            res[f"checksum-only-1gib:{name}:{label}"] = e
+    # xxHash32 pre-pass: the hash stage of one map-side call over the 1 GiB single-partition block (HIP events in the library)
+    offs = np.array([0, n_bytes], np.int64)
+    cap = c.max_compressed_size(s3shuffle.CODEC_LZ4, offs)
+    dst = torch.empty(cap, dtype=torch.uint8, device=dev)
+    hs = []
+    for k in range(4):
+        c.compress_map_output_device(s3shuffle.CODEC_LZ4, s3shuffle.CHECKSUM_ADLER32, d.data_ptr(), offs, dst.data_ptr(), cap)
+        if k:
+            hs.append(c.stage_ms(s3shuffle.codec.STAGE_HASH))
+    ms = sum(hs) / len(hs)
+    if ms > 0:
+        res["xxh32-prepass-1gib"] = {"value": round(n_bytes / (ms * 1e-3) / 1e9, 1), "ms": round(ms, 4),
+                                     "roofline": {"bound": "hbm", "kernel": "xxh32 of every 32 KiB block (frame check values)",
+                                                  "achieved": round(n_bytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                                  "frac": round(n_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                                  "algorithmic_bytes_per_launch": n_bytes, "traffic": None},
+                                     "note": "HIP-event time of the hash stage inside s3s_compress_map_output_device (3 calls after 1 warm-up)"}
+    c.close()
+    del d, dst
+    torch.cuda.synchronize()
     return res
 
 
@@ -967,6 +1107,9 @@ def main():
 
     if args.host_path_only:
         print(json.dumps({"host_path": run_host_path(args, local_rank)}), flush=True)
+        return
+    if args.hbm_stages_only:
+        print(json.dumps({"hbm_bound_stages": run_hbm_stages(args, local_rank)}), flush=True)
         return
     out = run_workload(args, rank, local_rank, world, dist)
     if rank == 0 and world == 1 and args.secondary and not args.dry_run:

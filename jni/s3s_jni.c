@@ -163,6 +163,15 @@ static int same_length(JNIEnv* e, jsize n, ...) {
   return bad;
 }
 
+/* stamp a status array with S3S_STATUS_NOT_RUN (the library does the same on entry; this covers the returns in front of it) */
+static void not_run(JNIEnv* e, jintArray status) {
+  const jsize m = (*e)->GetArrayLength(e, status);
+  jint* st = (*e)->GetIntArrayElements(e, status, NULL);
+  if (!st) return;
+  for (jsize i = 0; i < m; i++) st[i] = S3S_STATUS_NOT_RUN;
+  (*e)->ReleaseIntArrayElements(e, status, st, 0);
+}
+
 JNIEXPORT jint JNICALL FN(compressMapOutputsBatch)(JNIEnv* e, jclass c, jlong h, jint codec, jint algo, jobjectArray src,
                                                    jobjectArray srcOffsets, jobjectArray dst, jlongArray dstCap,
                                                    jobjectArray outIndex, jobjectArray outChecksums, jlongArray outTotal,
@@ -170,6 +179,7 @@ JNIEXPORT jint JNICALL FN(compressMapOutputsBatch)(JNIEnv* e, jclass c, jlong h,
   (void)c;
   if (!src || !srcOffsets || !dst || !dstCap || !outIndex || !outTotal || !outStatus) return S3S_E_INVALID;
   const jsize n = (*e)->GetArrayLength(e, src);
+  not_run(e, outStatus); /* every early return below leaves "not run", never a zero that reads as OK (advisor r4) */
   if (same_length(e, n, srcOffsets, dst, dstCap, outIndex, outTotal, outStatus, outChecksums, NULL) != 0) return S3S_E_INVALID;
   if ((*e)->EnsureLocalCapacity(e, 3 * n + 8) != 0) return S3S_E_NOMEM; /* three array references per task stay live over the call */
   /* the inner arrays against the partition count srcOffsets[i] implies (advisor r3: a short outIndex[i] / outChecksums[i]
@@ -240,6 +250,7 @@ JNIEXPORT jint JNICALL FN(decompressRangesBatch)(JNIEnv* e, jclass c, jlong h, j
   (void)c;
   if (!comp || !compLen || !partOffsets || !dst || !dstCap || !outLen || !outBadPartition || !outStatus) return S3S_E_INVALID;
   const jsize n = (*e)->GetArrayLength(e, comp);
+  not_run(e, outStatus);
   if (same_length(e, n, compLen, partOffsets, dst, dstCap, outLen, outBadPartition, outStatus, refChecksums, NULL) != 0)
     return S3S_E_INVALID;
   if ((*e)->EnsureLocalCapacity(e, 2 * n + 8) != 0) return S3S_E_NOMEM;

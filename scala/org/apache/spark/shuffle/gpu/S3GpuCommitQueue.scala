@@ -60,11 +60,17 @@ object S3GpuCommitQueue {
       val n = same.length
       val totals = new Array[Long](n)
       val status = new Array[Int](n)
+      // the JNI unit and the library have early returns (bad argument, allocation failure) that never reach the per-task
+      // stamping: a fresh Array[Int] would read as n x OK with total 0 - an EMPTY map output committed instead of an
+      // exception (advisor r4).  Every entry starts as "not run"; only the library's own verdict can make it OK.
+      java.util.Arrays.fill(status, S3SCodec.STATUS_NOT_RUN)
       try {
         val rc = S3SCodec.compressMapOutputsBatch(ctx, first.codec, first.algo, same.map(_.src).toArray,
           same.map(_.srcOffsets).toArray, same.map(_.dst).toArray, same.map(_.dstCap).toArray, same.map(_.index).toArray,
           if (first.algo == S3SCodec.CHECKSUM_NONE) null else same.map(_.sums).toArray, totals, status)
         val why = if (rc != S3SCodec.OK) S3SCodec.lastError(ctx) else ""
+        // backstop: a failed call in which every task claims OK cannot be trusted task by task
+        if (rc != S3SCodec.OK && status.forall(_ == S3SCodec.OK)) java.util.Arrays.fill(status, S3SCodec.STATUS_NOT_RUN)
         var i = 0
         while (i < n) {
           same(i).total = totals(i)
@@ -104,9 +110,17 @@ object S3GpuCommitQueue {
     worker(device).queue.put(r)
     var interrupted = false
     var finished = false
+    val w = worker(device)
     while (!finished) {
-      try { r.done.await(); finished = true }
-      catch { case _: InterruptedException => interrupted = true }
+      // bounded waits: if the worker thread has died (an Error escaping run()) nothing will ever count the latch down -
+      // the request fails with E_HIP instead of holding an executor slot for ever (advisor r4).  A live worker inside the
+      // native call is still waited for without limit: the buffers belong to that call until it returns.
+      try {
+        finished = r.done.await(1, java.util.concurrent.TimeUnit.SECONDS)
+        if (!finished && !w.isAlive && r.done.getCount > 0) {
+          r.rc = S3SCodec.E_HIP; r.error = "GPU commit worker thread is gone"; finished = true
+        }
+      } catch { case _: InterruptedException => interrupted = true }
     }
     if (interrupted) Thread.currentThread().interrupt()
     r

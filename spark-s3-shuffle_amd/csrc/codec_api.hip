@@ -480,6 +480,9 @@ int s3s_compress_map_outputs_batch_device(s3s_ctx* ctx, int codec, int checksum_
   ctx->err[0] = 0;
   const CompressCallScope in_flight(ctx);
   if (n_tasks < 0 || (n_tasks > 0 && !tasks)) return fail(ctx, S3S_E_INVALID, "null task array or negative count");
+  // "stamped on entry" (s3shuffle_codec.h): BEFORE the argument checks below, so a caller with zeroed status fields never reads
+  // S3S_OK out of a call that was refused (advisor r4)
+  BatchVerdict<s3s_map_task> verdict(tasks, n_tasks);
   if (codec == S3S_CODEC_ZSTD || codec == S3S_CODEC_LZF)
     return fail(ctx, S3S_E_UNSUPPORTED, "%s compression stays on the JVM codec (decode only: s3s_decompress_range*)", codec == S3S_CODEC_LZF ? "lzf" : "zstd");
   if (codec != S3S_CODEC_NONE && codec != S3S_CODEC_LZ4 && codec != S3S_CODEC_SNAPPY)
@@ -490,7 +493,6 @@ int s3s_compress_map_outputs_batch_device(s3s_ctx* ctx, int codec, int checksum_
   if (codec == S3S_CODEC_SNAPPY && !snappy_compress_available())
     return fail(ctx, S3S_E_UNSUPPORTED, "snappy compression is not available in this build");
   if (n_tasks == 0) return S3S_OK;
-  BatchVerdict<s3s_map_task> verdict(tasks, n_tasks);
   if (codec == S3S_CODEC_NONE) {  // nothing to batch: plain copies
     int worst = S3S_OK;
     for (int32_t t = 0; t < n_tasks; t++) {

@@ -436,6 +436,7 @@ extern "C" int s3s_decompress_ranges_batch_device(s3s_ctx* ctx, int codec, int c
   if (!ctx) return S3S_E_INVALID;
   ctx->err[0] = 0;
   if (n_ranges < 0 || (n_ranges > 0 && !R)) return fail(ctx, S3S_E_INVALID, "null range array or negative count");
+  BatchVerdict<s3s_fetch_range> verdict(R, n_ranges);  // stamped before the argument checks (advisor r4)
   if (codec != S3S_CODEC_NONE && codec != S3S_CODEC_LZ4 && codec != S3S_CODEC_SNAPPY && codec != S3S_CODEC_ZSTD && codec != S3S_CODEC_LZF)
     return fail(ctx, S3S_E_INVALID, "unknown codec %d", codec);
   if (checksum_algo != S3S_CHECKSUM_NONE && checksum_algo != S3S_CHECKSUM_ADLER32 && checksum_algo != S3S_CHECKSUM_CRC32 &&
@@ -454,7 +455,6 @@ extern "C" int s3s_decompress_ranges_batch_device(s3s_ctx* ctx, int codec, int c
     return S3S_OK;
   };
   if (n_ranges == 0) return S3S_OK;
-  BatchVerdict<s3s_fetch_range> verdict(R, n_ranges);
   if (codec == S3S_CODEC_NONE || n_ranges == 1) {  // nothing to batch
     for (int32_t r = 0; r < n_ranges; r++) single(R[r]);
     return verdict.finish(first_error());

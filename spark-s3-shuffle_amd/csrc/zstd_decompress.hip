@@ -219,7 +219,15 @@ int zstd_decompress_ranges(s3s_ctx* ctx, int checksum_algo, s3s_fetch_range* R, 
     const char* e = getenv("S3S_ZSTD_GUESS");  // 0: always two passes
     return e ? atoi(e) : 8;
   }();
-  if (!size_only && kGuess > 0) {
+  // scratch of the single pass is bounded (advisor r4): it exists per context and never shrinks, so a call whose guess would
+  // take more than the budget (default 4 GiB, S3S_ZSTD_SCRATCH_MIB) - or whose allocation fails - takes the two-pass form,
+  // which sizes its literal scratch by the measured need and decodes straight into the caller's buffer
+  static const int64_t kScratchBudget = [] {
+    const char* e = getenv("S3S_ZSTD_SCRATCH_MIB");
+    return (int64_t)(e ? atoll(e) : 4096) << 20;
+  }();
+  bool single = !size_only && kGuess > 0;
+  if (single) {
     int64_t scr_total = 0, lit_total1 = 0;
     {
       int32_t pp = 0;
@@ -231,13 +239,22 @@ int zstd_decompress_ranges(s3s_ctx* ctx, int checksum_algo, s3s_fetch_range* R, 
           z.cap = z.size > 0 ? (int64_t)kGuess * z.size + 4096 : 0;
           z.dst = reinterpret_cast<uint8_t*>((uintptr_t)scr_total);  // (offset for now: the buffer may still move)
           z.lit_off = lit_total1;
-          z.lit_stride = s3s_zstd::kMaxBlock + 64;  // the largest regenerated literals section a block can have
+          // the largest regenerated (Huffman-coded) literals section a block of this partition can have: a block's limit, and
+          // at most 8 symbols per compressed byte (raw / RLE literals never pass through this scratch)
+          const int64_t by_size = 8 * z.size + 256;
+          z.lit_stride = (((by_size < (int64_t)s3s_zstd::kMaxBlock ? by_size : (int64_t)s3s_zstd::kMaxBlock) + 64) + 15) & ~int64_t(15);
           scr_total += (z.cap + 255) & ~int64_t(255);
           if (z.size > 0) lit_total1 += 2 * z.lit_stride;
         }
     }
-    if ((rc = ensure(ctx, B_ZSCRATCH, (size_t)scr_total + 256))) return rc;
-    if ((rc = ensure(ctx, B_SLOTS, (size_t)lit_total1 + 64))) return rc;
+    if (scr_total + lit_total1 > kScratchBudget) single = false;
+    else if (ensure(ctx, B_ZSCRATCH, (size_t)scr_total + 256) != S3S_OK || ensure(ctx, B_SLOTS, (size_t)lit_total1 + 64) != S3S_OK) {
+      (void)hipGetLastError();  // an allocation that did not fit: not this call's verdict
+      ctx->err[0] = 0;
+      single = false;
+    }
+  }
+  if (single) {
     if ((rc = ensure(ctx, B_RANGES, sizeof(ZPart) * (size_t)n_parts))) return rc;
     if ((rc = ensure(ctx, B_FRAMES, sizeof(ZRes) * (size_t)n_parts))) return rc;
     uint8_t* scr = dev<uint8_t>(ctx, B_ZSCRATCH);
@@ -284,9 +301,9 @@ int zstd_decompress_ranges(s3s_ctx* ctx, int checksum_algo, s3s_fetch_range* R, 
       }
     }
     if (!outgrown) {
+      std::vector<ZPiece> pcs;  // (source of an asynchronous copy: lives until the stream has been synchronised below)
       if (n_pieces > 0) {
         if ((rc = ensure(ctx, B_ZPIECES, sizeof(ZPiece) * (size_t)n_pieces))) return rc;
-        std::vector<ZPiece> pcs;
         pcs.reserve((size_t)n_pieces);
         int32_t pp = 0;
         for (int32_t r = 0; r < n_ranges; r++) {

@@ -3,7 +3,8 @@ format compress-lzf implements — reached through `imagecodecs.lzf_encode` of t
 interpreter:   /opt/conda/bin/python3.9 tests/golden/make_lzf_golden.py
 Also usable as a filter for live pins (tests/test_oracle_pins.py):
    ... make_lzf_golden.py --encode  < raw   > lzf      (stdin -> stdout)
-   ... make_lzf_golden.py --decode N < lzf   > raw"""
+   ... make_lzf_golden.py --decode N < lzf   > raw
+   ... make_lzf_golden.py --streams  (length-prefixed partitions in, length-prefixed LZFOutputStream images out: bench.py)"""
 import os
 import sys
 
@@ -31,6 +32,34 @@ if len(sys.argv) > 1 and sys.argv[1] == "--stream":
         else:
             out += b"ZV\x01" + struct.pack(">HH", len(enc), len(chunk)) + enc
     sys.stdout.buffer.write(bytes(out))
+    sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "--streams":
+    # stdin: <u64 LE length><bytes> per partition -> stdout: <u64 LE length><LZFOutputStream bytes> per partition
+    # (bench.py builds a whole map task's LZF image with ONE interpreter start)
+    import struct
+
+    def stream(raw):
+        out = bytearray()
+        for p in range(0, len(raw), 0xFFFF):
+            chunk = raw[p:p + 0xFFFF]
+            try:
+                enc = bytes(imagecodecs.lzf_encode(chunk))
+            except Exception:
+                enc = b""
+            if not enc or len(enc) >= len(chunk) - 2:
+                out += b"ZV\x00" + struct.pack(">H", len(chunk)) + chunk
+            else:
+                out += b"ZV\x01" + struct.pack(">HH", len(enc), len(chunk)) + enc
+        return bytes(out)
+
+    buf = sys.stdin.buffer.read()
+    pos, w = 0, sys.stdout.buffer
+    while pos < len(buf):
+        (n,) = struct.unpack_from("<Q", buf, pos)
+        s_ = stream(buf[pos + 8:pos + 8 + n])
+        w.write(struct.pack("<Q", len(s_)))
+        w.write(s_)
+        pos += 8 + n
     sys.exit(0)
 if len(sys.argv) > 2 and sys.argv[1] == "--decode":
     sys.stdout.buffer.write(bytes(imagecodecs.lzf_decode(sys.stdin.buffer.read(), out=int(sys.argv[2]))))

@@ -235,7 +235,9 @@ int main(void) {
     mj_i(a_status)[0] = 77;
     CHECK(FN(compressMapOutputsBatch)(e, NULL, h, CODEC, ALGO, a_src, a_offs, a_dst, a_cap, a_index, a_sums, a_total, a_status) == S3S_E_INVALID);
     CLEAN();
-    CHECK(mj_i(a_status)[0] == 77);
+    /* (round 5, advisor r4: a refused call stamps every status with S3S_STATUS_NOT_RUN — a fresh JVM int[] is all zeros = OK,
+       and an empty map output would be committed; nothing ELSE is written) */
+    CHECK(mj_i(a_status)[0] == S3S_STATUS_NOT_RUN && mj_i(a_status)[1] == S3S_STATUS_NOT_RUN && mj_i(a_status)[2] == S3S_STATUS_NOT_RUN);
     mj_o(a_index)[1] = keep_i;
     mj_o(a_sums)[2] = short_sums;
     CHECK(FN(compressMapOutputsBatch)(e, NULL, h, CODEC, ALGO, a_src, a_offs, a_dst, a_cap, a_index, a_sums, a_total, a_status) == S3S_E_INVALID);

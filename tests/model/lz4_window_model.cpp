@@ -70,7 +70,8 @@ struct Ctx {
   int64_t st[16] = {0};
 };
 enum { ST_GENERAL = 0, ST_CUTS, ST_SEQ, ST_WINDOWS, ST_FAST_SEQ, ST_BAIL_STALE, ST_BAIL_FWD, ST_BAIL_BACK,
-       ST_RUN_ITERS, ST_SNAPSHOTS, ST_WIN_SKIPPED_SNAP };
+       ST_RUN_ITERS, ST_SNAPSHOTS, ST_WIN_SKIPPED_SNAP,
+       ST_SPEC_VISITED_STALE, ST_SPEC_LIVE_STALE, ST_LIVE_DUP, ST_SPEC_UNFIXABLE };
 
 void emit_sequence(Ctx& o, int anchor, int lit, bool has_match, int offset, int mcode) {
   int need = 1 + lit + (lit >= 15 ? (lit - 15) / 255 + 1 : 0);
@@ -279,6 +280,19 @@ int fast_window(Ctx& c, int& base, int& t0, const Snap& snap, bool& bailed) {
   int rs = base - wbase, rt = t0;
   int pending_q = -1;
   int rc = -2;
+  // statistics for the speculative next-window gather: is the candidate snapshot taken one
+  // window early still the table's answer for the lanes that matter?
+  uint64_t stale = 0;
+  for (int i = 0; i < WAVE; i++)
+    if (cp[i] != snap.c[i]) stale |= 1ull << i;
+  if (stale & range(rs, WAVE)) c.st[ST_SPEC_LIVE_STALE]++;
+  {
+    bool dup = false;
+    for (int i = rs; i < WAVE && !dup; i++)
+      if (eq[i] & range(rs, i)) dup = true;
+    if (dup) c.st[ST_LIVE_DUP]++;
+  }
+  uint64_t visited = 0;
   for (;;) {  // ---- runs
     int e = rs + (65 - rt) + 1;  // consecutive probes need t <= 65
     bool t_limited = true;
@@ -320,6 +334,7 @@ int fast_window(Ctx& c, int& base, int& t0, const Snap& snap, bool& bailed) {
       }
       scan = i + 1;
     }
+    visited |= range(rs, m < 0 ? e : m + 1);
     if (m < 0) {
       K |= range(rs, e);
       if (e <= rs && !hit_mf) {  // t too large for consecutive probes: the general batch takes over
@@ -372,6 +387,14 @@ int fast_window(Ctx& c, int& base, int& t0, const Snap& snap, bool& bailed) {
     if (((K >> i) & 1) && !(eq[i] & K & ~((2ull << i) - 1ull))) c.T[h[i]] = (uint16_t)pos[i];
   if (pending_q >= 0) c.T[hash13(rd32(in + pending_q))] = (uint16_t)pending_q;
   c.st[ST_RUN_ITERS]++;
+  if (stale & visited) c.st[ST_SPEC_VISITED_STALE]++;
+  {  // ... and is the fresh candidate of every such lane a position of the PREVIOUS window (its bytes are in registers)?
+    bool unfixable = false;
+    for (int i = 0; i < WAVE; i++)
+      if (((stale & visited) >> i) & 1)
+        if (!(cp[i] >= wbase - 64 && cp[i] < wbase)) unfixable = true;
+    if (unfixable) c.st[ST_SPEC_UNFIXABLE]++;
+  }
   return rc;
 }
 

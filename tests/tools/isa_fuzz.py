@@ -127,7 +127,9 @@ def main():
     ap.add_argument("--codec", default="both")
     ap.add_argument("--out", default="/tmp/isa_fuzz")
     ap.add_argument("--batch", type=int, default=6)
+    ap.add_argument("--flags", default="", help="extra hipcc flags for the LZ4 kernel, e.g. -DS3S_ENGINE_SPEC (experiment builds)")
     args = ap.parse_args()
+    lz4_flags = tuple(args.flags.split())
     os.makedirs(args.out, exist_ok=True)
     import lz4_kernel as lk
     import snappy_kernel as sk
@@ -145,7 +147,7 @@ def main():
         for codec in (("lz4", "snappy") if args.codec == "both" else (args.codec,)):
             try:
                 if codec == "lz4":
-                    res = lk.compress_chunks(chunks)
+                    res = lk.compress_chunks(chunks, flags=lz4_flags)
                     for c, (payload, hdr, w) in zip(chunks, res):
                         ref = oracle.lz4_compress_block(c)
                         ok = (len(ref) >= len(c)) if payload is None else np.array_equal(payload, ref)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of codec-library builds on the GPU (round 3): tools/r3_ab.sh <outdir-tag> <exp-name> [<exp-name> ...]
+# A/B of codec-library builds on the GPU (round 3): tools/ab.sh <outdir-tag> <exp-name> [<exp-name> ...]
 #   exp libs: make -C spark-s3-shuffle_amd/csrc exp EXPNAME=<name> EXPFLAGS=...; "default" = the shipped library.
 # Per library: bench.py --verify (bit-exact vs the oracle + headline), wide rows, and the single-stream kernel times.
 export TMPDIR=/tmp

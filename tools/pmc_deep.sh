@@ -1,6 +1,6 @@
 #!/bin/bash
 # Deep PMC passes of the LZ4 compress kernel (round 3): vector-memory latency and the TA / TCP / TD path, instruction
-# fetch, LDS conflicts.  usage: tools/r3_pmc_deep.sh <tag> [bench args]
+# fetch, LDS conflicts.  usage: tools/pmc_deep.sh <tag> [bench args]
 tag=$1; shift
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
