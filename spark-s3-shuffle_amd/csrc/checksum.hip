@@ -150,35 +150,51 @@ __global__ __launch_bounds__(kThreads) void checksum_segments_kernel(
     }
     c = ~c;
     v0 = mine ? multmodp(tabs->pow_piece[T - 1 - tid], c, tabs->poly) : 0u;  // shift by the bytes after this piece
-  } else if (tid < T) {
-    const int end = seg_len - kPiece * (T - 1 - tid);
-    const int beg = end - kPiece > 0 ? end - kPiece : 0;
-    const int pl = end - beg;
-    if (ALGO == S3S_CHECKSUM_ADLER32) {
-      uint32_t s1 = 0, s2 = 0;  // s2 = sum d_k * (pl - k)
-      if (pl == kPiece) {
-        uint4 q[4];
-        __builtin_memcpy(q, g + beg, 64);
-        const uint32_t* wds = reinterpret_cast<const uint32_t*>(q);
+  } else {
+    // Adler32 (round 5): position weights instead of pieces.  A byte at index i of a segment of L bytes adds d to A and
+    // d * (L - i) to B, whoever reads it — so the loads are laid out for the memory system: thread t takes the 16 bytes
+    // [4096 r + 16 t, + 16) of the segment for r = 0..3 (a wavefront reads 1 KiB in one instruction; the pieces of round 1
+    // were 64 bytes per THREAD, 64 bytes apart: four instructions to use a cache line, 3.9 TB/s on a 1 GiB range), and
+    // the sums come from v_dot4_u32_u8: S = sum d_j, W = sum j d_j per 16 bytes, B += (L - c) S - W.
+    uint32_t s1 = 0, s2 = 0;
+    auto add16 = [&](const uint4& q, int c) {
+      uint32_t S = __builtin_amdgcn_udot4(q.x, 0x01010101u, 0u, false);
+      S = __builtin_amdgcn_udot4(q.y, 0x01010101u, S, false);
+      S = __builtin_amdgcn_udot4(q.z, 0x01010101u, S, false);
+      S = __builtin_amdgcn_udot4(q.w, 0x01010101u, S, false);
+      uint32_t W = __builtin_amdgcn_udot4(q.x, 0x03020100u, 0u, false);
+      W = __builtin_amdgcn_udot4(q.y, 0x07060504u, W, false);
+      W = __builtin_amdgcn_udot4(q.z, 0x0b0a0908u, W, false);
+      W = __builtin_amdgcn_udot4(q.w, 0x0f0e0d0cu, W, false);
+      s1 += S;                                // <= 4 * 4080
+      s2 += (uint32_t)(seg_len - c) * S - W;  // <= 4 * 16384 * 4080 < 2^32; W <= (L - c) S (zero padding has no weight)
+    };
+    constexpr int kRows = kChecksumSegBytes / (16 * kThreads);
+    if (seg_len == kChecksumSegBytes) {  // a whole segment (all but a range's last): every load goes out before the first sum
+      uint4 q[kRows];
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-          const uint32_t x = wds[j];
-          const uint32_t b0 = x & 0xff, b1 = (x >> 8) & 0xff, b2 = (x >> 16) & 0xff, b3 = x >> 24;
-          s1 += b0 + b1 + b2 + b3;
-          s2 += b0 * (uint32_t)(64 - 4 * j) + b1 * (uint32_t)(63 - 4 * j) +
-                b2 * (uint32_t)(62 - 4 * j) + b3 * (uint32_t)(61 - 4 * j);
-        }
-      } else {
-        for (int k = 0; k < pl; k++) {
-          const uint32_t d = g[beg + k];
-          s1 += d;
-          s2 += d * (uint32_t)(pl - k);
+      for (int r = 0; r < kRows; r++) __builtin_memcpy(&q[r], g + 16 * kThreads * r + 16 * tid, 16);
+#pragma unroll
+      for (int r = 0; r < kRows; r++) add16(q[r], 16 * kThreads * r + 16 * tid);
+    } else {
+#pragma unroll
+      for (int r = 0; r < kRows; r++) {
+        const int c = 16 * kThreads * r + 16 * tid;
+        if (c < seg_len) {
+          uint4 q = make_uint4(0, 0, 0, 0);
+          if (c + 16 <= seg_len) {
+            __builtin_memcpy(&q, g + c, 16);
+          } else {  // the segment's last, short chunk: byte loads, the rest stays zero
+            uint32_t w[4] = {0, 0, 0, 0};
+            for (int k = 0; k < seg_len - c; k++) w[k >> 2] |= (uint32_t)g[c + k] << (8 * (k & 3));
+            q = make_uint4(w[0], w[1], w[2], w[3]);
+          }
+          add16(q, c);
         }
       }
-      const uint32_t after = (uint32_t)(seg_len - end);  // < 16384
-      v0 = s1;                              // <= 16320
-      v1 = (s2 + s1 * after) % kAdlerMod;   // < 2^32 before the mod
     }
+    v0 = s1;
+    v1 = s2 % kAdlerMod;
   }
   uint32_t* out = partial + 4 * (size_t)b;
   if (ALGO == S3S_CHECKSUM_ADLER32) {
@@ -207,22 +223,24 @@ __global__ __launch_bounds__(kThreads) void checksum_segments_kernel(
   }
 }
 
+// unit = bytes one partial stands for (all but a range's last): kChecksumSegBytes, or — behind checksum_fold_kernel —
+// fold_groups x kChecksumSegBytes with the partials of range p at partial + 4 * p * max_groups
 template <int ALGO>
 __global__ __launch_bounds__(kThreads) void checksum_combine_kernel(
     const int64_t* __restrict__ offsets, int32_t n, const int32_t* __restrict__ seg_start,
     const Tables* __restrict__ tabs, const uint32_t* __restrict__ partial,
-    int64_t* __restrict__ out) {
+    int64_t* __restrict__ out, int64_t unit, int32_t max_groups) {
   const int p = blockIdx.x, tid = threadIdx.x;
   if (p >= n) return;
   const int64_t plen = offsets[p + 1] - offsets[p];
-  const int64_t nseg = (plen + kChecksumSegBytes - 1) / kChecksumSegBytes;
-  const uint32_t* part = partial + 4 * (size_t)seg_start[p];
+  const int64_t nseg = (plen + unit - 1) / unit;
+  const uint32_t* part = partial + 4 * (max_groups > 0 ? (size_t)p * (size_t)max_groups : (size_t)seg_start[p]);
   if (ALGO == S3S_CHECKSUM_ADLER32) {
     // one wavefront per partition, no LDS (see checksum_segments_kernel)
     uint32_t sa = 0, sb = 0;
     for (int64_t s = tid; s < nseg; s += kWave) {
       const uint32_t A = part[4 * s] % kAdlerMod, B = part[4 * s + 1] % kAdlerMod, len = part[4 * s + 2];
-      const int64_t after = plen - (s * kChecksumSegBytes + len);
+      const int64_t after = plen - (s * unit + len);
       sa = (sa + A) % kAdlerMod;
       sb = (uint32_t)((sb + B + (uint64_t)A * (uint64_t)(after % kAdlerMod)) % kAdlerMod);
     }
@@ -247,17 +265,85 @@ __global__ __launch_bounds__(kThreads) void checksum_combine_kernel(
     uint32_t c = 0;
     int64_t end = 0;
     if (s0 < s1) {
-      const uint32_t xseg = x8n(x2n, kChecksumSegBytes, poly);
+      const uint32_t xseg = x8n(x2n, (uint64_t)unit, poly);
       for (int64_t s = s0; s < s1; s++) {
         const uint32_t len = part[4 * s + 2];
-        c = multmodp(c, len == (uint32_t)kChecksumSegBytes ? xseg : x8n(x2n, len, poly), poly) ^ part[4 * s];
-        end = s * kChecksumSegBytes + len;
+        c = multmodp(c, (int64_t)len == unit ? xseg : x8n(x2n, len, poly), poly) ^ part[4 * s];
+        end = s * unit + len;
       }
       c = multmodp(c, x8n(x2n, (uint64_t)(plen - end), poly), poly);
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) c ^= __shfl_xor(c, d);
     if (tid == 0) out[p] = (int64_t)(uint64_t)c;
+  }
+}
+
+
+// A range of very many segments (a 1 GiB single-partition block: 65 536) would have the combine kernel's ONE wavefront fold
+// them all — 0.37 ms of the 0.65 ms a 1 GiB Adler32 took in round 4's layout.  The fold kernel is the same arithmetic one
+// level down: one wavefront per (range, group of `G` consecutive segments) writes the group's partial
+// { A | crc relative to the group's end, B, bytes } to partial2[p * max_groups + g]; the combine kernel then runs over
+// groups (unit = G segments).  Launched only when a range is that large (launch_checksum_with_tables).
+template <int ALGO>
+__global__ __launch_bounds__(kWave) void checksum_fold_kernel(
+    const int64_t* __restrict__ offsets, int32_t n, const int32_t* __restrict__ seg_start,
+    const Tables* __restrict__ tabs, const uint32_t* __restrict__ partial, uint32_t* __restrict__ partial2,
+    int32_t G, int32_t max_groups) {
+  const int p = (int)(blockIdx.x / (uint32_t)max_groups), gi = (int)(blockIdx.x % (uint32_t)max_groups), tid = threadIdx.x;
+  if (p >= n) return;
+  const int64_t plen = offsets[p + 1] - offsets[p];
+  const int64_t nseg = (plen + kChecksumSegBytes - 1) / kChecksumSegBytes;
+  const int64_t s_lo = (int64_t)gi * G;
+  if (s_lo >= nseg) return;
+  const int64_t s_hi = s_lo + G < nseg ? s_lo + G : nseg;
+  const uint32_t* part = partial + 4 * (size_t)seg_start[p];
+  uint32_t* o = partial2 + 4 * ((size_t)p * (size_t)max_groups + (size_t)gi);
+  const int64_t gend = s_hi * kChecksumSegBytes < plen ? s_hi * kChecksumSegBytes : plen;  // (bytes from the range's start)
+  if (ALGO == S3S_CHECKSUM_ADLER32) {
+    uint32_t sa = 0, sb = 0;
+    for (int64_t s = s_lo + tid; s < s_hi; s += kWave) {
+      const uint32_t A = part[4 * s] % kAdlerMod, B = part[4 * s + 1] % kAdlerMod, len = part[4 * s + 2];
+      const int64_t after = gend - (s * kChecksumSegBytes + len);
+      sa = (sa + A) % kAdlerMod;
+      sb = (uint32_t)((sb + B + (uint64_t)A * (uint64_t)(after % kAdlerMod)) % kAdlerMod);
+    }
+    uint32_t a = sa, b = sb;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      a += __shfl_xor(a, d);
+      b += __shfl_xor(b, d);
+    }
+    if (tid == 0) {
+      o[0] = a % kAdlerMod;
+      o[1] = b % kAdlerMod;
+      o[2] = (uint32_t)(gend - s_lo * kChecksumSegBytes);
+      o[3] = 0;
+    }
+  } else {
+    const uint32_t* x2n = tabs->x2n;
+    const uint32_t poly = tabs->poly;
+    const int64_t cnt = s_hi - s_lo, run = (cnt + kWave - 1) / kWave;
+    const int64_t s0 = s_lo + (int64_t)tid * run, s1 = (s0 + run) < s_hi ? (s0 + run) : s_hi;
+    uint32_t c = 0;
+    if (s0 < s1) {
+      const uint32_t xseg = x8n(x2n, kChecksumSegBytes, poly);
+      int64_t end = 0;
+      for (int64_t s = s0; s < s1; s++) {
+        const uint32_t len = part[4 * s + 2];
+        c = multmodp(c, len == (uint32_t)kChecksumSegBytes ? xseg : x8n(x2n, len, poly), poly) ^ part[4 * s];
+        end = s * kChecksumSegBytes + len;
+      }
+      c = multmodp(c, x8n(x2n, (uint64_t)(gend - end), poly), poly);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c ^= __shfl_xor(c, d);
+    if (tid == 0) {
+      o[0] = c;
+      o[1] = 0;
+      o[2] = (uint32_t)(gend - s_lo * kChecksumSegBytes);
+      o[3] = 0;
+    }
   }
 }
 
@@ -300,25 +386,33 @@ void checksum_tables_build(void* host_buf) {
 void launch_checksum_with_tables(int algo, const uint8_t* d_data, const int64_t* d_offsets,
                                  int32_t n, const int32_t* d_seg_start, int32_t total_segs,
                                  const void* d_tables, uint32_t* d_partial, int64_t* d_out,
-                                 int64_t data_len, hipStream_t st) {
+                                 int64_t data_len, hipStream_t st, int32_t max_segs_per_range, uint32_t* d_partial2) {
   if (n <= 0) return;
   const Tables* tabs = static_cast<const Tables*>(d_tables) + (algo == S3S_CHECKSUM_CRC32C ? 1 : 0);  // (the CRC kernels are the polynomial's tables away from each other)
+  // ranges of more than kChecksumFoldFrom segments: fold groups of kChecksumFoldGroup segments first (d_partial2 holds
+  // n x max_groups partials; the caller sizes it with checksum_fold_groups())
+  const int32_t max_groups = d_partial2 ? checksum_fold_groups(n, max_segs_per_range) : 0;
+  const int64_t unit = max_groups > 0 ? (int64_t)kChecksumFoldGroup * kChecksumSegBytes : (int64_t)kChecksumSegBytes;
+  const uint32_t* comb_in = max_groups > 0 ? d_partial2 : d_partial;
+  if (total_segs > 0) (void)hipMemsetAsync(d_partial, 0, 16 * (size_t)total_segs, st);  // wavefront results are added / xor-ed in atomically
   if (algo == S3S_CHECKSUM_ADLER32) {
-    if (total_segs > 0) {
-      (void)hipMemsetAsync(d_partial, 0, 16 * (size_t)total_segs, st);  // wavefront sums are added atomically
+    if (total_segs > 0)
       hipLaunchKernelGGL(checksum_segments_kernel<S3S_CHECKSUM_ADLER32>, dim3((unsigned)total_segs),
                          dim3(kThreads), 0, st, d_data, d_offsets, n, d_seg_start, tabs, d_partial, data_len);
-    }
+    if (max_groups > 0)
+      hipLaunchKernelGGL(checksum_fold_kernel<S3S_CHECKSUM_ADLER32>, dim3((unsigned)max_groups * (unsigned)n), dim3(kWave), 0, st,
+                         d_offsets, n, d_seg_start, tabs, d_partial, d_partial2, kChecksumFoldGroup, max_groups);
     hipLaunchKernelGGL(checksum_combine_kernel<S3S_CHECKSUM_ADLER32>, dim3((unsigned)n),
-                       dim3(kWave), 0, st, d_offsets, n, d_seg_start, tabs, d_partial, d_out);
+                       dim3(kWave), 0, st, d_offsets, n, d_seg_start, tabs, comb_in, d_out, unit, max_groups);
   } else {
-    if (total_segs > 0) {
-      (void)hipMemsetAsync(d_partial, 0, 16 * (size_t)total_segs, st);  // wavefront results are xor-ed in atomically
+    if (total_segs > 0)
       hipLaunchKernelGGL(checksum_segments_kernel<S3S_CHECKSUM_CRC32>, dim3((unsigned)total_segs),
                          dim3(kThreads), 0, st, d_data, d_offsets, n, d_seg_start, tabs, d_partial, data_len);
-    }
+    if (max_groups > 0)
+      hipLaunchKernelGGL(checksum_fold_kernel<S3S_CHECKSUM_CRC32>, dim3((unsigned)max_groups * (unsigned)n), dim3(kWave), 0, st,
+                         d_offsets, n, d_seg_start, tabs, d_partial, d_partial2, kChecksumFoldGroup, max_groups);
     hipLaunchKernelGGL(checksum_combine_kernel<S3S_CHECKSUM_CRC32>, dim3((unsigned)n),
-                       dim3(kWave), 0, st, d_offsets, n, d_seg_start, tabs, d_partial, d_out);
+                       dim3(kWave), 0, st, d_offsets, n, d_seg_start, tabs, comb_in, d_out, unit, max_groups);
   }
 }
 

@@ -336,7 +336,7 @@ __device__ int lz4_compress_wave(const Src in, const Tab T, int len, uint8_t* ou
                            "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133",
                            "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145",
                            "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v157", "v158",
-#if defined(S3S_ENGINE_SPEC)  // speculative next-window gather: two more gather register sets, cpS, the next window's hash
+#if !defined(S3S_ENGINE_NO_SPEC)  // speculative next-window gather: two more gather register sets, cpS, the next window's hash
                            "v155", "v156", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167",
 #elif defined(S3S_ABL_DUP_PW) || defined(S3S_ABL_DUP_GATHER) || defined(S3S_ABL_DUP_IPSIDE)
                            "v160", "v161", "v162", "v163",

@@ -25,6 +25,7 @@ enum BufId {
   B_FRAME_OUT, B_REF_SUMS, B_ITEM_CHECK, B_RANGES, B_TILE_RANGE,
   B_HB_IN0, B_HB_IN1, B_HB_OUT0, B_HB_OUT1,  // host-buffer batch pipeline (host_batch.hip): double-buffered device staging
   B_WORK,  // block counter of the persistent codec grid
+  B_PARTIAL2,  // checksum partials of folded segment groups (ranges of more than kChecksumFoldFrom segments)
   B_ZSCRATCH, B_ZPIECES,  // zstd single pass: decoded partitions at guessed capacities, and the compaction's piece list
   B_COUNT
 };
@@ -194,11 +195,15 @@ inline int run_checksum(s3s_ctx* ctx, int algo, const uint8_t* d_data, const int
   int rc;
   if ((rc = ensure(ctx, B_SEG_START, sizeof(int32_t) * (size_t)(n + 1)))) return rc;
   if ((rc = ensure(ctx, B_PARTIAL, sizeof(uint32_t) * 4 * (size_t)(total > 0 ? total : 1)))) return rc;
+  int32_t max_segs = 0;
+  for (int32_t p = 0; p < n; p++) max_segs = h_seg_start[p + 1] - h_seg_start[p] > max_segs ? h_seg_start[p + 1] - h_seg_start[p] : max_segs;
+  const int32_t groups = checksum_fold_groups(n, max_segs);
+  if (groups > 0 && (rc = ensure(ctx, B_PARTIAL2, sizeof(uint32_t) * 4 * (size_t)n * (size_t)groups))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(dev<int32_t>(ctx, B_SEG_START), h_seg_start,
                               sizeof(int32_t) * (size_t)(n + 1), hipMemcpyHostToDevice, ctx->stream));
   launch_checksum_with_tables(algo, d_data, d_offsets, n, dev<int32_t>(ctx, B_SEG_START), total,
                               ctx->buf[B_TABLES].p, dev<uint32_t>(ctx, B_PARTIAL), d_out, data_len,
-                              ctx->stream);
+                              ctx->stream, max_segs, groups > 0 ? dev<uint32_t>(ctx, B_PARTIAL2) : nullptr);
   HIP_TRY(ctx, hipGetLastError());
   return S3S_OK;
 }

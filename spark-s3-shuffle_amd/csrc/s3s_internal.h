@@ -77,11 +77,23 @@ void launch_gather_items(const uint8_t* d_src, const Item* d_items, int32_t n_it
 //   d_tables: constant tables (checksum_tables_build), d_partial: 4 x uint32 per segment slot
 size_t checksum_tables_bytes();
 void checksum_tables_build(void* host_buf);
+//   max_segs_per_range / d_partial2: a range of more than kChecksumFoldFrom segments has groups of kChecksumFoldGroup
+//   segments folded first (checksum_fold_kernel); d_partial2 then holds 4 x uint32 per (range, group):
+//   n x checksum_fold_groups(n, max_segs_per_range) entries.  nullptr / 0: no folding (one wavefront folds a whole range).
 void launch_checksum_with_tables(int algo, const uint8_t* d_data, const int64_t* d_offsets,
                                  int32_t n, const int32_t* d_seg_start, int32_t total_segs,
                                  const void* d_tables, uint32_t* d_partial, int64_t* d_out,
-                                 int64_t data_len /* bytes readable at d_data */, hipStream_t st);
+                                 int64_t data_len /* bytes readable at d_data */, hipStream_t st,
+                                 int32_t max_segs_per_range = 0, uint32_t* d_partial2 = nullptr);
 constexpr int kChecksumSegBytes = 16384;
+constexpr int kChecksumFoldGroup = 256;   // segments per folded group (4 MiB)
+constexpr int kChecksumFoldFrom = 2048;   // a range with more segments than this (32 MiB) is folded in two levels
+// groups per range of the folded layout, 0 = do not fold (no range is large, or n x groups would not be small)
+inline int32_t checksum_fold_groups(int32_t n, int32_t max_segs_per_range) {
+  if (max_segs_per_range <= kChecksumFoldFrom) return 0;
+  const int64_t g = ((int64_t)max_segs_per_range + kChecksumFoldGroup - 1) / kChecksumFoldGroup;
+  return (int64_t)n * g <= (1 << 20) ? (int32_t)g : 0;
+}
 
 // reduce side ------------------------------------------------------------------------------
 struct Frame {        // one discovered codec frame

@@ -58,9 +58,12 @@ def _program(needle):
     return _PROG[needle]
 
 
-def checksum_ranges(algo, data: bytes, offsets, data_len=None):
+def checksum_ranges(algo, data: bytes, offsets, data_len=None, fold_group=0):
     """algo 1 = Adler32, 2 = CRC32, 3 = CRC32C (the CRC32 kernels on the other polynomial's tables, as
-    launch_checksum_with_tables picks them); offsets: n + 1 ascending positions into data.  -> list of n checksums"""
+    launch_checksum_with_tables picks them); offsets: n + 1 ascending positions into data.  -> list of n checksums.
+    fold_group = G > 0: the two-level form for ranges of very many segments (checksum_fold_kernel over groups of G segments,
+    then the combine kernel over groups) — the product folds 256 segments from 2 048 per range on; a small G exercises the
+    same code on ranges the interpreter can afford."""
     offsets = np.asarray(offsets, np.int64)
     n = len(offsets) - 1
     seg_start = np.zeros(n + 1, np.int32)
@@ -83,6 +86,16 @@ def checksum_ranges(algo, data: bytes, offsets, data_len=None):
         prog, entry = _program(tag)
         emu.launch(prog, entry, mem, struct.pack("<QQiiQQQq", a_data, a_off, n, 0, a_seg, a_tab, a_par, dl), total, 0,
                    block_x=256, objects=_PROG["objs"])
+    unit, groups, a_in = SEG, 0, a_par
+    if fold_group:
+        groups = max(1, max((int(seg_start[p + 1] - seg_start[p]) + fold_group - 1) // fold_group for p in range(n)))
+        partial2 = np.full(4 * n * groups, 0xDEADBEEF, np.uint32)  # (never pre-zeroed by the product either)
+        a_par2 = mem.map(partial2, "partial2")
+        prog, entry = _program("checksum_fold_kernelILi%dE" % algo)
+        emu.launch(prog, entry, mem, struct.pack("<QiiQQQQii", a_off, n, 0, a_seg, a_tab, a_par, a_par2, fold_group, groups),
+                   groups * n, 0, objects=_PROG["objs"])
+        unit, a_in = fold_group * SEG, a_par2
     prog, entry = _program("checksum_combine_kernelILi%dE" % algo)
-    emu.launch(prog, entry, mem, struct.pack("<QiiQQQQ", a_off, n, 0, a_seg, a_tab, a_par, a_out), n, 0, objects=_PROG["objs"])
+    emu.launch(prog, entry, mem, struct.pack("<QiiQQQQqii", a_off, n, 0, a_seg, a_tab, a_in, a_out, unit, groups, 0), n, 0,
+               objects=_PROG["objs"])
     return [int(x) for x in out]

@@ -615,7 +615,15 @@ def _perm(a, b, sel):
     return out
 
 
+def _dot4_u32_u8(a, b, c):
+    r = c.copy()
+    for k in range(4):
+        r = r + ((a >> np.uint32(8 * k)) & np.uint32(0xFF)) * ((b >> np.uint32(8 * k)) & np.uint32(0xFF))
+    return r
+
+
 V3 = {
+    "v_dot4_u32_u8": _dot4_u32_u8,
     "v_lshl_add_u32": lambda a, b, c: _shl(a, b) + c,
     "v_add_lshl_u32": lambda a, b, c: _shl(a + b, c),
     "v_lshl_or_b32": lambda a, b, c: _shl(a, b) | c,

@@ -136,8 +136,32 @@ def test_compiled_kernels_on_the_bench_workloads(oracle):
     print("instructions per block: lz4 terasort %d, snappy terasort %d, lz4 wide rows %d, snappy wide rows %d" % tuple(counts))
     # end of round 2 (r02k): 163.2k / 161.9k / 330.5k / 319.9k on these four blocks; round 3 (stream bytes through one
     # 80-byte load + ds_bpermute instead of a 64-lane x 16-byte load: + 13 instructions per LZ4 window, - 34 % of the
-    # kernel's L1 lookups): 169.3k / 161.9k / 336.6k / 319.9k; a change that adds ~3 % shows up here
-    assert counts[0] < 174_000 and counts[1] < 167_000 and counts[2] < 346_000 and counts[3] < 330_000, counts
+    # kernel's L1 lookups): 169.3k / 161.9k / 336.6k / 319.9k; round 5 (LZ4: speculative next-window gather, records at
+    # the previous window's end, first-extension prefetch — + 46 instructions per window for - 26 % wait cycles, measured:
+    # profiles/r05_experiments.md): 192.9k / 161.9k / 363.1k / 319.9k; a change that adds ~3 % shows up here
+    assert counts[0] < 198_000 and counts[1] < 167_000 and counts[2] < 372_000 and counts[3] < 330_000, counts
+
+
+def test_speculative_paths_of_the_window_block_are_taken(oracle):
+    """round 5: the sequential entry, the stale-lane repair from the previous window's registers, the repeated gather and
+    the prefetched first extension must all occur on ordinary data (a silent fall-back to .Lw_winm would hide a regression)"""
+    import lz4_kernel as lk
+    from s3shuffle import datagen
+
+    data, offs = datagen.terasort_map_output(1 << 20, 4, seed=2, map_id=1)
+    chunk = np.asarray(data[int(offs[1]):int(offs[1]) + 32768], dtype=np.uint8).copy()
+    prof = {}
+    _check([chunk], oracle, profile=prof)
+    n = lambda name: sum(v[0] for k, v in prof.items() if k.startswith(name))  # noqa: E731
+    assert n(".Lw_winf") > 20 * n(".Lw_winm") > 0, (n(".Lw_winf"), n(".Lw_winm"))
+    assert n(".Lw_fix") > 0 and n(".Lw_exth") > 0 and n(".Lw_nopf") > 0, {k: v[0] for k, v in prof.items() if "fix" in k or "exth" in k}
+
+
+def test_round4_window_block_still_builds_and_matches(oracle):
+    """-DS3S_ENGINE_NO_SPEC = the block as it shipped in round 4 (the A/B baseline of profiles/r05_*): still exact"""
+    rng = np.random.default_rng(29)
+    chunks = [corpus.chunk_corpus(k, n, rng) for k, n in [(7, 20000), (3, 9000), (2, 3000)]]
+    _check(chunks, oracle, flags=("-DS3S_ENGINE_NO_SPEC",))
 
 
 def test_window_blocks_take_their_rare_paths(oracle):
@@ -600,6 +624,10 @@ def test_compiled_checksum_kernels(algo, oracle):
     assert ck.checksum_ranges(algo, zeros, [0, 40_000]) == [f(zeros)]
     ff = b"\xff" * 100_000
     assert ck.checksum_ranges(algo, ff, [0, 100_000]) == [f(ff)]
+    # the two-level form of very large ranges (checksum_fold_kernel), with groups of 3 segments instead of the product's 256
+    offs = [0, 5, 5, 16384 * 3, 16384 * 7 + 100, 120_000]
+    assert ck.checksum_ranges(algo, data, offs, fold_group=3) == [f(data[a:b]) for a, b in zip(offs, offs[1:])]
+    assert ck.checksum_ranges(algo, ff, [0, 100_000], fold_group=2) == [f(ff)]
     # offsets computed on the device after a capacity overflow exceed the caller's buffer: those ranges are skipped, not read
     got = ck.checksum_ranges(algo, data[:50_000], [0, 20_000, 50_000, 90_000, 120_000], data_len=50_000)
     assert got[:2] == [f(data[:20_000]), f(data[20_000:50_000])]
