@@ -900,6 +900,109 @@ __global__ __launch_bounds__(kWave) void xxh32_items_wave_kernel(
   if (lane == 0) item_check[it] = h;
 }
 
+
+// Round 5: four lanes per chunk, sixteen chunks per wavefront.  xxHash32 is four serial chains per chunk (the stripe
+// accumulators); one wavefront per chunk kept 4 of 64 lanes busy and spent the rest on cross-lane reads (1.36 TB/s on
+// a 1 GiB block, 0.34 ms in front of every map-side call).  Here lane 4 b + k is accumulator k of the wavefront's chunk b
+// and reads its own dword of every stripe: a quad reads 16 contiguous bytes per load, eight stripes ahead.
+template <bool kNonTemporal>
+__global__ __launch_bounds__(kWave) void xxh32_items_quad_kernel(
+    const uint8_t* __restrict__ src, const Item* __restrict__ items, int32_t n_items, uint32_t seed,
+    uint32_t* __restrict__ item_check) {
+  const int lane = threadIdx.x, k = lane & 3;
+  const int it = (int)blockIdx.x * 16 + (lane >> 2);
+  Item item;
+  item.src_off = 0;
+  item.len = 0;
+  item.kind = 0;
+  item.chunk = 0;
+  if (it < n_items) item = items[it];
+  const bool mine = it < n_items && (item.kind & 0xff) == kItemLz4Chunk;
+  const int len = mine ? item.len : 0;
+  const uint8_t* g = src + item.src_off;
+  typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+  auto ld = [&](int byte_pos) -> uint32_t {
+    const u32_unaligned* q = reinterpret_cast<const u32_unaligned*>(g + byte_pos);
+    return kNonTemporal ? __builtin_nontemporal_load(q) : *q;
+  };
+  uint32_t acc = k == 0 ? seed + XXP1 + XXP2 : k == 1 ? seed + XXP2 : k == 2 ? seed : seed - XXP1;
+  const int stripes = len >> 4;
+  int i = 0;
+  // The chain of a chunk is 2 048 dependent rounds (~14 cycles each) and a map task has only 4 096 chunks = 256 wavefronts
+  // of this kernel: nothing else hides the memory latency, so every lane keeps kDepth stripes (kDepth dwords) in flight — a
+  // ring of registers, refilled sixteen at a time while the sixteen before them are consumed (first version: 8 in flight,
+  // 1.08 ms per two map tasks; the round-2 kernel with one wavefront per chunk: 0.34 ms).
+  // Chunks of a wavefront differ in length (every partition ends with a short one, and the plan has items that are not
+  // chunks): NO branch may depend on that, or the compiler can no longer count the loads in flight and waits for all of
+  // them at every use (measured: 409 cycles per round).  So every lane streams — a lane without 16 stripes of its own
+  // reads the chunk of the wavefront's first lane that has them and discards the result — and a lane whose chunk ends
+  // early clamps its stripe index and stops accumulating (one select per 16 rounds).
+  const int s16 = stripes & ~15;
+  const unsigned long long good = __ballot(s16 > 0);
+  int wmax = s16;
+#pragma unroll
+  for (int d = 32; d >= 4; d >>= 1) {
+    const int o = __shfl_xor(wmax, d);
+    wmax = o > wmax ? o : wmax;
+  }
+  wmax = __builtin_amdgcn_readfirstlane(wmax);
+  constexpr int kDepth = 48;  // (vmcnt counts to 63: more loads in flight cannot be waited for selectively)
+  if (good != 0ull) {
+    const int donor = (int)__builtin_ctzll(good);
+    // (offsets, not pointers, cross the lanes: a pointer rebuilt from integers loses its address space and the loads become
+    // flat_load, whose second counter forces a wait for ALL of them)
+    const uint64_t od = (uint64_t)(uint32_t)__shfl((int)(uint32_t)(uint64_t)item.src_off, donor) |
+                        ((uint64_t)(uint32_t)__shfl((int)(uint32_t)((uint64_t)item.src_off >> 32), donor) << 32);
+    const int sd = __shfl(s16, donor);
+    const uint8_t* gr = src + (s16 > 0 ? item.src_off : (int64_t)od);  // what this lane streams
+    const int last = (s16 > 0 ? s16 : sd) - 1;                                            // its last whole stripe
+    auto ldr = [&](int t) -> uint32_t {
+      const u32_unaligned* q = reinterpret_cast<const u32_unaligned*>(gr + 16 * (t < last ? t : last) + 4 * k);
+      return kNonTemporal ? __builtin_nontemporal_load(q) : *q;
+    };
+    uint32_t w[kDepth];
+#pragma unroll
+    for (int j = 0; j < kDepth; j++) w[j] = ldr(j);
+    // invariant: the ring holds stripes i .. i + kDepth - 1 (clamped)
+    for (; i + kDepth <= wmax; i += kDepth) {  // one turn: every group is consumed, then loaded kDepth stripes ahead
+#pragma unroll
+      for (int gq = 0; gq < kDepth / 16; gq++) {
+        uint32_t a = acc;
+#pragma unroll
+        for (int j = 0; j < 16; j++) a = rotl32(a + w[16 * gq + j] * XXP2, 13) * XXP1;
+        acc = i + 16 * gq < s16 ? a : acc;
+#pragma unroll
+        for (int j = 0; j < 16; j++) w[16 * gq + j] = ldr(i + kDepth + 16 * gq + j);
+      }
+    }
+#pragma unroll
+    for (int gq = 0; gq < kDepth / 16; gq++) {
+      uint32_t a = acc;
+#pragma unroll
+      for (int j = 0; j < 16; j++) a = rotl32(a + w[16 * gq + j] * XXP2, 13) * XXP1;
+      acc = i + 16 * gq < s16 ? a : acc;
+    }
+    i = s16;
+  }
+  for (; i < stripes; i++) acc = rotl32(acc + ld(16 * i + 4 * k) * XXP2, 13) * XXP1;
+  const int q0 = lane & ~3;
+  const uint32_t v1 = (uint32_t)__shfl((int)acc, q0), v2 = (uint32_t)__shfl((int)acc, q0 + 1),
+                 v3 = (uint32_t)__shfl((int)acc, q0 + 2), v4 = (uint32_t)__shfl((int)acc, q0 + 3);
+  uint32_t h = len >= 16 ? rotl32(v1, 1) + rotl32(v2, 7) + rotl32(v3, 12) + rotl32(v4, 18) : seed + XXP5;
+  h += (uint32_t)len;
+  if (mine && k == 0) {
+    int p = stripes << 4;
+    for (; p + 4 <= len; p += 4) h = rotl32(h + ld(p) * XXP3, 17) * XXP4;
+    for (; p < len; p++) h = rotl32(h + (uint32_t)g[p] * XXP5, 11) * XXP1;
+    h ^= h >> 15;
+    h *= XXP2;
+    h ^= h >> 13;
+    h *= XXP3;
+    h ^= h >> 16;
+    item_check[it] = h;
+  }
+}
+
 }  // namespace
 
 void launch_lz4_compress(const uint8_t* d_src, const Item* d_items, int32_t n_items,
@@ -909,8 +1012,23 @@ void launch_lz4_compress(const uint8_t* d_src, const Item* d_items, int32_t n_it
     if (after_hash) hipEventRecord(after_hash, st);
     return;
   }
-  hipLaunchKernelGGL(xxh32_items_wave_kernel, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src, d_items,
-                     n_items, kLz4BlockSeed, d_item_check);
+  // Default (round 5): four lanes per chunk, sixteen chunks per wavefront, 48 loads in flight per lane, ORDINARY loads —
+  // measured against the per-chunk wavefronts of round 2 and against non-temporal loads (profiles/r05_experiments.md §4):
+  // hash stage of a two-task call 0.20 ms / 0.38 / 0.35 - 0.42, headline 99.2 - 99.4 / 98.1 - 98.3 / 96.6 - 98.1 GB/s, a 1 GiB
+  // block 0.22 ms (4.8 TB/s) / 0.75 / 0.53.  (Round 3 had made the pass non-temporal so that it would not displace the blocks
+  // being parsed; with the block touch inside the persistent wavefront that no longer shows, and the pass leaves the chunks
+  // in the Infinity Cache for that touch.)  S3S_XXH forces a variant: 0 = per-chunk wavefronts, 1 = quads, non-temporal.
+  static const int xxh_env = getenv("S3S_XXH") ? atoi(getenv("S3S_XXH")) : -1;
+  const int xxh_mode = xxh_env >= 0 ? xxh_env : 2;
+  if (xxh_mode == 0)
+    hipLaunchKernelGGL(xxh32_items_wave_kernel, dim3((unsigned)n_items), dim3(kWave), 0, st, d_src, d_items,
+                       n_items, kLz4BlockSeed, d_item_check);
+  else if (xxh_mode == 2)
+    hipLaunchKernelGGL(xxh32_items_quad_kernel<false>, dim3((unsigned)((n_items + 15) / 16)), dim3(kWave), 0, st, d_src, d_items,
+                       n_items, kLz4BlockSeed, d_item_check);
+  else
+    hipLaunchKernelGGL(xxh32_items_quad_kernel<true>, dim3((unsigned)((n_items + 15) / 16)), dim3(kWave), 0, st, d_src, d_items,
+                       n_items, kLz4BlockSeed, d_item_check);
   if (after_hash) hipEventRecord(after_hash, st);
 #ifdef S3S_X_GTAB
   {

@@ -1,7 +1,7 @@
 """One whole map-side call (LZ4 + checksum) through the compiled kernels on the CPU (TEST INFRASTRUCTURE): the launches of
 compress_core in csrc/codec_api.hip in their order —
 
-    xxh32_items_wave_kernel   (frame checks)          csrc/lz4_compress.hip
+    xxh32_items_quad_kernel   (frame checks)          csrc/lz4_compress.hip
     lz4_compress_l2_kernel    (blocks + end frames)   csrc/lz4_compress.hip   (persistent grid: one wavefront draws every item)
     scan_items_kernel         (item offsets + index)  csrc/assemble.hip
     gather_items_kernel       (.data image)           csrc/assemble.hip       (256-thread workgroups)
@@ -85,8 +85,9 @@ def compress_map_output(parts, algo, dst_bytes, codec=1, block=None):
         emu.launch(prog, entry, mem, struct.pack("<QQiiQqQ", a_src, a_items, n_items, 0, a_slots, stride, a_size), n_items, 32768,
                    objects=objs)
     elif n_items:
-        prog, entry, objs = _prog("lz4_compress.hip", "xxh32_items_wave_kernel")
-        emu.launch(prog, entry, mem, struct.pack("<QQiIQ", a_src, a_items, n_items, SEED, a_check), n_items, 0, objects=objs)
+        # the kernel launch_lz4_compress launches by default: four lanes per chunk, sixteen chunks per wavefront, ordinary loads
+        prog, entry, objs = _prog("lz4_compress.hip", "xxh32_items_quad_kernelILb0E")
+        emu.launch(prog, entry, mem, struct.pack("<QQiIQ", a_src, a_items, n_items, SEED, a_check), (n_items + 15) // 16, 0, objects=objs)
         prog, entry, objs = _prog("lz4_compress.hip", "lz4_compress_l2_kernelILb1E")
         emu.launch(prog, entry, mem, struct.pack("<QQiiQQQQ", a_src, a_items, n_items, stride, a_check, a_slots, a_size, a_work), 1, 16384,
                    objects=objs)
