@@ -957,6 +957,20 @@ def run_hbm_stages(args, local_rank: int):
     c.close()
     del d, dst
     torch.cuda.synchronize()
+    # roofline.traffic of these lines: the stamped PMC pass of the same command (tools/r4_profile.sh hbm, tools/r4_report.py)
+    try:
+        ref = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+        stamp = _kernel_stamp()
+        for key, e in res.items():
+            if not isinstance(e, dict) or "roofline" not in e:
+                continue
+            t = ref.get("hbm-stages:adler32" if ":adler32:" in key else "hbm-stages:crc32" if ":crc32" in key else "hbm-stages:xxh32" if key.startswith("xxh32") else "")
+            if t and stamp and t.get("kernel_sources_sha256") == stamp:
+                e["roofline"]["traffic"] = int(t["hbm_bytes_per_launch"])
+                e["roofline"]["traffic_over_algorithmic"] = round(t["hbm_bytes_per_launch"] / n_bytes, 3)
+                e["roofline"]["traffic_source"] = t.get("source")
+    except Exception:
+        pass
     return res
 
 
@@ -982,6 +996,11 @@ def run_block_size_sweep(args, rank: int, local_rank: int, have: dict):
             a = copy.copy(args)
             a.workload, a.direction, a.map_mib, a.maps_per_gpu = "skew-1part-lz4", direction, mib, maps
             a.steps, a.warmup, a.task_threads, a.batch, a.verify, a.no_cpu_baseline = 6, 2, 0, -1, False, True
+            if direction == "compress" and mib * maps <= 256:
+                # small blocks: ONE batched call over all blocks of the step (what the shim's commit queue does with the commits of
+                # concurrent tasks, S3GpuCommitQueue): 8 x 8 MiB split over four task threads are four launches of 512 block
+                # chains each on a chip that holds 2 560 — every one of them lasts a whole block chain (0.8 ms)
+                a.task_threads = 1
             try:
                 o = run_workload(a, rank, local_rank, 1, None)
                 point[direction], point[direction + "_ms_per_step"] = o["value"], o["ms_per_step"]

@@ -82,8 +82,17 @@ void s3s_destroy(s3s_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
-  if (ctx->hb_in) hipStreamSynchronize(ctx->hb_in);
-  if (ctx->hb_out) hipStreamSynchronize(ctx->hb_out);
+  // the copy lanes may be the device's SHARED ones (host_batch.hip's arbiter): wait for what THIS context put on them (its
+  // group events), not for other contexts' DMA — reaping a dead task thread's context must not stall behind live ones (advisor r4)
+  if (ctx->hb_shared) {
+    for (int i = 0; i < 2; i++) {
+      if (ctx->hb_ev_in[i]) hipEventSynchronize(ctx->hb_ev_in[i]);
+      if (ctx->hb_ev_out[i]) hipEventSynchronize(ctx->hb_ev_out[i]);
+    }
+  } else {
+    if (ctx->hb_in) hipStreamSynchronize(ctx->hb_in);
+    if (ctx->hb_out) hipStreamSynchronize(ctx->hb_out);
+  }
   for (auto& b : ctx->buf)
     if (b.p) hipFree(b.p);
   if (ctx->h_stage) hipHostFree(ctx->h_stage);

@@ -216,28 +216,6 @@ struct TabLds {
   };
   __device__ __forceinline__ Cell operator[](uint32_t i) const { return Cell{t + i}; }
 };
-#ifdef S3S_X_GTAB
-struct TabGlobal {
-  static constexpr bool kLds = false;
-  uint16_t* t;
-  struct Cell {
-    uint16_t* p;
-    __device__ __forceinline__ operator uint32_t() const {
-      uint32_t v;
-      asm volatile("global_load_ushort %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-      return v;
-    }
-    __device__ __forceinline__ void operator=(uint16_t v) const {
-#ifdef S3S_X_GTAB_SAFE  // wait for the store's acknowledgement before anything else of this wave touches memory
-      asm volatile("global_store_short %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" ::"v"(p), "v"((uint32_t)v) : "memory");
-#else
-      asm volatile("global_store_short %0, %1, off sc1" ::"v"(p), "v"((uint32_t)v) : "memory");
-#endif
-    }
-  };
-  __device__ __forceinline__ Cell operator[](uint32_t i) const { return Cell{t + i}; }
-};
-#endif
 
 #ifndef S3S_FAST_STEPS
 #define S3S_FAST_STEPS 5  // measured: 3 -> 45.3, 5 -> 45.4 GB/s (TeraSort, two task threads), 21.2 vs 20.6 on wide rows
@@ -854,38 +832,6 @@ __global__ __launch_bounds__(kWave) void lz4_compress_l2_kernel(
   }
 }
 
-#ifdef S3S_X_GTAB
-template <bool kWindows>
-__global__ __launch_bounds__(kWave) void lz4_compress_gtab_kernel(
-    const uint8_t* __restrict__ src, const Item* __restrict__ items, int32_t i0, int32_t i1,
-    const uint32_t* __restrict__ item_check, uint8_t* __restrict__ slots, uint32_t* __restrict__ item_size,
-    uint16_t* __restrict__ tables, int32_t stride) {
-  const int lane = threadIdx.x;
-  uint16_t* table = tables + (size_t)blockIdx.x * 8192;
-  for (int it = i0 + blockIdx.x; it < i1; it += stride) {  // static round-robin: wavefront b takes items b, b + stride, ...
-    const Item item = items[it];
-    const int kind = item.kind & 0xff;
-    if (kind != kItemLz4Chunk) {
-      if (lane == 0 && kind == kItemLz4End) item_size[it] = kLz4FrameHeader;
-      continue;
-    }
-    {
-      uint4* tz = reinterpret_cast<uint4*>(table);
-      for (int i = lane; i < 16384 / 16; i += kWave) tz[i] = make_uint4(0, 0, 0, 0);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-    uint8_t* slot = slots + (size_t)item.chunk * kSlotBytes;
-    const uint32_t check = item_check[it];
-    const int clen = lz4_compress_wave<SrcGlobal, kWindows, TabGlobal>(SrcGlobal{src + item.src_off}, TabGlobal{table}, item.len,
-                                                                       slot + kSlotHeader, lane);
-    finish_frame(slot, item.len, clen, check, item.kind >> 8, item_size + it, lane);
-  }
-}
-template __global__ void lz4_compress_gtab_kernel<true>(const uint8_t*, const Item*, int32_t, int32_t, const uint32_t*, uint8_t*,
-                                                        uint32_t*, uint16_t*, int32_t);
-template __global__ void lz4_compress_gtab_kernel<false>(const uint8_t*, const Item*, int32_t, int32_t, const uint32_t*, uint8_t*,
-                                                         uint32_t*, uint16_t*, int32_t);
-#endif
 
 // one wavefront per chunk, coalesced streaming (xxh32_wave): ~3x the 4-lanes-per-chunk kernel above
 __global__ __launch_bounds__(kWave) void xxh32_items_wave_kernel(
@@ -1030,46 +976,6 @@ void launch_lz4_compress(const uint8_t* d_src, const Item* d_items, int32_t n_it
     hipLaunchKernelGGL(xxh32_items_quad_kernel<true>, dim3((unsigned)((n_items + 15) / 16)), dim3(kWave), 0, st, d_src, d_items,
                        n_items, kLz4BlockSeed, d_item_check);
   if (after_hash) hipEventRecord(after_hash, st);
-#ifdef S3S_X_GTAB
-  {
-    // S3S_X_GTAB_WAVES = wavefronts per CU of the global-table kernel (0: off), S3S_X_GTAB_PCT = share of the items it gets
-    // (100: it runs alone; otherwise it runs on a second stream next to the LDS kernel)
-    static const int gw = getenv("S3S_X_GTAB_WAVES") ? atoi(getenv("S3S_X_GTAB_WAVES")) : 0;
-    static const int pct = getenv("S3S_X_GTAB_PCT") ? atoi(getenv("S3S_X_GTAB_PCT")) : 100;
-    if (gw > 0) {
-      static uint16_t* tables = nullptr;
-      static hipStream_t st2 = nullptr;
-      static hipEvent_t ev_a = nullptr, ev_b = nullptr;
-      const int grid = gw * 256;
-      if (!tables) {
-        (void)hipMalloc(&tables, (size_t)grid * 16384);
-        (void)hipStreamCreateWithFlags(&st2, hipStreamNonBlocking);
-        (void)hipEventCreateWithFlags(&ev_a, hipEventDisableTiming);
-        (void)hipEventCreateWithFlags(&ev_b, hipEventDisableTiming);
-      }
-      const int32_t n_g = (int32_t)((int64_t)n_items * pct / 100);
-      (void)hipEventRecord(ev_a, st);
-      (void)hipStreamWaitEvent(st2, ev_a, 0);
-      if (n_g > 0) {
-        if (variant == 1)
-          hipLaunchKernelGGL(lz4_compress_gtab_kernel<false>, dim3((unsigned)grid), dim3(kWave), 0, st2, d_src, d_items, 0, n_g,
-                             d_item_check, d_slots, d_item_size, tables, grid);
-        else
-          hipLaunchKernelGGL(lz4_compress_gtab_kernel<true>, dim3((unsigned)grid), dim3(kWave), 0, st2, d_src, d_items, 0, n_g,
-                             d_item_check, d_slots, d_item_size, tables, grid);
-      }
-      if (n_g < n_items)
-      {
-        (void)hipMemsetAsync(d_work, 0, sizeof(uint32_t), st);
-        hipLaunchKernelGGL(lz4_compress_l2_kernel<true>, dim3((unsigned)std::min(n_items - n_g, resident_waves)), dim3(kWave), 0, st, d_src,
-                           d_items + n_g, n_items - n_g, slot_stride, d_item_check + n_g, d_slots, d_item_size + n_g, d_work);
-      }
-      (void)hipEventRecord(ev_b, st2);
-      (void)hipStreamWaitEvent(st, ev_b, 0);
-      return;
-    }
-  }
-#endif
   // d_work: the launch's block counter (zeroed in stream order); resident_waves: 10 per CU
   (void)hipMemsetAsync(d_work, 0, sizeof(uint32_t), st);
   static const int grid_env = getenv("S3S_LZ4_GRID") ? atoi(getenv("S3S_LZ4_GRID")) : 0;  // (experiments)

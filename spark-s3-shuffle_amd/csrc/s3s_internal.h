@@ -24,7 +24,6 @@ constexpr int kLz4MaxBlock = 65536;       // largest LZ4 chunk of the map side (
                                           // 4096 x u32 table with a 5-byte hash: another parse, not built
 constexpr int kBatchMaxBlock = 1 << 25;   // largest LZ4Block frame the batch decoder takes (lz4-java's MAX_BLOCK_SIZE)
 constexpr int kSlotHeader = 32;           // bytes reserved in front of a slot's payload
-constexpr int kSlotBytes = kSlotHeader + kMaxBlock;
 constexpr int kLz4FrameHeader = 21;       // "LZ4Block" + token + 3 x i32
 constexpr int kSnappyStreamHeader = 16;
 constexpr uint32_t kLz4BlockSeed = 0x9747b28cu;

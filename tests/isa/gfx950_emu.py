@@ -275,6 +275,7 @@ class Wave:
         self.n_taken = 0
         self.n_salu = self.n_valu = self.n_lds = self.n_vmem = self.n_smem = 0
         self.clock = 0
+        self.sgpr_ready = {}  # SGPR -> cycle at which a VALU-produced value can be read by the scalar unit (Cost.CROSS)
         self.trace = None
         self.region_counts = None
         # outstanding memory operations, oldest first: lists of pending destination VGPR numbers ([] for stores)
@@ -1678,6 +1679,7 @@ class Cost:
     VMEM = 700
     VMEM_STORE = 300
     SMEM = 200
+    CROSS = 25  # VALU result in an SGPR -> first scalar instruction that may read it (issue_probe: 30 per producer + consumer pair)
 
 
 def run_wave(prog, w, entry=None, max_inst=50_000_000, profile=None, hooks=None):
@@ -1723,6 +1725,27 @@ def run_wave(prog, w, entry=None, max_inst=50_000_000, profile=None, hooks=None)
             w.n_vmem += 1
         else:
             w.n_smem += 1
+        # VALU -> SGPR -> SALU crossing (round 5, tools/probe/issue_probe.hip on the MI355X: a v_readlane / v_cmp whose SGPR
+        # result the NEXT scalar instruction reads costs the pair 30 cycles instead of 9.4): the scalar consumer waits until
+        # Cost.CROSS cycles after the producer issued; independent instructions in between hide it.
+        if k == "valu":
+            d = i.ops[0] if i.ops else None
+            if d is not None and d[0] == "s":
+                for r in range(d[1], d[1] + d[2]):
+                    w.sgpr_ready[r] = w.clock + Cost.CROSS
+            elif op.startswith("v_cmp") and op.endswith("_e32"):
+                w.sgpr_ready[VCC] = w.sgpr_ready[VCC + 1] = w.clock + Cost.CROSS
+        elif k == "salu" and w.sgpr_ready:
+            t = 0
+            for o in (i.ops[1:] if len(i.ops) > 1 else i.ops):
+                if o[0] == "s":
+                    for r in range(o[1], o[1] + o[2]):
+                        t = max(t, w.sgpr_ready.get(r, 0))
+            if op.startswith("s_cbranch_vcc"):
+                t = max(t, w.sgpr_ready.get(VCC, 0), w.sgpr_ready.get(VCC + 1, 0))
+            if t > w.clock:
+                w.n_cross_wait = getattr(w, "n_cross_wait", 0) + (t - w.clock)
+                w.clock = t
         w.clock += Cost.ISSUE
         if i.target is not None:
             if op == "s_branch":

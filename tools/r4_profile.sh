@@ -14,6 +14,7 @@ python tools/src_stamp.py > $O/kernel_sources_sha256.txt
 prof() {  # prof <name> <bench args...>
   local P=$O/prof_$1; shift; mkdir -p $P
   local CMD="python $R/bench.py --no-cpu-baseline --no-secondary --steps 3 --warmup 1 $*"
+  if [ "$1" = "--hbm-stages-only" ]; then CMD="python $R/bench.py --hbm-stages-only"; fi
   echo "$CMD" > $P/command.txt
   cd /tmp
   timeout 200 rocprofv3 --kernel-trace --stats -d $P/trace -o t -- $CMD > $P/trace.log 2>&1
@@ -35,6 +36,7 @@ for s in $SETS; do
     crc2000) prof crc2000 --workload terasort-100g-2000p-lz4-crc32 --maps-per-gpu 4 ;;
     snappy_decompress) prof snappy_decompress --workload tpcds-wide-100g-200p-snappy --direction decompress --maps-per-gpu 4 ;;
     zstd) prof zstd --workload terasort-10g-200p-zstd --direction decompress ;;
+    hbm) prof hbm --hbm-stages-only ;;  # round 5: checksum-only / xxHash32 lines on a 1 GiB range
   esac
   head -12 $O/prof_$s/summary.md | cut -c1-200
 done

@@ -35,7 +35,11 @@ SETS = {
     "decompress": ("batch_decode_kernel<0>", "terasort-10g-200p-lz4:decompress", 4),
     "crc2000": ("lz4_compress_l2_kernel<true>", "terasort-100g-2000p-lz4-crc32:compress", 1),
     "snappy_decompress": ("batch_decode_kernel<1>", "tpcds-wide-100g-200p-snappy:decompress", 4),
+    "zstd": ("zstd_partitions_kernel", "terasort-10g-200p-zstd:decompress", 8),
 }
+# round 5: the HBM-bound stage lines (bench.py --hbm-stages-only): traffic per launch of each kernel, keyed for run_hbm_stages
+HBM_KERNELS = {"checksum_segments_kernel<1>": "hbm-stages:adler32", "checksum_segments_kernel<2>": "hbm-stages:crc32",
+               "xxh32_items_quad_kernel<false>": "hbm-stages:xxh32"}
 stamp_file = os.path.join(G, "kernel_sources_sha256.txt")
 stamp = open(stamp_file).read().strip() if os.path.exists(stamp_file) else None
 traffic_file = os.path.join(P, "traffic_latest.json")
@@ -72,7 +76,8 @@ for name, (kernel, key, tasks) in SETS.items():
         "hbm_bytes_per_launch": int((2 * c.get("FETCH_SIZE", 0) + c.get("WRITE_SIZE", 0)) * 1024),
         "pmc": {x: round(v, 1) for x, v in sorted(c.items())},
     }
-    cal = d["pmc"].get("xxh32_items_wave_kernel", {}).get("FETCH_SIZE") or d["pmc"].get("lz4_verify_frames_kernel", {}).get("FETCH_SIZE")
+    cal = (d["pmc"].get("xxh32_items_quad_kernel<false>", {}).get("FETCH_SIZE") or d["pmc"].get("xxh32_items_wave_kernel", {}).get("FETCH_SIZE")
+           or d["pmc"].get("lz4_verify_frames_kernel", {}).get("FETCH_SIZE"))
     der["fetch_calibration_kernel_kb"] = cal
     json.dump({"derived": der, "kernels": d["kernels"], "pmc": d["pmc"]}, open(os.path.join(P, f"{tag}_{name}_rocprofv3_summary.json"), "w"), indent=1)
     with open(os.path.join(P, f"{tag}_{name}_rocprofv3_summary.md"), "w") as f:
@@ -95,6 +100,27 @@ for name, (kernel, key, tasks) in SETS.items():
                     "source": f"profiles/{tag}_{name}_rocprofv3_summary.md ({cmd}; 2 x FETCH_SIZE + WRITE_SIZE, gfx950 half-count "
                               f"correction calibrated on the streaming kernel of the same run)"}
     print(name, json.dumps({a: b for a, b in der.items() if a != "pmc"}))
+hsrc = os.path.join(G, "prof_hbm", "summary.json")
+if os.path.exists(hsrc):
+    d = json.load(open(hsrc))
+    rows = []
+    for kn, key in HBM_KERNELS.items():
+        c, k = d["pmc"].get(kn, {}), d["kernels"].get(kn)
+        if not c or not k:
+            continue
+        hbm = int((2 * c.get("FETCH_SIZE", 0) + c.get("WRITE_SIZE", 0)) * 1024)
+        traffic[key] = {"kernel": kn, "hbm_bytes_per_launch": hbm, "fetch_kb": round(c.get("FETCH_SIZE", 0), 1), "write_kb": round(c.get("WRITE_SIZE", 0), 1),
+                        "avg_kernel_us": round(k["avg_ns"] / 1e3, 1), "commit": commit, "kernel_sources_sha256": stamp,
+                        "source": f"profiles/{tag}_hbm_rocprofv3_summary.md (bench.py --hbm-stages-only; 2 x FETCH_SIZE + WRITE_SIZE per launch over a 1 GiB range)"}
+        rows.append((kn, k, c, hbm))
+    json.dump({"kernels": d["kernels"], "pmc": d["pmc"]}, open(os.path.join(P, f"{tag}_hbm_rocprofv3_summary.json"), "w"), indent=1)
+    with open(os.path.join(P, f"{tag}_hbm_rocprofv3_summary.md"), "w") as f:
+        f.write(f"# {tag} — rocprofv3 of `bench.py --hbm-stages-only` (commit {commit}): checksums and xxHash32 over a 1 GiB range\n\n")
+        f.write("| kernel | calls | avg us (trace) | HBM bytes per launch (2 x FETCH + WRITE) | bytes / 2^30 | SALU + VALU instructions | LDS instructions | wave cycles in s_waitcnt |\n|---|---|---|---|---|---|---|---|\n")
+        for kn, k, c, hbm in rows:
+            f.write(f"| {kn} | {k['calls']} | {k['avg_ns']/1e3:.1f} | {hbm} | {hbm / 2**30:.3f} | {c.get('SQ_INSTS_SALU', 0) + c.get('SQ_INSTS_VALU', 0):.0f} | "
+                    f"{c.get('SQ_INSTS_LDS', 0):.0f} | {c.get('SQ_WAIT_ANY', 0) / max(c.get('SQ_WAVE_CYCLES', 1), 1):.3f} |\n")
+    print("hbm", {k: traffic[k]["hbm_bytes_per_launch"] for k in traffic if k.startswith("hbm-stages")})
 json.dump(traffic, open(traffic_file, "w"), indent=1)
 for f in sorted(os.listdir(G)):
     if f.startswith("bench") and f.endswith(".json"):

@@ -1,0 +1,30 @@
+#!/bin/bash
+# (GPU) round-5 closing call: GPU suite, the driver's bench line, then the PMC profile of exactly these sources
+#   gpurun --timeout 2700 -- 'bash tools/r5_final.sh r05z "compress decompress crc2000 snappy_compress snappy_decompress zstd hbm"'
+#   then here: python tools/r4_report.py r05z    (profiles/r05z_*, profiles/traffic_latest.json)
+tag=${1:-r05z}
+R=$GRAFT_REPO_ROOT; cd $R; export TMPDIR=/tmp
+O=gpurun_out/$tag; mkdir -p $O
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 | tee $O/pytest_gpu.txt
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2>$O/bench_full.err | grep '^{' > $O/bench_full.json
+python - <<PY | tee $O/bench_full.txt
+import json
+d = json.loads(open("$O/bench_full.json").read())
+print("headline", d["value"], "GB/s; ms/step", d["ms_per_step"], "; cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["kind"], "speedup", d.get("speedup_vs_cpu_all_cores"),
+      "roofline", {k: d["roofline"].get(k) for k in ("achieved", "frac", "avg_launch_ms", "traffic", "traffic_over_algorithmic")})
+for k, v in d.get("secondary", {}).items():
+    if isinstance(v, dict) and "value" in v:
+        cb = v.get("cpu_baseline") or {}
+        print(" ", k, v["value"], "| cpu", cb.get("value"), cb.get("kind"), "x", v.get("speedup_vs_cpu_all_cores"), "| verified", v.get("bytes_verified"))
+    elif isinstance(v, dict) and "error" in v:
+        print(" ", k, "ERROR", v["error"])
+for p in d.get("secondary", {}).get("block_size_sweep", {}).get("points", []):
+    print("  sweep", p["block_MiB"], "MiB x", p["blocks_per_step"], ":", p.get("compress"), "/", p.get("decompress"), "threads", p.get("compress_task_threads"))
+for k, v in d.get("secondary", {}).get("hbm_bound_stages", {}).items():
+    if isinstance(v, dict) and "roofline" in v:
+        print("  hbm", k, v["value"], "achieved", v["roofline"]["achieved"], "frac", v["roofline"]["frac"], "traffic", v["roofline"].get("traffic"))
+h = d.get("secondary", {}).get("host_path", {})
+print("  host_path", h.get("compress_by_task_threads"), h.get("verify_decompress_by_task_threads"))
+print("  wall", d.get("secondary", {}).get("wall_s_total"))
+PY
+if [ -n "$2" ]; then bash tools/r4_profile.sh $tag "$2" 2>&1 | tail -60; fi
