@@ -996,10 +996,12 @@ def run_block_size_sweep(args, rank: int, local_rank: int, have: dict):
             a = copy.copy(args)
             a.workload, a.direction, a.map_mib, a.maps_per_gpu = "skew-1part-lz4", direction, mib, maps
             a.steps, a.warmup, a.task_threads, a.batch, a.verify, a.no_cpu_baseline = 6, 2, 0, -1, False, True
-            if direction == "compress" and mib * maps <= 256:
+            if direction == "compress" and mib * maps <= 64:
                 # small blocks: ONE batched call over all blocks of the step (what the shim's commit queue does with the commits of
                 # concurrent tasks, S3GpuCommitQueue): 8 x 8 MiB split over four task threads are four launches of 512 block
-                # chains each on a chip that holds 2 560 — every one of them lasts a whole block chain (0.8 ms)
+                # chains each on a chip that holds 2 560 — every one of them lasts a whole block chain (0.8 ms).  Measured
+                # (profiles/r05z_bench_full.json): 48.9 GB/s against 47.1 with four threads; at 8 x 32 MiB one thread LOSES (72.7
+                # against 77.9: the stages of one call no longer overlap another call's codec kernel), so only the smallest point
                 a.task_threads = 1
             try:
                 o = run_workload(a, rank, local_rank, 1, None)

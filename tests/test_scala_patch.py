@@ -244,3 +244,18 @@ def test_calls_of_the_natives_pass_as_many_arguments_as_they_declare():
             assert n == decl[m.group(1)], (f, m.group(1), n, decl[m.group(1)])
             calls += 1
     assert calls >= 15
+
+
+def test_commit_queue_never_reads_a_refused_call_as_empty_map_outputs():
+    """advisor r4: a fresh `Array[Int]` is all zeros = all S3S_OK.  The JNI unit and the library refuse some calls before any
+    per-task stamping; the queue must (a) pre-fill the status array with STATUS_NOT_RUN before the native call, (b) treat
+    "call failed, every entry OK" as a call failure, and (c) not wait for ever on a worker thread that has died."""
+    src = open(os.path.join(ROOT, "scala", "org", "apache", "spark", "shuffle", "gpu", "S3GpuCommitQueue.scala")).read()
+    fill = src.index("java.util.Arrays.fill(status, S3SCodec.STATUS_NOT_RUN)")
+    call = src.index("S3SCodec.compressMapOutputsBatch(")
+    assert fill < call, "the status array must be stamped before the native call"
+    assert "rc != S3SCodec.OK && status.forall(_ == S3SCodec.OK)" in src
+    assert "r.done.await(1, java.util.concurrent.TimeUnit.SECONDS)" in src and "!w.isAlive" in src
+    jni = open(os.path.join(ROOT, "jni", "s3s_jni.c")).read()
+    body = jni[jni.index("FN(compressMapOutputsBatch)"):]
+    assert body.index("not_run(e, outStatus)") < body.index("same_length("), "the JNI unit stamps before its first refusal"
