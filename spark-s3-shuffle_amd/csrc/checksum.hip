@@ -60,22 +60,26 @@ __device__ __forceinline__ uint32_t x8n(const uint32_t* x2n, uint64_t n, uint32_
 // ds_bpermute_b32 with the nibble as lane index (the LDS crossbar, no LDS memory; lanes that read the same source lane
 // are a broadcast, different ones hit different banks: conflict-free by construction).
 // Round 5: SIX-bit tables for the word step.  ds_bpermute_b32 picks one of 64 lanes, so a table of 64 entries costs the
-// same lookup as one of 16: the 32-bit word is cut into the bit groups [0:5] [6:11] [12:17] [18:23] [24:29] [30:31] — six
-// lookups per word instead of eight (the kernel is bound by the LDS crossbar: 2.08 TB/s with eight).  A group that
+// same lookup as one of 16: the 32-bit word is cut into the bit groups [0:5] [6:11] [12:17] [18:23] [24:29] [30:31] — five
+// lookups per word (the two top bits: two masked xors on the vector unit) instead of eight (the kernel is bound by the LDS
+// crossbar: 2.08 TB/s with eight, 2.5 - 2.6 with six).  A group that
 // straddles a byte boundary is the xor of two byte-table entries, folded in when the register is built.  The byte step
 // (short first pieces only) keeps its two nibble tables.
 struct NibbleTabs {
-  uint32_t g[6];  // g[k]: lane v holds f(v << 6 k), f = the four-byte step slice[3][b0] ^ slice[2][b1] ^ slice[1][b2] ^ slice[0][b3]
+  uint32_t g[5];  // g[k]: lane v holds f(v << 6 k), f = the four-byte step slice[3][b0] ^ slice[2][b1] ^ slice[1][b2] ^ slice[0][b3]
+  uint32_t f30, f31;  // f(1 << 30), f(1 << 31): the sixth group has two bits — two masked xors on the vector unit instead of a lookup
   uint32_t b[2];  // b[h]: lane v holds slice[0][h ? (v & 15) << 4 : v & 15]   (one-byte step)
 };
 __device__ __forceinline__ NibbleTabs load_nibble_tabs(const Tables* tabs, int lane) {
   NibbleTabs n;
   const uint32_t v = (uint32_t)lane & 63u;
 #pragma unroll
-  for (int k = 0; k < 6; k++) {
-    const uint32_t x = k < 5 ? v << (6 * k) : (v & 3u) << 30;
+  for (int k = 0; k < 5; k++) {
+    const uint32_t x = v << (6 * k);
     n.g[k] = tabs->slice[3][x & 0xff] ^ tabs->slice[2][(x >> 8) & 0xff] ^ tabs->slice[1][(x >> 16) & 0xff] ^ tabs->slice[0][x >> 24];
   }
+  n.f30 = tabs->slice[0][0x40];
+  n.f31 = tabs->slice[0][0x80];
   // (f(0) = 0 for every slice table, so the bytes a group does not touch add nothing — but slice[j][0] is read four times
   // per register; the tables are 4 KiB and stay in cache)
   const uint32_t w = (uint32_t)lane & 15u;
@@ -90,7 +94,8 @@ __device__ __forceinline__ uint32_t nib_lookup(uint32_t table_reg, uint32_t idx_
 __device__ __forceinline__ uint32_t crc_word(const NibbleTabs& n, uint32_t c) {
   const uint32_t a0 = nib_lookup(n.g[0], (c << 2) & 0xfcu), a1 = nib_lookup(n.g[1], (c >> 4) & 0xfcu);
   const uint32_t a2 = nib_lookup(n.g[2], (c >> 10) & 0xfcu), a3 = nib_lookup(n.g[3], (c >> 16) & 0xfcu);
-  const uint32_t a4 = nib_lookup(n.g[4], (c >> 22) & 0xfcu), a5 = nib_lookup(n.g[5], (c >> 28) & 0xcu);
+  const uint32_t a4 = nib_lookup(n.g[4], (c >> 22) & 0xfcu);
+  const uint32_t a5 = ((uint32_t)((int32_t)(c << 1) >> 31) & n.f30) ^ ((uint32_t)((int32_t)c >> 31) & n.f31);
   return (a0 ^ a1 ^ a2) ^ (a3 ^ a4 ^ a5);
 }
 __device__ __forceinline__ int wave_max_i32(int v) {
