@@ -975,6 +975,7 @@ def run_hbm_stages(args, local_rank: int):
 
 
 SWEEP = [(8, 8), (32, 8), (128, 8), (512, 2), (1024, 1)]  # (MiB per single-partition block, blocks per step)
+SWEEP_IN_FLIGHT = [(8, 32)]  # the smallest block size again with 256 MiB per step
 
 
 def run_block_size_sweep(args, rank: int, local_rank: int, have: dict):
@@ -997,12 +998,11 @@ def run_block_size_sweep(args, rank: int, local_rank: int, have: dict):
             a.workload, a.direction, a.map_mib, a.maps_per_gpu = "skew-1part-lz4", direction, mib, maps
             a.steps, a.warmup, a.task_threads, a.batch, a.verify, a.no_cpu_baseline = 6, 2, 0, -1, False, True
             if direction == "compress" and mib * maps <= 64:
-                # small blocks: ONE batched call over all blocks of the step (what the shim's commit queue does with the commits of
-                # concurrent tasks, S3GpuCommitQueue): 8 x 8 MiB split over four task threads are four launches of 512 block
-                # chains each on a chip that holds 2 560 — every one of them lasts a whole block chain (0.8 ms).  Measured
-                # (profiles/r05z_bench_full.json): 48.9 GB/s against 47.1 with four threads; at 8 x 32 MiB one thread LOSES (72.7
-                # against 77.9: the stages of one call no longer overlap another call's codec kernel), so only the smallest point
-                a.task_threads = 1
+                # small blocks: two task threads, each with ONE batched call over half of the step's blocks (what the shim's commit
+                # queue does with the commits of concurrent tasks, S3GpuCommitQueue).  8 x 8 MiB are 2 048 block chains for a chip
+                # that holds 2 560: the step lasts one block chain (0.9 - 1.0 ms) whatever the split; measured
+                # (profiles/r05k_small_blocks.txt) 49.9 / 52.4 / 42.6 / 37.9 GB/s with 1 / 2 / 4 / 8 threads
+                a.task_threads = 2
             try:
                 o = run_workload(a, rank, local_rank, 1, None)
                 point[direction], point[direction + "_ms_per_step"] = o["value"], o["ms_per_step"]
@@ -1011,6 +1011,24 @@ def run_block_size_sweep(args, rank: int, local_rank: int, have: dict):
                 point[direction] = None
                 point[direction + "_error"] = repr(e)
         res["points"].append(point)
+    # The small points above hold 64 / 256 MiB per step: they measure the LATENCY of one block chain (a 32 KiB block is 0.9 ms of
+    # serial parse whoever runs it), not what the chip does with small blocks.  The same block sizes with as many blocks per
+    # step as the executor's tasks commit together (32 x 8 MiB = 256 MiB in flight), two task threads:
+    res["points_more_blocks_in_flight"] = []
+    for mib, maps in SWEEP_IN_FLIGHT:
+        point = {"block_MiB": mib, "blocks_per_step": maps}
+        for direction in ("compress", "decompress"):
+            a = copy.copy(args)
+            a.workload, a.direction, a.map_mib, a.maps_per_gpu = "skew-1part-lz4", direction, mib, maps
+            a.steps, a.warmup, a.task_threads, a.batch, a.verify, a.no_cpu_baseline = 6, 2, 2, -1, False, True
+            try:
+                o = run_workload(a, rank, local_rank, 1, None)
+                point[direction], point[direction + "_ms_per_step"] = o["value"], o["ms_per_step"]
+                point[direction + "_task_threads"] = o["config"]["task_threads_per_gpu"]
+            except Exception as e:
+                point[direction] = None
+                point[direction + "_error"] = repr(e)
+        res["points_more_blocks_in_flight"].append(point)
     return res
 
 

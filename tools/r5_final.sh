@@ -20,6 +20,8 @@ for k, v in d.get("secondary", {}).items():
         print(" ", k, "ERROR", v["error"])
 for p in d.get("secondary", {}).get("block_size_sweep", {}).get("points", []):
     print("  sweep", p["block_MiB"], "MiB x", p["blocks_per_step"], ":", p.get("compress"), "/", p.get("decompress"), "threads", p.get("compress_task_threads"))
+for p in d.get("secondary", {}).get("block_size_sweep", {}).get("points_more_blocks_in_flight", []):
+    print("  sweep (more blocks in flight)", p["block_MiB"], "MiB x", p["blocks_per_step"], ":", p.get("compress"), "/", p.get("decompress"))
 for k, v in d.get("secondary", {}).get("hbm_bound_stages", {}).items():
     if isinstance(v, dict) and "roofline" in v:
         print("  hbm", k, v["value"], "achieved", v["roofline"]["achieved"], "frac", v["roofline"]["frac"], "traffic", v["roofline"].get("traffic"))
