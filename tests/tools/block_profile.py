@@ -44,7 +44,7 @@ def main():
         a[2] += v[2] if len(v) > 2 else 0
     print("%s %s: %.0f instructions, %.0f SALU + VALU (%.2f per byte), %.0f model cycles per 32 KiB block" % (
         wl, codec, tot_i / n, sum(w.n_salu + w.n_valu for w in ws) / n, sum(w.n_salu + w.n_valu for w in ws) / n / 32768, tot_c / n))
-    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])[:16]:
+    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])[:int(os.environ.get("ROWS", "16"))]:
         print("   %-16s instructions %7d (%4.1f %%)  taken branches %5d  model cycles %8d (%4.1f %%)" % (
             k, v[0] / n, 100 * v[0] / tot_i, v[1] / n, v[2] / n, 100 * v[2] / tot_c))
 
