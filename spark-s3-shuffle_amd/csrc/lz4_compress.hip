@@ -316,6 +316,10 @@ __device__ int lz4_compress_wave(const Src in, const Tab T, int len, uint8_t* ou
                            "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v157", "v158",
 #if !defined(S3S_ENGINE_NO_SPEC)  // speculative next-window gather: two more gather register sets, cpS, the next window's hash
                            "v155", "v156", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167",
+#if !defined(S3S_ENGINE_NO_DEFER)  // deferred emission: the waiting sequences' records (v118, v119), the flush's scratch, the record count
+                           "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110",
+                           "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "m0",
+#endif
 #elif defined(S3S_ABL_DUP_PW) || defined(S3S_ABL_DUP_GATHER) || defined(S3S_ABL_DUP_IPSIDE)
                            "v160", "v161", "v162", "v163",
 #endif

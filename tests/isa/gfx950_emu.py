@@ -517,6 +517,7 @@ V2 = {  # name -> f(src0, src1) on uint32 arrays
     "v_xor_b32": lambda a, b: a ^ b,
     "v_xnor_b32": lambda a, b: ~(a ^ b),
     "v_lshlrev_b32": lambda a, b: _shl(b, a),
+    "v_bfm_b32": lambda a, b: _shl((np.uint64(1) << (a & np.uint32(31)).astype(np.uint64)).astype(np.uint32) - np.uint32(1), b),
     "v_lshrrev_b32": lambda a, b: b >> (a & np.uint32(31)),
     "v_ashrrev_i32": lambda a, b: (_i32(b) >> (a & np.uint32(31)).astype(np.int32)).astype(np.uint32),
     "v_min_u32": np.minimum,
@@ -768,6 +769,17 @@ class Program:
 
             def run(w, i, f=f):
                 w.scc = 1 if f(_lit64(i.ops[0], w), _lit64(i.ops[1], w)) else 0
+            return run
+        m = re.match(r"^v_cmpx_(eq|ne|lg|gt|ge|lt|le)_(u32|i32)$", base)
+        if m:  # (gfx9: the compare's result goes to the SGPR pair / VCC AND to EXEC; inactive lanes read as 0)
+            f, signed = _CMP[m.group(1)], m.group(2) == "i32"
+
+            def run(w, i, f=f, signed=signed):
+                x, y = w.rv32(i.ops[1]), w.rv32(i.ops[2])
+                if signed:
+                    x, y = _i32(x), _i32(y)
+                w.wmask(i.ops[0], f(x, y))
+                w.exec = w.rs64(i.ops[0])
             return run
         m = re.match(r"^v_cmp_(eq|ne|lg|gt|ge|lt|le)_(u32|i32|u16|i16|u64|i64)$", base)
         if m:

@@ -188,8 +188,9 @@ def test_window_blocks_take_their_rare_paths(oracle):
     hit_s = {re.sub(r"\d*_\d+$", "", k) for k in prof_s if k.startswith(".Ls_")}
     # (.Lw_regather / .Lw_winm / .Lw_nvw / .Lw_fix / .Lw_exth = the speculation's paths; the commit's repair loop .Lw_cfix runs
     # only when a LOWER lane wins a same-address store: test_lds_race_winner_is_irrelevant shuffles the winner and requires it)
+    # (.Lw_flush = the deferred emission's flush, .Lw_flw = asked for at a window's end, .Lw_frx = at a hand-back)
     assert {".Lw_pendb", ".Lw_dispf", ".Lw_dispx", ".Lw_dup", ".Lw_extb", ".Lw_noev", ".Lw_regather", ".Lw_winm",
-            ".Lw_nvw", ".Lw_fix", ".Lw_exth"} <= hit_l, hit_l
+            ".Lw_fix", ".Lw_exth", ".Lw_flush", ".Lw_flw", ".Lw_frx"} <= hit_l, hit_l
     assert {".Ls_dispf", ".Ls_dispx", ".Ls_dup", ".Ls_ext", ".Ls_cloop", ".Ls_noev", ".Ls_pendset"} <= hit_s, hit_s
 
 
