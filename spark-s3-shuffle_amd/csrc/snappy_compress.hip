@@ -247,7 +247,9 @@ __device__ int snappy_compress_wave(const uint8_t* in, lds_u16* table, int len, 
                          : [len] "s"(len), [inp] "s"(in), [outp] "s"(out), [shift] "s"(__builtin_amdgcn_readfirstlane(shift))
                          : "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77",
                            "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91",
-                           "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "v120", "v121", "v122", "v123", "v124",
+                           "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "m0", "v97", "v98", "v99", "v100", "v101", "v102",
+                           "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115",
+                           "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124",
                            "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136",
                            "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148",
                            "v149", "v150", "v151", "v152", "v153", "vcc", "scc", "memory");

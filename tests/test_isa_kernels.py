@@ -186,12 +186,14 @@ def test_window_blocks_take_their_rare_paths(oracle):
             assert bytes(slot[32:32 + sz - 4]) == bytes(oracle.snappy_compress_block(c))
     hit_l = {re.sub(r"\d*_\d+$", "", k) for k in prof_l if k.startswith(".Lw_")}
     hit_s = {re.sub(r"\d*_\d+$", "", k) for k in prof_s if k.startswith(".Ls_")}
-    # (.Lw_regather / .Lw_winm / .Lw_nvw / .Lw_fix / .Lw_exth = the speculation's paths; the commit's repair loop .Lw_cfix runs
+    # (.Lw_regather / .Lw_winm / .Lw_fix / .Lw_exth = the speculation's paths; the commit's repair loop .Lw_cfix runs
     # only when a LOWER lane wins a same-address store: test_lds_race_winner_is_irrelevant shuffles the winner and requires it)
     # (.Lw_flush = the deferred emission's flush, .Lw_flw = asked for at a window's end, .Lw_frx = at a hand-back)
     assert {".Lw_pendb", ".Lw_dispf", ".Lw_dispx", ".Lw_dup", ".Lw_extb", ".Lw_noev", ".Lw_regather", ".Lw_winm",
             ".Lw_fix", ".Lw_exth", ".Lw_flush", ".Lw_flw", ".Lw_frx"} <= hit_l, hit_l
-    assert {".Ls_dispf", ".Ls_dispx", ".Ls_dup", ".Ls_ext", ".Ls_cloop", ".Ls_noev", ".Ls_pendset"} <= hit_s, hit_s
+    # (.Ls_flush / .Ls_flw / .Ls_frx as above; .Ls_long = a literal run above 12 bytes, .Ls_frl = emitted at once behind a flush)
+    assert {".Ls_dispf", ".Ls_dispx", ".Ls_dup", ".Ls_ext", ".Ls_cloop", ".Ls_noev", ".Ls_pendset", ".Ls_flush", ".Ls_flw",
+            ".Ls_frx", ".Ls_long", ".Ls_frl"} <= hit_s, hit_s
 
 
 def test_snappy_asm_block_keeps_its_wait_states():
