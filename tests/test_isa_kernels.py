@@ -54,6 +54,110 @@ def test_compiled_kernel_matches_oracle(oracle, windows):
 
 
 
+def _lz4_sequences(block):
+    """(literal length, match length) of every sequence of a raw LZ4 block (the last one has match length 0)"""
+    b, i, out = bytes(block), 0, []
+    while i < len(b):
+        t = b[i]
+        i += 1
+        lit = t >> 4
+        if lit == 15:
+            while True:
+                x = b[i]
+                i += 1
+                lit += x
+                if x != 255:
+                    break
+        i += lit
+        if i >= len(b):
+            out.append((lit, 0))
+            break
+        i += 2
+        ml = t & 15
+        if ml == 15:
+            while True:
+                x = b[i]
+                i += 1
+                ml += x
+                if x != 255:
+                    break
+        out.append((lit, ml + 4))
+    return out
+
+
+def _snappy_elements(block):
+    """(literal length in front, copy length, copy tag bytes) of every copy element of a raw Snappy block"""
+    b, i = bytes(block), 0
+    while b[i] & 0x80:
+        i += 1
+    i += 1
+    out, lit = [], 0
+    while i < len(b):
+        t = b[i]
+        k = t & 3
+        if k == 0:
+            n = (t >> 2) + 1
+            i += 1
+            if n > 60:
+                nb = n - 60
+                n = int.from_bytes(b[i:i + nb], "little") + 1
+                i += nb
+            i += n
+            lit = n
+        else:
+            ln, sz = (((t >> 2) & 7) + 4, 2) if k == 1 else ((t >> 2) + 1, 3 if k == 2 else 5)
+            i += sz
+            out.append((lit, ln, sz))
+            lit = 0
+    return out
+
+
+def _planted(rng, n, lits, mlens):
+    """a dictionary of random bytes, then units of `lit` fresh bytes + a copy of `m` dictionary bytes, every (lit, m) pair in turn"""
+    dic = rng.integers(0, 256, 1536, dtype=np.uint8)
+    parts, have = [dic], len(dic)
+    pairs = [(a, m) for a in lits for m in mlens]
+    k = 0
+    while have < n:
+        a, m = pairs[k % len(pairs)]
+        k += 1
+        o = int(rng.integers(0, len(dic) - m))
+        parts += [rng.integers(0, 256, a, dtype=np.uint8), dic[o:o + m]]
+        have += a + m
+    return np.concatenate(parts)[:n].copy()
+
+
+def test_deferred_emission_covers_every_sequence_shape(oracle):
+    """The flush of the window blocks (lz4_window_engine.inc S3S_ENGINE_FLUSH, .Ls_flush): every literal length it takes, with and
+    without the extra length byte / with the two- and the three-byte copy, i.e. every byte count and every tail position of a lane"""
+    import lz4_kernel as lk
+    import snappy_kernel as sk
+
+    rng = np.random.default_rng(31)
+    # LZ4: literal runs 0 .. 14 (15 leaves the block: long form), match lengths around the one-byte boundary (18 / 19) and up to 273
+    chunks = [_planted(rng, 32768, range(0, 16), (4, 5, 7, 12, 17, 18, 19, 20, 33, 70, 150, 272, 273, 280)) for _ in range(2)]
+    prof = {}
+    _check(chunks, oracle, profile=prof)
+    shapes = set()
+    for c in chunks:
+        shapes |= {(a, m >= 19) for a, m in _lz4_sequences(oracle.lz4_compress_block(c)) if m}
+    assert {(a, e) for a in range(15) for e in (False, True)} <= shapes, sorted(shapes)
+    # (most of these sequences must have gone through the block's record path, and the flush must have run)
+    n_rec = sum(v[1] for k, v in prof.items() if k.startswith(".Lw_len"))  # .Lw_len's taken branch = one recorded sequence
+    n_seq = sum(len(_lz4_sequences(oracle.lz4_compress_block(c))) for c in chunks)
+    assert any(k.startswith(".Lw_flush") for k in prof) and n_rec > 0.5 * n_seq, (n_rec, n_seq)
+    # Snappy: literal runs 0 .. 12 wait as records, 13 .. 20 go out at once behind a flush; two-byte copies (length < 12, offset
+    # < 2048) and three-byte ones
+    chunks = [_planted(rng, 32768, range(0, 21), (4, 6, 11, 12, 13, 30, 64, 65, 90)) for _ in range(2)]
+    prof = {}
+    for c, (slot, sz, w) in zip(chunks, sk.compress_chunks(chunks, profile=prof)):
+        ref = oracle.snappy_compress_block(c)
+        assert bytes(slot[32:32 + sz - 4]) == bytes(ref)
+        shapes |= {("s", min(a, 13), z) for a, ln, z in _snappy_elements(ref)}
+    assert {("s", a, z) for a in range(14) for z in (2, 3)} <= shapes, sorted(x for x in shapes if x[0] == "s")
+    assert any(k.startswith(".Ls_flush") for k in prof) and any(k.startswith(".Ls_frl") for k in prof)
+
+
 def test_lds_race_winner_is_irrelevant(oracle):
     """same-address LDS stores of one instruction: any lane may win (tests/model proves it; here on the real code)"""
     rng = np.random.default_rng(22)
