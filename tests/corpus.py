@@ -76,3 +76,18 @@ def ragged_map_output(rng: np.random.Generator, n_parts: int, max_len: int, kind
     np.cumsum([p.size for p in parts], out=offsets[1:])
     data = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
     return data.astype(np.uint8), offsets
+
+
+def planted_sequence_shapes(rng, n, lits, mlens):
+    """a dictionary of random bytes, then units of `lit` fresh bytes + a copy of `m` dictionary bytes, every (lit, m) pair in turn"""
+    dic = rng.integers(0, 256, 1536, dtype=np.uint8)
+    parts, have = [dic], len(dic)
+    pairs = [(a, m) for a in lits for m in mlens]
+    k = 0
+    while have < n:
+        a, m = pairs[k % len(pairs)]
+        k += 1
+        o = int(rng.integers(0, len(dic) - m))
+        parts += [rng.integers(0, 256, a, dtype=np.uint8), dic[o:o + m]]
+        have += a + m
+    return np.concatenate(parts)[:n].copy()

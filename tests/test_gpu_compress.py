@@ -280,3 +280,12 @@ def test_multi_spill_segments_are_one_stream_per_piece(gpu_codec, oracle, codec,
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
     with pytest.raises(Exception):
         gpu_codec.compress_map_output_segments(codec, ADLER, data, seg_offsets, [0, 2, 1, len(pieces)])
+
+
+def test_lz4_every_sequence_shape_of_the_deferred_flush(gpu_codec, oracle):
+    """literal runs 0 .. 15 x match lengths around the length-byte boundary: every byte count / tail position a lane of the window
+    block's flush writes (lz4_window_engine.inc S3S_ENGINE_FLUSH); several partitions so that blocks start at every phase"""
+    rng = np.random.default_rng(53)
+    n = 3 * 32768 + 1234
+    data = corpus.planted_sequence_shapes(rng, n, range(0, 16), (4, 5, 7, 12, 17, 18, 19, 20, 33, 70, 150, 272, 273, 280))
+    _check(gpu_codec, oracle, LZ4, ADLER, data, [0, 40000, 40000, n])

@@ -127,3 +127,12 @@ def test_snappy_block_size_option(gpu_codec, oracle):
             _check(gpu_codec, oracle, ADLER, data, offsets, block_size=eff)
         finally:
             gpu_codec.set_option(2, 32768)
+
+
+def test_snappy_every_element_shape_of_the_deferred_flush(gpu_codec, oracle):
+    """literal runs 0 .. 20 (up to 12 wait as records, longer ones go out at once behind a flush) x two- and three-byte copies:
+    every byte count / tail position a lane of the Snappy window block's flush writes (snappy_window_engine.inc .Ls_flush)"""
+    rng = np.random.default_rng(54)
+    n = 3 * 32768 + 777
+    data = corpus.planted_sequence_shapes(rng, n, range(0, 21), (4, 6, 11, 12, 13, 30, 64, 65, 90))
+    _check(gpu_codec, oracle, 1, data, [0, 33333, 33333, n])

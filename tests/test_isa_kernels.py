@@ -112,21 +112,6 @@ def _snappy_elements(block):
     return out
 
 
-def _planted(rng, n, lits, mlens):
-    """a dictionary of random bytes, then units of `lit` fresh bytes + a copy of `m` dictionary bytes, every (lit, m) pair in turn"""
-    dic = rng.integers(0, 256, 1536, dtype=np.uint8)
-    parts, have = [dic], len(dic)
-    pairs = [(a, m) for a in lits for m in mlens]
-    k = 0
-    while have < n:
-        a, m = pairs[k % len(pairs)]
-        k += 1
-        o = int(rng.integers(0, len(dic) - m))
-        parts += [rng.integers(0, 256, a, dtype=np.uint8), dic[o:o + m]]
-        have += a + m
-    return np.concatenate(parts)[:n].copy()
-
-
 def test_deferred_emission_covers_every_sequence_shape(oracle):
     """The flush of the window blocks (lz4_window_engine.inc S3S_ENGINE_FLUSH, .Ls_flush): every literal length it takes, with and
     without the extra length byte / with the two- and the three-byte copy, i.e. every byte count and every tail position of a lane"""
@@ -135,7 +120,7 @@ def test_deferred_emission_covers_every_sequence_shape(oracle):
 
     rng = np.random.default_rng(31)
     # LZ4: literal runs 0 .. 14 (15 leaves the block: long form), match lengths around the one-byte boundary (18 / 19) and up to 273
-    chunks = [_planted(rng, 32768, range(0, 16), (4, 5, 7, 12, 17, 18, 19, 20, 33, 70, 150, 272, 273, 280)) for _ in range(2)]
+    chunks = [corpus.planted_sequence_shapes(rng, 32768, range(0, 16), (4, 5, 7, 12, 17, 18, 19, 20, 33, 70, 150, 272, 273, 280)) for _ in range(2)]
     prof = {}
     _check(chunks, oracle, profile=prof)
     shapes = set()
@@ -148,7 +133,7 @@ def test_deferred_emission_covers_every_sequence_shape(oracle):
     assert any(k.startswith(".Lw_flush") for k in prof) and n_rec > 0.5 * n_seq, (n_rec, n_seq)
     # Snappy: literal runs 0 .. 12 wait as records, 13 .. 20 go out at once behind a flush; two-byte copies (length < 12, offset
     # < 2048) and three-byte ones
-    chunks = [_planted(rng, 32768, range(0, 21), (4, 6, 11, 12, 13, 30, 64, 65, 90)) for _ in range(2)]
+    chunks = [corpus.planted_sequence_shapes(rng, 32768, range(0, 21), (4, 6, 11, 12, 13, 30, 64, 65, 90)) for _ in range(2)]
     prof = {}
     for c, (slot, sz, w) in zip(chunks, sk.compress_chunks(chunks, profile=prof)):
         ref = oracle.snappy_compress_block(c)
