@@ -1,6 +1,6 @@
 """A/B of two versions of the window blocks in the interpreter's cycle model (TEST INFRASTRUCTURE, no GPU).
 
-    python tests/tools/engine_ab_model.py [<base commit, default a16bbe8 = last GPU measurement of round 2>]
+    python tests/tools/engine_ab_model.py [<base commit, default b044428 = the window blocks before the deferred emission of round 5>]
 
 Builds hipcc's assembly of lz4_compress.hip / snappy_compress.hip once with the working tree's *_window_engine.inc and
 once with the base commit's, runs three 32 KiB blocks of each bench.py generator through both in tests/isa/gfx950_emu.py
@@ -48,7 +48,7 @@ def base_asm(commit):
 
 
 def main():
-    commit = sys.argv[1] if len(sys.argv) > 1 else "a16bbe8"
+    commit = sys.argv[1] if len(sys.argv) > 1 else "b044428"
     old = base_asm(commit)
     t = old["lz4_compress.hip"]
     e = lk.find_kernel(t, "lz4_compress_l2_kernelILb1E")
