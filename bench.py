@@ -13,10 +13,13 @@ has no exchange step, so there is no data-path collective (only the timing barri
 Launch:  python bench.py --gpus 1 --steps K --warmup W
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
                 --master-port P bench.py --gpus N --steps K --warmup W
-Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant kernel:
-the LZ4 block-compress kernel, HIP-event timed on the library's own stream) and `cpu_baseline`
-(the CPU oracle driving liblz4 1.9.3 on the host cores; checker code, timed here only as the
-baseline).
+         python bench.py --gpus N ...   (no launcher: re-executes itself under torch.distributed.run)
+Rank 0's LAST stdout line is the ONE compact JSON line of the contract (< 4 KB) with `roofline`
+(dominant kernel: the LZ4 block-compress kernel, HIP-event timed on the library's own stream) and
+`cpu_baseline` (the CPU oracle driving liblz4 1.9.3 on the host cores; checker code, timed here only
+as the baseline).  The plain N=1 command also runs the other BASELINE configurations: their full
+records go to bench_secondary.json and to an EARLIER stdout line, a short summary to the line
+before the headline.
 """
 from __future__ import annotations
 
@@ -267,12 +270,15 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU leg")
     ap.add_argument("--verify", action="store_true", help="check one map task against the oracle first")
+    ap.add_argument("--no-image-check", action="store_true",
+                    help="skip the untimed image_verified check after a compress leg (profiling runs: it adds checksum launches)")
     ap.add_argument("--secondary", dest="secondary", action="store_true", default=None,
                     help="after the headline, run short (3-step) passes of the other BASELINE.json configurations and attach "
                          "them as `secondary` to the JSON line (default: on for the plain N=1 headline command)")
     ap.add_argument("--no-secondary", dest="secondary", action="store_false")
     ap.add_argument("--host-path-only", action="store_true", help="run only the host-buffer leg (run_host_path) and print it")
     ap.add_argument("--hbm-stages-only", action="store_true", help="run only the HBM-bound stage lines (run_hbm_stages) and print them")
+    ap.add_argument("--full-line", action="store_true", help="also print the full (long) record of the run as an earlier stdout line")
     ap.add_argument("--dry-run", action="store_true",
                     help="no timing: every rank reports (rank, local rank, device, its map ids); rank 0 checks that "
                          "mapId %% nGPU covers every map task exactly once and prints the table as one JSON line "
@@ -378,6 +384,8 @@ def cpu_baseline(workload: str, target_s: float, map_mib: int = 128):
                   f"framing / index by oracle/s3s_oracle_mt.c; "
                   f"JVM/JNI overheads not included (upper bound on the reference path); "
                   f"os.cpu_count()={os.cpu_count()}, cgroup/affinity limit={cores}",
+        "sample_short": f"{cores} thr x {reps} reps x one {sample_mib} MiB map task ({parts} parts), {codec}+{algo}; "
+                        f"{'lib' + codec if have_lib else 'oracle port'} + SIMD checksums; no JVM/JNI overhead",
         "single_thread_GBps": round(one, 3), "wall_s": round(s, 2),
     }
 
@@ -414,8 +422,41 @@ def cpu_baseline_decompress(workload: str, target_s: float, map_mib: int = 128, 
                   f"{codec}+{algo}, reduce-side verify+decompress; block decoder = "
                   f"{_LIB_NAMES[codec][1] if have_lib else 'oracle restatement'}; checksums = {_simd_names(simd)}; "
                   f"JVM/JNI overheads not included; os.cpu_count()={os.cpu_count()}, cgroup/affinity limit={cores}",
+        "sample_short": f"{cores} thr x {reps} reps x one {sample_mib} MiB map task ({parts} parts), {codec}+{algo} verify+decode; "
+                        f"{'lib' + codec if have_lib else 'oracle port'} + SIMD checksums; no JVM/JNI overhead",
         "single_thread_GBps": round(data.size * 4 / t1 / 1e9, 3), "wall_s": round(s, 2),
     }
+
+
+def verify_images(workload, codec_id, algo_id, codec, tasks, map_ids, n_bytes, last_result) -> bool:
+    """Untimed self-check of a compress leg (rank 0): for every map task, CRC32 of dst[:total] computed ON THE DEVICE by the
+    library (s3s_checksum_ranges_device) == zlib.crc32 of the oracle's .data image of the same map output, and the index and
+    per-partition checksums the last timed call returned == the oracle's.  The oracle is the checker here, never timed."""
+    import zlib
+
+    import s3shuffle
+    from oracle import binding as oracle
+
+    ok = [None] * len(tasks)
+
+    def one(i):
+        data, offs = make_map_output(workload, map_ids[i], n_bytes)
+        r_img, r_index, r_sums = oracle.compress_map_output(codec_id, algo_id, data, offs)
+        total, index, sums = last_result[i]
+        if total != r_img.size or not np.array_equal(index, r_index) or not np.array_equal(sums, r_sums):
+            return
+        ok[i] = zlib.crc32(r_img) & 0xFFFFFFFF
+
+    th = [threading.Thread(target=one, args=(i,)) for i in range(len(tasks))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for i, t in enumerate(tasks):
+        if ok[i] is None:
+            return False
+        got = codec.checksum_ranges_device(s3shuffle.CHECKSUM_CRC32, t["dst"].data_ptr(), np.array([0, last_result[i][0]], np.int64))
+        if int(got[0]) != ok[i]:
+            return False
+    return True
 
 
 def dry_run(args, rank: int, local_rank: int, world: int, launched: bool):
@@ -538,6 +579,7 @@ def run_workload(args, rank: int, local_rank: int, world: int, dist):
 
     stage = {"codec": 0.0, "hash": 0.0, "assemble": 0.0, "checksum": 0.0, "total": 0.0, "launches": 0}
     comp_bytes = [0] * len(tasks)
+    last_result = [None] * len(tasks)  # (total, index, checksums) of each map task's most recent compress call
     lock = threading.Lock()
 
     decompress = args.direction == "decompress"
@@ -581,6 +623,7 @@ def run_workload(args, rank: int, local_rank: int, world: int, dist):
                                              tasks[i]["cap"]) for i in grp])
                     for i, r in zip(grp, res):
                         comp_bytes[i] = r[0]
+                        last_result[i] = r
                     if record:
                         acc[0] += c.stage_ms(s3shuffle.codec.STAGE_CODEC)
                         acc[1] += c.stage_ms(s3shuffle.codec.STAGE_HASH)
@@ -611,9 +654,9 @@ def run_workload(args, rank: int, local_rank: int, world: int, dist):
                                                     t["sums"], t["out"].data_ptr(), t["u"])
                     assert got == t["u"]
                 else:
-                    total, _, _ = c.compress_map_output_device(codec_id, algo_id, t["src"].data_ptr(), t["offs"],
-                                                               t["dst"].data_ptr(), t["cap"])
-                    comp_bytes[i] = total
+                    last_result[i] = c.compress_map_output_device(codec_id, algo_id, t["src"].data_ptr(), t["offs"],
+                                                                  t["dst"].data_ptr(), t["cap"])
+                    comp_bytes[i] = last_result[i][0]
                 if record:
                     acc[0] += c.stage_ms(s3shuffle.codec.STAGE_CODEC)
                     acc[1] += c.stage_ms(s3shuffle.codec.STAGE_HASH)
@@ -664,6 +707,19 @@ def run_workload(args, rank: int, local_rank: int, world: int, dist):
         bytes_verified = all(bool(torch.equal(t["out"], t["src"])) for t in tasks)
         if not bytes_verified:
             raise SystemExit(f"{args.workload}: decoded bytes differ from the source")
+
+    # map side: the timed calls return sizes only — so, once, after the timed region (untimed), the .data image every task's LAST
+    # timed call left in HBM is hashed on the device (the library's own CRC32 over dst[:total]) and compared, together with the
+    # index and the checksums, with the oracle's image of the same map output computed on the host
+    image_verified = None
+    if not decompress and not args.no_image_check:
+        image_verified = verify_images(args.workload, codec_id, algo_id, codecs[0], tasks, map_ids, n_bytes, last_result)
+        if dist:  # every rank checks its own map outputs; the line reports the AND over ranks
+            iv = torch.tensor([int(image_verified)], dtype=torch.int32, device=dev)
+            dist.all_reduce(iv, op=dist.ReduceOp.MIN)
+            image_verified = bool(iv.item())
+        if not image_verified:
+            raise SystemExit(f"{args.workload}: the .data image / index / checksums of the timed calls differ from the oracle's")
 
     u_rank = sum(t["u"] for t in tasks)
     c_rank = sum(comp_bytes)
@@ -770,6 +826,8 @@ def run_workload(args, rank: int, local_rank: int, world: int, dist):
             },
             "stages_ms_per_library_call": {k: round(stage[k] / launches, 4) for k in ("hash", "codec", "assemble", "checksum", "total")},
         }
+        if image_verified is not None:
+            out["image_verified"] = bool(image_verified)  # CRC32 of every task's .data image in HBM + index + checksums == the oracle's, after the timed region
         if decompress:
             out["bytes_verified"] = bool(bytes_verified)  # torch.equal(decoded, source) for every map task of the step, after the timed region
         if world == 1 and not args.no_cpu_baseline:
@@ -968,7 +1026,7 @@ def run_hbm_stages(args, local_rank: int):
         for key, e in res.items():
             if not isinstance(e, dict) or "roofline" not in e:
                 continue
-            t = ref.get("hbm-stages:adler32" if ":adler32:" in key else "hbm-stages:crc32" if ":crc32" in key else "hbm-stages:xxh32" if key.startswith("xxh32") else "")
+            t = ref.get("hbm-stages:adler32" if ":adler32:" in key else "hbm-stages:crc32" if ":crc32:" in key else "hbm-stages:xxh32" if key.startswith("xxh32") else "")
             if t and stamp and t.get("kernel_sources_sha256") == stamp:
                 e["roofline"]["traffic"] = int(t["hbm_bytes_per_launch"])
                 e["roofline"]["traffic_over_algorithmic"] = round(t["hbm_bytes_per_launch"] / n_bytes, 3)
@@ -1114,6 +1172,121 @@ def run_host_path(args, local_rank: int):
     }
 
 
+SECONDARY_FILE = "bench_secondary.json"  # written next to bench.py (and under gpurun_out/ when that directory exists)
+HEADLINE_MAX_BYTES = 4096                 # the LAST stdout line; tests/test_bench_line.py holds it under 8 192
+
+
+def _short(s, n: int):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 1] + "~"
+
+
+def compact_headline(out: dict, secondary_file=None) -> dict:
+    """The one line the driver parses (the round-5 line had grown to 22 KB and was not parsed): every
+    contract key, `roofline` incl. `traffic`, `cpu_baseline`, short strings only.  Everything else — per-stage times, the long
+    `sample` / `what` descriptions, the secondary workloads, the sweep, HBM-bound stages, host path — goes to SECONDARY_FILE
+    and to EARLIER stdout lines."""
+    cfg, rf, cb = out["config"], out["roofline"], out.get("cpu_baseline")
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step",
+                                "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {
+        "workload": cfg["workload"], "direction": cfg["direction"], "codec": _short(cfg["codec"], 48).split(" (")[0],
+        "checksum": cfg["checksum"], "partitions_per_map_task": cfg["partitions_per_map_task"],
+        "map_task_bytes": cfg["map_task_bytes"], "map_tasks_per_gpu": cfg["map_tasks_per_gpu"],
+        "uncompressed_bytes_per_step": cfg["uncompressed_bytes_per_step"],
+        "compressed_bytes_per_step": cfg["compressed_bytes_per_step"], "compression_ratio": cfg["compression_ratio"],
+        "sharding": "mapId % nGPU", "task_threads_per_gpu": cfg["task_threads_per_gpu"],
+        "map_tasks_per_library_call": cfg["map_tasks_per_library_call"], "inputs": "resident in HBM",
+    }
+    line["roofline"] = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic",
+                                               "avg_launch_ms", "concurrent_launches", "algorithmic_bytes_per_launch",
+                                               "achieved_all_streams", "frac_of_copy_ceiling", "whole_path_read_frac")}
+    line["roofline"]["kernel"] = _short(rf["kernel"], 60)
+    if rf.get("traffic_source"):
+        line["roofline"]["traffic_source"] = _short(rf["traffic_source"], 64)
+    if cb:
+        line["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                "sample": _short(cb.get("sample_short") or cb.get("sample", ""), 120),
+                                "single_thread_GBps": cb.get("single_thread_GBps"), "wall_s": cb.get("wall_s")}
+    else:
+        line["cpu_baseline"] = None
+    for k in ("speedup_vs_cpu_all_cores", "speedup_vs_cpu_1_core", "image_verified", "bytes_verified", "kernel_sources_sha256"):
+        if k in out:
+            line[k] = out[k]
+    line["stages_ms_per_library_call"] = out.get("stages_ms_per_library_call")
+    line["per_rank"] = [{"rank": r["rank"], "GBps": r["GBps"], "elapsed_s": r["elapsed_s"]} for r in out.get("per_rank", [])][:16]
+    if secondary_file:
+        line["secondary_file"] = secondary_file
+    return line
+
+
+def secondary_summary(sec: dict) -> dict:
+    """One short stdout line (the one before the headline) with the driver-visible figure of every secondary leg: value in
+    GB/s of uncompressed bytes, the dominant kernel's roofline fraction, the speed-up over the host cores and the
+    post-run byte checks.  Full records: SECONDARY_FILE."""
+    legs = {}
+    for label, e in sec.items():
+        if not isinstance(e, dict):
+            continue
+        if "error" in e:
+            legs[label] = {"error": _short(e["error"], 80)}
+        elif "value" in e and "roofline" in e:
+            legs[label] = {"GBps": e["value"], "ms_per_step": e["ms_per_step"], "frac": e["roofline"]["frac"],
+                           "kernel_GBps": e["roofline"]["achieved"],
+                           "cpu_GBps": (e.get("cpu_baseline") or {}).get("value"), "x_cpu": e.get("speedup_vs_cpu_all_cores")}
+            for k in ("image_verified", "bytes_verified"):
+                if k in e:
+                    legs[label][k] = e[k]
+    res = {"secondary_summary": legs}
+    sw = sec.get("block_size_sweep") or {}
+    if "points" in sw:
+        res["sweep_MiB_blocks_compress_decompress_GBps"] = [
+            [pt["block_MiB"], pt["blocks_per_step"], pt.get("compress"), pt.get("decompress")]
+            for pt in sw["points"] + sw.get("points_more_blocks_in_flight", [])]
+    hb = sec.get("hbm_bound_stages") or {}
+    res["hbm_stage_kernel_GBps_frac"] = {k: [e["roofline"]["achieved"], e["roofline"]["frac"]] + ([e["matches_zlib"]] if "matches_zlib" in e else [])
+                                         for k, e in hb.items() if isinstance(e, dict) and "roofline" in e}
+    hp = sec.get("host_path") or {}
+    if "compress_by_task_threads" in hp:
+        res["host_path_GBps"] = {"compress": hp["compress_by_task_threads"], "decompress": hp["verify_decompress_by_task_threads"],
+                                 "bit_exact": hp.get("round_trip_bit_exact")}
+    return res
+
+
+def write_secondary_file(full: dict):
+    """The full record (headline with its long descriptions + every secondary leg) as a file; returns the path reported in the
+    headline."""
+    blob = json.dumps(full, indent=1)
+    paths = [os.path.join(ROOT, SECONDARY_FILE)]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        paths.append(os.path.join(ROOT, "gpurun_out", SECONDARY_FILE))
+    for p in paths:
+        try:
+            with open(p, "w") as f:
+                f.write(blob)
+        except OSError:
+            pass
+    return SECONDARY_FILE
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: re-exec this command under torch.distributed.run, one
+    rank per GPU on 127.0.0.1 (S3ShuffleDispatcher.scala:142-143: map task m -> GPU m % N); the ranks print, this process only
+    relays their exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
     if args.secondary is None:  # plain headline command only (the driver's); profiling / A-B commands stay short
@@ -1121,10 +1294,10 @@ def main():
                           and not args.no_cpu_baseline and not args.dry_run and args.map_mib == 128)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run --nproc-per-node N (one rank per GPU)")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
 
     import torch
@@ -1155,10 +1328,20 @@ def main():
         print(json.dumps({"hbm_bound_stages": run_hbm_stages(args, local_rank)}), flush=True)
         return
     out = run_workload(args, rank, local_rank, world, dist)
-    if rank == 0 and world == 1 and args.secondary and not args.dry_run:
-        out["secondary"] = run_secondaries(args, rank, local_rank)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        # stdout: [full record incl. secondaries, one long line] [secondary summary, short] [THE headline, short, LAST]
+        sec_file = None
+        if world == 1 and args.secondary and not args.dry_run:
+            sec = run_secondaries(args, rank, local_rank)
+            full = dict(out, secondary=sec)
+            sec_file = write_secondary_file(full)
+            print(json.dumps({"full_record": full}), flush=True)
+            print(json.dumps(secondary_summary(sec)), flush=True)
+        elif args.full_line:
+            print(json.dumps({"full_record": out}), flush=True)
+        line = json.dumps(compact_headline(out, sec_file))
+        assert len(line) < HEADLINE_MAX_BYTES, len(line)
+        print(line, flush=True)
     if dist:
         dist.destroy_process_group()
 
