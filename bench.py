@@ -929,8 +929,9 @@ def run_secondaries(args, rank: int, local_rank: int):
             "speedup_vs_cpu_all_cores": o.get("speedup_vs_cpu_all_cores"),
             "wall_s": round(time.perf_counter() - t0, 2),
         }
-        if "bytes_verified" in o:
-            res[label]["bytes_verified"] = o["bytes_verified"]
+        for k in ("bytes_verified", "image_verified"):
+            if k in o:
+                res[label][k] = o[k]
     t0 = time.perf_counter()
     try:
         res["block_size_sweep"] = run_block_size_sweep(args, rank, local_rank, res)

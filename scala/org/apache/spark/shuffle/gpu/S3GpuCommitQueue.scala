@@ -119,6 +119,11 @@ object S3GpuCommitQueue {
         finished = r.done.await(1, java.util.concurrent.TimeUnit.SECONDS)
         if (!finished && !w.isAlive && r.done.getCount > 0) {
           r.rc = S3SCodec.E_HIP; r.error = "GPU commit worker thread is gone"; finished = true
+          // drop the dead worker so that the NEXT commit on this device starts a fresh one (instead of every later commit
+          // waiting a second and failing for the rest of the executor's life), and take the request out of the dead queue:
+          // it references src / dst buffers the caller releases now (advisor r5)
+          workers.remove(device, w)
+          w.queue.remove(r)
         }
       } catch { case _: InterruptedException => interrupted = true }
     }

@@ -93,6 +93,8 @@ void s3s_destroy(s3s_ctx* ctx) {
     if (ctx->hb_in) hipStreamSynchronize(ctx->hb_in);
     if (ctx->hb_out) hipStreamSynchronize(ctx->hb_out);
   }
+  // (hipFree itself still synchronises the device — the buffers are hipMalloc'd, not pool allocations, so there is no
+  // stream-ordered free for them; the per-event waits above only keep this thread from blocking on the shared lanes BEFORE it)
   for (auto& b : ctx->buf)
     if (b.p) hipFree(b.p);
   if (ctx->h_stage) hipHostFree(ctx->h_stage);

@@ -702,6 +702,10 @@ ZS_HD int literals_header(const uint8_t* b, int64_t bsize, LitHdr* h) {
     h->streams = 4;
   }
   if (h->regen > kMaxBlock || h->lh + h->lcomp > bsize) return ZS_FAIL();
+  // a Huffman code spends at least one bit per symbol: a section that claims more than 8 literals per compressed byte is
+  // corrupt.  The single-pass literal scratch (zstd_decompress.hip: min(8 * partition bytes + 256, kMaxBlock) + 64 per
+  // buffer) relies on this bound, so it is enforced here, where every caller passes.
+  if (h->regen > 8 * h->lcomp) return ZS_FAIL();
   return ZS_OK;
 }
 
@@ -1401,7 +1405,9 @@ ZS_HD void literal_side(LitPipe* lps, LitWalker* ks, int n_parts, Lanes L) {
       any = true;
       if (pipe_get(&lp.quit)) { k.done = 1; continue; }            // its sequence side has left
       if (pipe_get(&lp.consumed) < k.hblock - 1) continue;         // buffer hblock & 1 still holds block hblock - 2
-      const int rc = block_literals(lp.h, k.lh, k.hp, k.lh.lcomp, k.lit_buf + (k.hblock & 1) * k.lit_stride, L);
+      // (second line of defence: the section must fit the buffer this partition was given, whatever sized it)
+      const int rc = k.lh.regen > k.lit_stride - 64 ? (int)ZS_BAD
+                                                    : block_literals(lp.h, k.lh, k.hp, k.lh.lcomp, k.lit_buf + (k.hblock & 1) * k.lit_stride, L);
       if (rc != ZS_OK) {
         pipe_set(&lp.err, rc, L);
         k.done = 1;

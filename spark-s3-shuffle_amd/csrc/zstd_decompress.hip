@@ -248,10 +248,24 @@ int zstd_decompress_ranges(s3s_ctx* ctx, int checksum_algo, s3s_fetch_range* R, 
         }
     }
     if (scr_total + lit_total1 > kScratchBudget) single = false;
-    else if (ensure(ctx, B_ZSCRATCH, (size_t)scr_total + 256) != S3S_OK || ensure(ctx, B_SLOTS, (size_t)lit_total1 + 64) != S3S_OK) {
-      (void)hipGetLastError();  // an allocation that did not fit: not this call's verdict
-      ctx->err[0] = 0;
-      single = false;
+    else {
+      int e = ensure(ctx, B_ZSCRATCH, (size_t)scr_total + 256);
+      if (e == S3S_OK) e = ensure(ctx, B_SLOTS, (size_t)lit_total1 + 64);
+      if (e == S3S_E_NOMEM) {
+        // an allocation that did not fit is not this call's verdict: the two-pass form needs less.  Give the (multi-GiB) scratch
+        // back first, so that its allocations find room.  Any OTHER failure (a stream error inside ensure) is the call's verdict.
+        (void)hipGetLastError();
+        ctx->err[0] = 0;
+        DevBuf& zb = ctx->buf[B_ZSCRATCH];
+        if (zb.p) {
+          (void)hipFree(zb.p);
+          zb.p = nullptr;
+          zb.cap = 0;
+        }
+        single = false;
+      } else if (e != S3S_OK) {
+        return e;
+      }
     }
   }
   if (single) {

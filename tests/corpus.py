@@ -91,3 +91,25 @@ def planted_sequence_shapes(rng, n, lits, mlens):
         parts += [rng.integers(0, 256, a, dtype=np.uint8), dic[o:o + m]]
         have += a + m
     return np.concatenate(parts)[:n].copy()
+
+
+def zstd_frame_with_oversized_huffman_literals(regen: int = 131072, stream_bytes: int = 40) -> "np.ndarray":
+    """A hand-built Zstandard frame (RFC 8878) of a few hundred bytes whose only block declares a 4-stream Huffman literals
+    section regenerating `regen` bytes out of 4 x `stream_bytes` compressed ones — more than 8 symbols per compressed byte,
+    which no Huffman code can do.  A decoder that sizes its literal scratch by the partition's compressed size (the product's
+    single pass: min(8 * size + 256, 128 KiB) + 64) must refuse it BEFORE writing stream k at k * regen / 4 (advisor r5)."""
+    import numpy as np
+
+    table = bytes([0x80, 0x10])                      # direct weights: one explicit 4-bit weight (1), the second implied: 2 symbols of 1 bit
+    stream = bytes([0x55] * (stream_bytes - 1) + [0x01])  # 1-bit symbols, last byte = the end marker alone
+    jump = (stream_bytes.to_bytes(2, "little")) * 3
+    huf = table + jump + stream * 4
+    lcomp = len(huf)
+    v = 2 | (3 << 2) | (regen << 4) | (lcomp << 22)  # ltype 2 (Huffman with a table), size format 3: 18 + 18 bits, 4 streams
+    lit_hdr = v.to_bytes(5, "little")
+    seq = bytes([0])                                  # no sequences: the block is its literals
+    block = lit_hdr + huf + seq
+    bh = (1 | (2 << 1) | (len(block) << 3)).to_bytes(3, "little")  # last block, compressed
+    # frame header: single segment, 4-byte frame content size
+    fhd = bytes([0x20 | (2 << 6)]) + regen.to_bytes(4, "little")
+    return np.frombuffer(bytes([0x28, 0xB5, 0x2F, 0xFD]) + fhd + bh + block, dtype=np.uint8).copy()

@@ -255,3 +255,38 @@ def test_damaged_multi_block_partitions_end_on_both_sides(gpu_codec):
     assert refused >= 5 and same >= 10, (refused, same)  # (a flipped bit in a Huffman stream is just other literals: no frame checksum)
     # and the call after all that is a clean one
     assert np.array_equal(gpu_codec.decompress_range(ZSTD, 0, img, index, None, dst_capacity=data.size), data)
+
+
+def test_small_partition_declaring_128k_of_huffman_literals_is_refused_and_harmless(gpu_codec):
+    """advisor r5 (high): the single pass sizes a partition's literal scratch from its COMPRESSED size.  A crafted partition
+    of a few hundred bytes whose 4-stream Huffman section claims regen = 131 072 (tests/corpus.py) must come back as a bad
+    frame — and the valid partitions decoded by the SAME call (its neighbours in the literal scratch) must be intact."""
+    from hipdev import Dev
+    from s3shuffle import datagen
+
+    data, offs = datagen.terasort_map_output(3 << 20, 24, seed=17)  # ~128 KiB partitions: Huffman-coded literals in every block
+    img, index, sums = _image(0, data, offs)
+    for regen, sb in ((131072, 40), (131072, 300), (30000, 64)):
+        crafted = corpus.zstd_frame_with_oversized_huffman_literals(regen, sb)
+        dev = Dev()
+        try:
+            d_good_out = dev.upload(np.full(data.size + 16, 0xA5, np.uint8))
+            d_bad_out = dev.upload(np.full(regen + 8192, 0xA5, np.uint8))
+            # the crafted frame sits BETWEEN valid partitions of one range as well: [first 12 partitions | crafted | the rest]
+            cut = int(index[12])
+            mixed = np.concatenate([img[:cut], crafted, img[cut:]])
+            m_index = np.concatenate([index[:13], index[12:] + crafted.size])
+            d_mixed_out = dev.upload(np.full(data.size + regen + 8192, 0xA5, np.uint8))
+            args = [(dev.upload(img), img.size, index, None, d_good_out, data.size),
+                    (dev.upload(crafted), crafted.size, np.array([0, crafted.size], np.int64), None, d_bad_out, regen + 4096),
+                    (dev.upload(mixed), mixed.size, m_index, None, d_mixed_out, data.size + regen + 4096)]
+            res = gpu_codec.decompress_ranges_batch_device(ZSTD, 0, args, raise_on_error=False)
+            assert res[0][0] == 0 and res[0][1] == data.size
+            back = dev.download(d_good_out, data.size + 16)
+            assert np.array_equal(back[:data.size], data) and np.all(back[data.size:] == 0xA5)
+            assert res[1][0] == -3 and res[2][0] == -3
+            assert np.all(dev.download(d_bad_out, regen + 8192)[regen + 4096:] == 0xA5)
+        finally:
+            dev.free()
+    # and the context is fine afterwards
+    assert np.array_equal(gpu_codec.decompress_range(ZSTD, 0, img, index, None, dst_capacity=data.size), data)

@@ -126,6 +126,21 @@ def test_content_checksum_is_verified_like_libzstd_does(model):
     assert ref is not None and rc == 0 and np.array_equal(out, ref) and not np.array_equal(out, data)
 
 
+def test_huffman_literals_larger_than_8_per_compressed_byte_are_refused(model):
+    """advisor r5 (high): a small partition whose 4-stream Huffman section declares regen = 128 KiB must be refused in the
+    literals header — the single-pass literal scratch on the GPU is sized from the compressed size.  libzstd refuses it too."""
+    from oracle import zstd_ref as z
+
+    for regen, sb in ((131072, 40), (131072, 300), (20000, 40), (4096 * 8 + 64, 1000)):
+        frame = corpus.zstd_frame_with_oversized_huffman_literals(regen, sb)
+        assert frame.size < 8192
+        assert z.decompress(frame, regen + 4096) is None
+        rc, out = _decode(model, frame, regen + 4096)
+        assert rc == -3 and out is None
+    # the bound itself is not too tight: 1-bit codes at exactly 8 symbols per byte still pass the header
+    # (covered by every libzstd-written stream in this file decoding; the densest real case is the zeros corpus)
+
+
 def test_mutated_streams_behave_like_libzstd(model):
     """every mutation either fails in both decoders or decodes to the same bytes in both"""
     from oracle import zstd_ref as z
