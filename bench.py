@@ -847,7 +847,7 @@ def run_workload(args, rank: int, local_rank: int, world: int, dist):
         else:
             out["cpu_baseline"] = None
         # roofline.traffic = HBM bytes per launch of the dominant kernel from the PMC counters (2 x FETCH_SIZE + WRITE_SIZE KB,
-        # gfx950 correction as in tools/r4_report.py).  Counters cannot be collected inside a timed run (rocprofv3 serialises
+        # gfx950 correction as in tools/profile_report.py).  Counters cannot be collected inside a timed run (rocprofv3 serialises
         # the kernels), so the figure comes from the tracked PMC pass of the SAME kernels: profiles/traffic_latest.json names
         # the sha256 of the kernel sources each entry was taken with, and it is used only when that equals the stamp of the
         # sources this library was built from (tools/src_stamp.py); otherwise traffic stays null and the entry is only cited.
@@ -1020,7 +1020,7 @@ def run_hbm_stages(args, local_rank: int):
     c.close()
     del d, dst
     torch.cuda.synchronize()
-    # roofline.traffic of these lines: the stamped PMC pass of the same command (tools/r4_profile.sh hbm, tools/r4_report.py)
+    # roofline.traffic of these lines: the stamped PMC pass of the same command (tools/profile_sets.sh hbm, tools/profile_report.py)
     try:
         ref = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
         stamp = _kernel_stamp()
@@ -1064,7 +1064,7 @@ def run_block_size_sweep(args, rank: int, local_rank: int, have: dict):
                 # small blocks: two task threads, each with ONE batched call over half of the step's blocks (what the shim's commit
                 # queue does with the commits of concurrent tasks, S3GpuCommitQueue).  8 x 8 MiB are 2 048 block chains for a chip
                 # that holds 2 560: the step lasts one block chain (0.9 - 1.0 ms) whatever the split; measured
-                # (profiles/r05k_small_blocks.txt) 49.9 / 52.4 / 42.6 / 37.9 GB/s with 1 / 2 / 4 / 8 threads
+                # (profiles/archive/r05k_small_blocks.txt) 49.9 / 52.4 / 42.6 / 37.9 GB/s with 1 / 2 / 4 / 8 threads
                 a.task_threads = 2
             try:
                 o = run_workload(a, rank, local_rank, 1, None)

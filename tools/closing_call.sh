@@ -1,12 +1,16 @@
 #!/bin/bash
-# (GPU) round-5 closing call: GPU suite, the driver's bench line, then the PMC profile of exactly these sources
-#   gpurun --timeout 2700 -- 'bash tools/r5_final.sh r05z "compress decompress crc2000 snappy_compress snappy_decompress zstd hbm"'
-#   then here: python tools/r4_report.py r05z    (profiles/r05z_*, profiles/traffic_latest.json)
-tag=${1:-r05z}
+# (GPU) closing call of a round: GPU suite, the driver's bench line, then the PMC profile of exactly these sources
+#   gpurun --timeout 2700 -- 'bash tools/closing_call.sh r06z "compress decompress crc2000 snappy_compress snappy_decompress zstd hbm"'
+#   then here: python tools/profile_report.py r06z    (profiles/r06z_*, profiles/traffic_latest.json)
+tag=${1:-r06z}
 R=$GRAFT_REPO_ROOT; cd $R; export TMPDIR=/tmp
 O=gpurun_out/$tag; mkdir -p $O
 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 | tee $O/pytest_gpu.txt
-timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2>$O/bench_full.err | grep '^{' > $O/bench_full.json
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_stdout.txt 2>$O/bench_full.err
+tail -n 1 $O/bench_stdout.txt > $O/bench_headline.json      # THE line the driver parses (compact)
+tail -n 2 $O/bench_stdout.txt | head -n 1 > $O/bench_secondary_summary.json
+cp bench_secondary.json $O/bench_full.json                   # full record: headline with long descriptions + every secondary leg
+rm -f $O/bench_stdout.txt
 python - <<PY | tee $O/bench_full.txt
 import json
 d = json.loads(open("$O/bench_full.json").read())
@@ -29,4 +33,4 @@ h = d.get("secondary", {}).get("host_path", {})
 print("  host_path", h.get("compress_by_task_threads"), h.get("verify_decompress_by_task_threads"))
 print("  wall", d.get("secondary", {}).get("wall_s_total"))
 PY
-if [ -n "$2" ]; then bash tools/r4_profile.sh $tag "$2" 2>&1 | tail -60; fi
+if [ -n "$2" ]; then bash tools/profile_sets.sh $tag "$2" 2>&1 | tail -60; fi

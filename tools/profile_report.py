@@ -1,9 +1,9 @@
-"""Round-4 profile report: gpurun_out/<tag>/prof_*/summary.json (tools/summarize_prof.py output of tools/r4_profile.sh) ->
+"""Profile report: gpurun_out/<tag>/prof_*/summary.json (tools/summarize_prof.py output of tools/profile_sets.sh) ->
 profiles/<tag>_<name>_rocprofv3_summary.{md,json} with derived figures, and profiles/traffic_latest.json, every entry stamped
 with the sha256 of the kernel sources it was taken with (gpurun_out/<tag>/kernel_sources_sha256.txt, tools/src_stamp.py):
 bench.py uses an entry as roofline.traffic only when that stamp equals the one of the library it runs.
 
-usage: python tools/r4_report.py <tag> [<commit>]
+usage: python tools/profile_report.py <tag> [<commit>]
 Derived per dominant kernel (per launch):
   cycles        GRBM_GUI_ACTIVE / 8 (the counter is summed over the 8 XCDs; PMC passes serialise the kernels)
   issue util    (SALU + VALU + LDS + VMEM_RD + VMEM_WR instructions) / (1024 SIMDs x cycles)
@@ -83,7 +83,7 @@ for name, (kernel, key, tasks) in SETS.items():
     with open(os.path.join(P, f"{tag}_{name}_rocprofv3_summary.md"), "w") as f:
         f.write(f"# {tag} — rocprofv3 of `{cmd}` (commit {commit})\n\n")
         f.write("Kernel trace (`--kernel-trace --stats`; four task threads share the GPU, so per-launch durations overlap) and separate "
-                "`--pmc` passes (FETCH_SIZE / WRITE_SIZE / SQ x2 / TCC; kernels run one at a time there). Produced by `tools/r4_profile.sh` + `tools/r4_report.py`.\n\n")
+                "`--pmc` passes (FETCH_SIZE / WRITE_SIZE / SQ x2 / TCC; kernels run one at a time there). Produced by `tools/profile_sets.sh` + `tools/profile_report.py`.\n\n")
         f.write("| kernel | calls | avg us | min us | max us | % of GPU time | vgpr | sgpr | lds B | workgroups |\n|---|---|---|---|---|---|---|---|---|---|\n")
         for kn, kv in sorted(d["kernels"].items(), key=lambda kv: -kv[1]["total_ns"]):
             f.write(f"| {kn} | {kv['calls']} | {kv['avg_ns']/1e3:.1f} | {kv['min_ns']/1e3:.1f} | {kv['max_ns']/1e3:.1f} | {kv['pct']:.2f} | {kv['vgpr']} | {kv['sgpr']} | {kv['lds']} | {kv['grid']//max(kv['wg'],1)} |\n")

@@ -1,8 +1,8 @@
 #!/bin/bash
 # (GPU) round 4: profile the kernels AS THEY SHIP — rocprofv3 kernel trace + separate PMC passes (FETCH / WRITE / SQ x2 / TCC)
 # of the five dominant-kernel commands, with the headline's launch shape (--maps-per-gpu 8: two map tasks per compress launch).
-#   gpurun --timeout 900 -- 'bash tools/r4_profile.sh r04b "compress snappy_compress decompress crc2000 snappy_decompress"'
-# then here:  python tools/r4_report.py r04b      (writes profiles/r04b_*_rocprofv3_summary.{md,json}, profiles/traffic_latest.json)
+#   gpurun --timeout 900 -- 'bash tools/profile_sets.sh r04b "compress snappy_compress decompress crc2000 snappy_decompress"'
+# then here:  python tools/profile_report.py r04b      (writes profiles/r04b_*_rocprofv3_summary.{md,json}, profiles/traffic_latest.json)
 tag=${1:-r04b}
 SETS=${2:-compress snappy_compress decompress crc2000 snappy_decompress}
 export TMPDIR=/tmp
@@ -13,7 +13,7 @@ cd $R
 python tools/src_stamp.py > $O/kernel_sources_sha256.txt
 prof() {  # prof <name> <bench args...>
   local P=$O/prof_$1; shift; mkdir -p $P
-  local CMD="python $R/bench.py --no-cpu-baseline --no-secondary --steps 3 --warmup 1 $*"
+  local CMD="python $R/bench.py --no-cpu-baseline --no-secondary --no-image-check --steps 3 --warmup 1 $*"
   if [ "$1" = "--hbm-stages-only" ]; then CMD="python $R/bench.py --hbm-stages-only"; fi
   echo "$CMD" > $P/command.txt
   cd /tmp

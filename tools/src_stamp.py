@@ -1,5 +1,5 @@
 """One stamp for "which kernels is this": sha256 over the sources of libs3shuffle_codec.so (csrc/*.hip, *.inc, *.h, Makefile),
-file names included, in sorted order.  bench.py puts it in its JSON line, the profile report (tools/r4_report.py) puts it into
+file names included, in sorted order.  bench.py puts it in its JSON line, the profile report (tools/profile_report.py) puts it into
 every entry of profiles/traffic_latest.json, and bench.py fills roofline.traffic from that file ONLY when the two agree — a
 PMC pass of an older kernel never stands in for the one that was timed.  There is no .git on the GPU box,
 so a commit id cannot play this role.
