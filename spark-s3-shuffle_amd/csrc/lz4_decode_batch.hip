@@ -103,19 +103,50 @@ __device__ __forceinline__ void lds_st64u(uint8_t* p, uint32_t lo, uint32_t hi) 
   const uint64_t v = (uint64_t)lo | ((uint64_t)hi << 32);
   asm volatile("ds_write_b64 %0, %1" : : "v"(lds_addr(p)), "v"(v) : "memory");
 }
-// the first n (1..16) bytes of x to d
+// the first n (1..16) bytes of x to d.  Per-lane lengths without a branch (round 6): the compiler's form of the obvious
+// cascade (b64 if n & 8, b32 if n & 4, ...) is four s_and_saveexec / s_or exec pairs with their skips — 49 instructions,
+// two thirds of them scalar, per round of the match copies, in a kernel that is bound by the CU's issue ports.  Here
+// the four dwords go out under v_cmpx (exec = "my run has this dword"), then the 1 - 3 tail bytes as a halfword and a
+// byte: 30 instructions, 5 of them scalar, no branch.  n = 0 stores nothing.
 __device__ __forceinline__ void lds_store16(uint8_t* d, u32x4 x, int n) {
-  if (n == 16) {
-    lds_st128u(d, x);
-  } else {
-    const bool h8 = (n & 8) != 0;
-    if (h8) lds_st64u(d, x.x, x.y);
-    const uint32_t a = h8 ? x.z : x.x, b = h8 ? x.w : x.y;
-    if (n & 4) lds_st32(d + (n & 8), a);
-    const uint32_t tw = (n & 4) ? b : a;
-    if (n & 2) lds_st16(d + (n & 12), tw);
-    if (n & 1) d[n & 14] = (uint8_t)(tw >> ((n & 2) * 8));
-  }
+  const uint32_t a = lds_addr(d);
+  uint64_t sv;
+  uint32_t t, ta, b;
+  asm volatile(
+      "s_mov_b64 %[sv], exec\n\t"
+      "v_cmpx_le_u32_e32 vcc, 4, %[n]\n\t"
+      "ds_write_b32 %[a], %[x0]\n\t"
+      "v_cmpx_le_u32_e32 vcc, 8, %[n]\n\t"
+      "ds_write_b32 %[a], %[x1] offset:4\n\t"
+      "v_cmpx_le_u32_e32 vcc, 12, %[n]\n\t"
+      "ds_write_b32 %[a], %[x2] offset:8\n\t"
+      "v_cmpx_le_u32_e32 vcc, 16, %[n]\n\t"
+      "ds_write_b32 %[a], %[x3] offset:12\n\t"
+      "s_mov_b64 exec, %[sv]\n\t"
+      // the dword that holds the tail: x[n >> 2] (two-level select on bits 2 and 3 of n)
+      "v_and_b32_e32 %[b], 4, %[n]\n\t"
+      "v_cmp_ne_u32_e32 vcc, 0, %[b]\n\t"
+      "v_cndmask_b32_e32 %[t], %[x0], %[x1], vcc\n\t"
+      "v_cndmask_b32_e32 %[ta], %[x2], %[x3], vcc\n\t"
+      "v_and_b32_e32 %[b], 8, %[n]\n\t"
+      "v_cmp_ne_u32_e32 vcc, 0, %[b]\n\t"
+      "v_cndmask_b32_e32 %[t], %[t], %[ta], vcc\n\t"
+      "v_and_b32_e32 %[ta], 12, %[n]\n\t"
+      "v_add_u32_e32 %[ta], %[a], %[ta]\n\t"
+      "v_and_b32_e32 %[b], 2, %[n]\n\t"
+      "v_cmpx_ne_u32_e32 vcc, 0, %[b]\n\t"
+      "ds_write_b16 %[ta], %[t]\n\t"
+      "s_mov_b64 exec, %[sv]\n\t"
+      "v_add_u32_e32 %[ta], %[ta], %[b]\n\t"
+      "v_lshlrev_b32_e32 %[b], 3, %[b]\n\t"
+      "v_lshrrev_b32_e32 %[t], %[b], %[t]\n\t"
+      "v_and_b32_e32 %[b], 1, %[n]\n\t"
+      "v_cmpx_ne_u32_e32 vcc, 0, %[b]\n\t"
+      "ds_write_b8 %[ta], %[t]\n\t"
+      "s_mov_b64 exec, %[sv]"
+      : [sv] "=&s"(sv), [t] "=&v"(t), [ta] "=&v"(ta), [b] "=&v"(b)
+      : [a] "v"(a), [n] "v"(n), [x0] "v"(x.x), [x1] "v"(x.y), [x2] "v"(x.z), [x3] "v"(x.w)
+      : "vcc", "memory");
 }
 
 // (HIP's __ballot takes an int: the compiler first materialises the condition as 0 / 1 and compares it again)
@@ -515,17 +546,21 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
         // (a source in front of the window was flushed long ago: those lanes read it back from L2)
         const bool near = a2 + sh >= wb, far = a2 + need + sh <= wb;
         const bool pieces = in && npc > 0 && (near || far);
-        if (need_drain && ballot64(pieces && !near)) {
+        // wave-uniform facts about [s0, s1), taken once instead of in every round (round 6): is any source in front of the
+        // window (those lanes read L2), is any match a period-1 / 2 / 4 splat
+        const bool any_far = ballot64(pieces & !near) != 0ull;
+        const bool any_pat = (ballot64(pieces) & ballot64(off < ml)) != 0ull;
+        if (need_drain && any_far) {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           need_drain = false;
         }
-        const uint64_t PM = ballot64(pieces || (in && ml == 0));
+        const uint64_t PM = ballot64(pieces) | (ballot64(in) & ballot64(ml == 0));
         const uint16_t* plist = reinterpret_cast<const uint16_t*>(rec);
+        const int lpe64 = lpe - kWave;  // (lpe - lp0 <= 64  <=>  lpe - 64 <= lp0)
         int cur = s0;
         while (cur < s1) {
           const int lp0 = __builtin_amdgcn_readlane(lpx, cur);  // pieces in front of sequence cur
-          const uint64_t dok = ballot64(dep <= cur && lpe - lp0 <= kWave);
-          const uint64_t am = (dok & PM) >> cur;
+          const uint64_t am = (ballot64(dep <= cur) & ballot64(lpe64 <= lp0) & PM) >> cur;
           const int run = (~am == 0ull) ? kWave - cur : __builtin_ctzll(~am);
           if (run == 0) {
             const int m0 = __builtin_amdgcn_readlane(ml, cur), o0 = __builtin_amdgcn_readlane(off, cur);
@@ -546,11 +581,12 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
           const int aq = ((int)(w2 << 4) >> 4) + opb, pat = (int)(w2 >> 28);
           int n = mlq - k16;
           n = n < 16 ? n : 16;
+          n = actp ? n : 0;  // (an idle lane stores nothing)
           const int so = aq + (pat ? 0 : k16);
           const bool nearp = aq + sh >= wb;
           // every lane reads 16 bytes of the window (an idle lane, or one whose source is in L2: the first 16)
           u32x4 x = lds_ld128u(win + ((actp && nearp) ? so + sh - wb : 0));
-          if (ballot64(actp && !nearp)) {
+          if (any_far) {
             if (actp && !nearp) {
               const uint8_t* gsrc = out + so;
               x.x = l2_ld32(gsrc);
@@ -559,11 +595,11 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
               if (n > 12 && !pat) x.w = l2_ld32(gsrc + 12);
             }
           }
-          if (ballot64(actp && pat != 0)) {  // period 1, 2 or 4: every dword of the output is the same
+          if (any_pat) {  // period 1, 2 or 4: every dword of the output is the same
             const uint32_t sp = pat == 1 ? (x.x & 0xffu) * 0x01010101u : (pat == 2 ? (x.x & 0xffffu) * 0x00010001u : x.x);
             if (pat) x.x = x.y = x.z = x.w = sp;
           }
-          if (actp) lds_store16(win + (msq + k16 + sh - wb), x, n);
+          lds_store16(win + (msq + k16 + sh - wb), x, n);
           cur += run;
           BT_MARK(3);
           BT_COUNT(9);
