@@ -110,8 +110,10 @@ __device__ __forceinline__ void lds_st64u(uint8_t* p, uint32_t lo, uint32_t hi) 
 // byte: 30 instructions, 5 of them scalar, no branch.  n = 0 stores nothing.
 __device__ __forceinline__ void lds_store16(uint8_t* d, u32x4 x, int n) {
   const uint32_t a = lds_addr(d);
-  uint64_t sv;
-  uint32_t t, ta, b;
+  uint64_t sv, q;
+  uint32_t t, t2, ta, b;
+  // wait states inside the block (tests/isa/hazards.py checks them): a v_cmp's SGPR / VCC result is read by a v_cndmask
+  // no sooner than the third instruction behind it
   asm volatile(
       "s_mov_b64 %[sv], exec\n\t"
       "v_cmpx_le_u32_e32 vcc, 4, %[n]\n\t"
@@ -125,15 +127,15 @@ __device__ __forceinline__ void lds_store16(uint8_t* d, u32x4 x, int n) {
       "s_mov_b64 exec, %[sv]\n\t"
       // the dword that holds the tail: x[n >> 2] (two-level select on bits 2 and 3 of n)
       "v_and_b32_e32 %[b], 4, %[n]\n\t"
-      "v_cmp_ne_u32_e32 vcc, 0, %[b]\n\t"
-      "v_cndmask_b32_e32 %[t], %[x0], %[x1], vcc\n\t"
-      "v_cndmask_b32_e32 %[ta], %[x2], %[x3], vcc\n\t"
-      "v_and_b32_e32 %[b], 8, %[n]\n\t"
-      "v_cmp_ne_u32_e32 vcc, 0, %[b]\n\t"
-      "v_cndmask_b32_e32 %[t], %[t], %[ta], vcc\n\t"
+      "v_and_b32_e32 %[t], 8, %[n]\n\t"
+      "v_cmp_ne_u32_e64 %[q], 0, %[b]\n\t"
+      "v_cmp_ne_u32_e32 vcc, 0, %[t]\n\t"
       "v_and_b32_e32 %[ta], 12, %[n]\n\t"
-      "v_add_u32_e32 %[ta], %[a], %[ta]\n\t"
       "v_and_b32_e32 %[b], 2, %[n]\n\t"
+      "v_cndmask_b32_e64 %[t], %[x0], %[x1], %[q]\n\t"
+      "v_add_u32_e32 %[ta], %[a], %[ta]\n\t"
+      "v_cndmask_b32_e64 %[t2], %[x2], %[x3], %[q]\n\t"
+      "v_cndmask_b32_e32 %[t], %[t], %[t2], vcc\n\t"
       "v_cmpx_ne_u32_e32 vcc, 0, %[b]\n\t"
       "ds_write_b16 %[ta], %[t]\n\t"
       "s_mov_b64 exec, %[sv]\n\t"
@@ -144,7 +146,7 @@ __device__ __forceinline__ void lds_store16(uint8_t* d, u32x4 x, int n) {
       "v_cmpx_ne_u32_e32 vcc, 0, %[b]\n\t"
       "ds_write_b8 %[ta], %[t]\n\t"
       "s_mov_b64 exec, %[sv]"
-      : [sv] "=&s"(sv), [t] "=&v"(t), [ta] "=&v"(ta), [b] "=&v"(b)
+      : [sv] "=&s"(sv), [q] "=&s"(q), [t] "=&v"(t), [t2] "=&v"(t2), [ta] "=&v"(ta), [b] "=&v"(b)
       : [a] "v"(a), [n] "v"(n), [x0] "v"(x.x), [x1] "v"(x.y), [x2] "v"(x.z), [x3] "v"(x.w)
       : "vcc", "memory");
 }
@@ -767,6 +769,123 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
       bool cx = true, is_lit = false;
       int nxt = 0;
       uint32_t r0 = 0, r1 = 0;
+      uint64_t mask = 0;
+      int rel = 0;
+      bool parsed = false;
+#if !defined(S3S_DEC_RING) && !defined(S3S_DEC_NO_PARSE_BLOCK)
+      if constexpr (kFmt == kFmtLz4) {
+        // ---- LZ4, interior windows: the hand-written parse block (round 6) ----------------------------------------------
+        // Same arithmetic as the generic front end + walk + record store below, for windows whose 64 first dwords lie inside
+        // the block (ip + 67 <= clen), in one asm statement that LOOPS over windows for as long as the plain case holds:
+        // the chain starts with a real token (mask != 0) and the window's sequences still fit into the batch.  It leaves
+        //   code 0: every window it took is stored (ip, nseq, sbase advanced) and the next one is not interior,
+        //   code 1: the window at ip starts with a token of the byte-wise path (mask == 0),
+        //   code 2: the window at ip is parsed (mask, rel, r0, r1) but the batch is full,
+        // and the code below carries on from there (flush, byte-wise path, store) exactly as after its own front end.
+        // Why by hand: the compiler's form of this loop is ~90 scalar instructions per window (flag registers for every
+        // break / continue, re-materialised bools) and the CU's ONE scalar port is what its 26 decoder wavefronts queue for
+        // (profiles/r06_experiments.md §2); this block has ~62, and 33 vector instructions instead of ~48.
+        if (ip + 67 <= clen) {
+          int code, n_, cnt_, t_;
+          uint64_t cx_, sv_, t1_;
+          uint32_t v_cpos, v_d0, v_lit, v_b1, v_ml, v_t, v_hdr, v_p2, v_d1, v_e, v_adv, v_t2, v_nrel;
+          asm volatile(
+              ".Lp_loop%=:\n\t"
+              "v_add_u32_e32 %[cpos], %[ip], %[lane]\n\t"
+              "global_load_dword %[d0], %[cpos], %[c]\n\t"
+              "s_waitcnt vmcnt(0)\n\t"
+              "v_bfe_u32 %[lit], %[d0], 4, 4\n\t"
+              "v_bfe_u32 %[b1], %[d0], 8, 8\n\t"
+              "v_and_b32_e32 %[ml], 15, %[d0]\n\t"
+              "v_cmp_eq_u32_e32 vcc, 15, %[lit]\n\t"              // literal length continues in the next byte
+              "v_add_u32_e32 %[vt], 15, %[b1]\n\t"
+              "v_cmp_eq_u32_e64 %[cx], %[ff], %[b1]\n\t"          // ... and that byte is 255: byte-wise path
+              "v_cndmask_b32_e32 %[lit], %[lit], %[vt], vcc\n\t"
+              "v_cndmask_b32_e64 %[hdr], 1, 2, vcc\n\t"
+              "s_and_b64 %[cx], %[cx], vcc\n\t"
+              "v_add3_u32 %[p2], %[cpos], %[hdr], %[lit]\n\t"      // where offset + match-length byte sit
+              "v_add_u32_e32 %[vt], 4, %[p2]\n\t"
+              "v_cmp_ge_i32_e32 vcc, %[clen], %[vt]\n\t"           // p2 + 4 <= clen
+              "s_orn2_b64 %[cx], %[cx], vcc\n\t"
+              "s_and_saveexec_b64 %[sv], vcc\n\t"
+              "global_load_dword %[d1], %[p2], %[c]\n\t"
+              "s_mov_b64 exec, %[sv]\n\t"
+              "v_cmp_eq_u32_e32 vcc, 15, %[ml]\n\t"               // match length continues in the byte behind the offset
+              "v_add_u32_e32 %[t2], %[lane], %[hdr]\n\t"
+              "s_waitcnt vmcnt(0)\n\t"
+              "v_bfe_u32 %[e], %[d1], 16, 8\n\t"
+              "v_and_b32_e32 %[d1], 0xffff, %[d1]\n\t"
+              "v_cndmask_b32_e64 %[adv], 2, 3, vcc\n\t"
+              "v_add_u32_e32 %[vt], %[ml], %[e]\n\t"
+              "v_cmp_eq_u32_e64 %[t1], %[ff], %[e]\n\t"
+              "v_cndmask_b32_e32 %[ml], %[ml], %[vt], vcc\n\t"
+              "s_and_b64 %[t1], %[t1], vcc\n\t"
+              "s_or_b64 %[cx], %[cx], %[t1]\n\t"
+              "v_add_u32_e32 %[nrel], %[p2], %[adv]\n\t"
+              "v_add_u32_e32 %[ml], 4, %[ml]\n\t"
+              "v_subrev_u32_e32 %[nrel], %[ip], %[nrel]\n\t"        // position of the next token, window-relative
+              "v_lshl_or_b32 %[r0], %[ml], 16, %[lit]\n\t"
+              "v_lshl_or_b32 %[r1], %[t2], 16, %[d1]\n\t"
+              "v_cndmask_b32_e64 %[nrel], %[nrel], -1, %[cx]\n\t"
+              // the walk (five instructions per token, see the generic one below)
+              "s_mov_b32 %[rel], 0\n\t"
+              "s_mov_b64 %[m], 0\n\t"
+              "v_readlane_b32 %[n], %[nrel], %[rel]\n\t"
+              "s_cmp_lt_u32 %[n], 64\n\t"
+              "s_cbranch_scc0 .Lp_wout%=\n\t"
+              ".Lp_wnext%=:\n\t"
+              "s_bitset1_b64 %[m], %[rel]\n\t"
+              "s_mov_b32 %[rel], %[n]\n\t"
+              "v_readlane_b32 %[n], %[nrel], %[rel]\n\t"
+              "s_cmp_lt_u32 %[n], 64\n\t"
+              "s_cbranch_scc1 .Lp_wnext%=\n\t"
+              ".Lp_wout%=:\n\t"
+              "s_cmp_gt_i32 %[n], -1\n\t"                           // the chain left the window: its last token is a real one
+              "s_cbranch_scc0 .Lp_wdone%=\n\t"
+              "s_bitset1_b64 %[m], %[rel]\n\t"
+              "s_mov_b32 %[rel], %[n]\n\t"
+              ".Lp_wdone%=:\n\t"
+              "s_bcnt1_i32_b64 %[cnt], %[m]\n\t"                    // scc = (mask != 0)
+              "s_mov_b32 %[code], 1\n\t"
+              "s_cbranch_scc0 .Lp_exit%=\n\t"
+              "s_add_i32 %[t], %[nseq], %[cnt]\n\t"
+              "s_mov_b32 %[code], 2\n\t"
+              "s_cmp_gt_i32 %[t], 64\n\t"
+              "s_cbranch_scc1 .Lp_exit%=\n\t"
+              // store the window's records: token lanes only, record index = nseq + tokens below the lane
+              "s_cmp_eq_u32 %[nseq], 0\n\t"
+              "s_cselect_b32 %[sbase], %[ip], %[sbase]\n\t"
+              "s_sub_i32 %[cnt], %[ip], %[sbase]\n\t"
+              "s_lshl_b32 %[cnt], %[cnt], 16\n\t"
+              "s_mov_b64 exec, %[m]\n\t"
+              "v_mbcnt_lo_u32_b32 %[vt], exec_lo, 0\n\t"
+              "v_mbcnt_hi_u32_b32 %[vt], exec_hi, %[vt]\n\t"
+              "v_add_u32_e32 %[r1], %[cnt], %[r1]\n\t"
+              "v_add_lshl_u32 %[vt], %[vt], %[nseq], 3\n\t"
+              "v_add_u32_e32 %[vt], %[rec], %[vt]\n\t"
+              "ds_write_b32 %[vt], %[r0]\n\t"
+              "ds_write_b32 %[vt], %[r1] offset:4\n\t"
+              "s_mov_b64 exec, -1\n\t"
+              "s_mov_b32 %[nseq], %[t]\n\t"
+              "s_add_i32 %[ip], %[ip], %[rel]\n\t"
+              "s_add_i32 %[t], %[ip], 67\n\t"
+              "s_mov_b32 %[code], 0\n\t"
+              "s_cmp_le_i32 %[t], %[clen]\n\t"
+              "s_cbranch_scc1 .Lp_loop%=\n\t"
+              ".Lp_exit%=:"
+              : [code] "=&s"(code), [m] "=&s"(mask), [rel] "=&s"(rel), [r0] "=&v"(r0), [r1] "=&v"(r1), [ip] "+s"(ip),
+                [nseq] "+s"(nseq), [sbase] "+s"(sbase), [n] "=&s"(n_), [cnt] "=&s"(cnt_), [t] "=&s"(t_), [cx] "=&s"(cx_),
+                [sv] "=&s"(sv_), [t1] "=&s"(t1_), [cpos] "=&v"(v_cpos), [d0] "=&v"(v_d0), [lit] "=&v"(v_lit), [b1] "=&v"(v_b1),
+                [ml] "=&v"(v_ml), [vt] "=&v"(v_t), [hdr] "=&v"(v_hdr), [p2] "=&v"(v_p2), [d1] "=&v"(v_d1), [e] "=&v"(v_e),
+                [adv] "=&v"(v_adv), [t2] "=&v"(v_t2), [nrel] "=&v"(v_nrel)
+              : [c] "s"(c), [clen] "s"(clen), [lane] "v"(lane), [rec] "s"(lds_addr(rec)), [ff] "s"(255)
+              : "vcc", "scc", "memory");
+          if (code == 0) continue;  // (the windows it took are stored; the next one is near the block's end: generic path)
+          parsed = true;
+        }
+      }
+#endif
+      if (!parsed) {
       if (ip >= clen) {
         // LZ4 blocks end inside the byte-wise path (last sequence: literals only); Snappy blocks end here
         if (kFmt == kFmtLz4 || ip > clen) { bad = true; break; }
@@ -857,8 +976,6 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
       // scalar walk over the chain of real tokens: lane `rel` holds the window-relative position of the
       // token behind it, or -1 if the byte-wise path has to take it
       const int nrel = cx ? -1 : nxt - ip;
-      uint64_t mask = 0;
-      int rel = 0;
       if (last_tokens >= (kFmt != kFmtLz4 ? kSnappyWalkTokens : kParallelWalkTokens)) {
         // many short tokens (Snappy elements are 2-3 bytes long on match-dense data, 25 and more per window): the chain
         // is followed by pointer doubling — six rounds of "lanes on the chain mark the lane 2^k tokens behind them"
@@ -903,6 +1020,7 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
           rel = n;
         }
       }
+      }  // (!parsed)
       last_tokens = __builtin_popcountll(mask);
       const int cur = ip + rel;
       // Snappy: a copy element that directly follows a literal element shares the literal's record (literal run +

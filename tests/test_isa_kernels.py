@@ -322,6 +322,38 @@ def test_compiled_decoder_valid_blocks(oracle):
     assert st == 0 and res == [c.tobytes() for c in chunks]
 
 
+def test_decoder_asm_blocks_keep_their_wait_states():
+    """round 6: the batch decoder has hand-written blocks too (the exact-length LDS store under v_cmpx, the LZ4 parse
+    window) — their v_cmp -> v_cndmask / v_readlane distances are not padded by hipcc, so the checker walks them"""
+    import hazards
+    import lz4_kernel as lk
+
+    text = lk.compile_asm("lz4_decode_batch.hip")
+    for fmt in (0, 1, 2):
+        entry = lk.find_kernel(text, "batch_decode_kernelILi%dE" % fmt)
+        asm_viol, cc_viol, _, _ = hazards.check_kernel(text, entry)
+        assert not asm_viol, asm_viol[:4]
+        assert not cc_viol, ("rule set stricter than the compiler", cc_viol[:3])
+
+
+def test_compiled_lz4_parse_block_takes_the_interior_windows(oracle):
+    """the hand-written parse block must be where the windows of an ordinary block are parsed (and the generic front end
+    only near the block's end / around byte-wise tokens): a silent fall-back to the compiled loop would keep the tests
+    green and lose the point"""
+    import decode_kernel as dk
+    from s3shuffle import datagen
+
+    d, _ = datagen.terasort_map_output(1 << 20, 1, seed=2, map_id=0)
+    blk = d[32768 * 5:32768 * 6]
+    c = bytes(oracle.lz4_compress_block(blk))
+    prof = {}
+    res, st, _ = dk.decode_blocks([(c, 32768)], fmt=0, profile=prof)
+    assert st == 0 and res[0] == bytes(blk)
+    walk = sum(v[0] for k, v in prof.items() if k.startswith(".Lp_wnext"))          # tokens walked inside the block (x 5)
+    generic = sum(v[0] for k, v in prof.items() if k.startswith(".Lwalk_next"))     # ... by the generic front end
+    assert walk > 4000 and walk > 20 * generic, (walk, generic)
+
+
 def test_compiled_decoder_on_chained_sources(oracle):
     """hand-made sequence lists whose matches copy from inside earlier matches, from literal runs and from periodic
     patterns (the generator of tests/test_batch_decode_model.py): what the decoder's source redirection, its 16-byte
