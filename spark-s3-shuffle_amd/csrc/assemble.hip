@@ -19,7 +19,7 @@ namespace {
 // workgroup that needs even a few bytes of it waits for one of their ~1 ms chunks to finish (the
 // 1024-thread LDS version of this kernel took 9 us alone and 234 us on average next to a second
 // stream, profiles/r01d).  256 items per step (4 per lane), carried in a register.
-__global__ __launch_bounds__(kWave) void scan_items_kernel(
+__device__ __forceinline__ void scan_items_body(
     const uint32_t* __restrict__ item_size, int32_t n_items, int64_t* item_off,
     const int32_t* __restrict__ part_first, int32_t n_parts, int64_t* __restrict__ index) {
   const int lane = threadIdx.x;
@@ -51,6 +51,34 @@ __global__ __launch_bounds__(kWave) void scan_items_kernel(
     index[p] = __builtin_nontemporal_load(&item_off[part_first[p]]);
 }
 
+__global__ __launch_bounds__(kWave) void scan_items_kernel(
+    const uint32_t* __restrict__ item_size, int32_t n_items, int64_t* item_off,
+    const int32_t* __restrict__ part_first, int32_t n_parts, int64_t* __restrict__ index) {
+  scan_items_body(item_size, n_items, item_off, part_first, n_parts, index);
+}
+
+// the task that owns global index i of a packed array: the last t with first(t) <= i  (wave-uniform: scalar loads)
+template <typename F>
+__device__ __forceinline__ int owner_task(int32_t n_tasks, int32_t i, F first) {
+  int lo = 0, hi = n_tasks;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (first(mid) <= i) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// one wavefront per TASK of a batched call (item_off holds one extra entry per task: + t)
+__global__ __launch_bounds__(kWave) void scan_items_batch_kernel(
+    const TaskTail* __restrict__ tails, int32_t n_tasks, const uint32_t* __restrict__ item_size, int64_t* item_off,
+    const int32_t* __restrict__ part_first, int64_t* __restrict__ index) {
+  const int t = blockIdx.x;
+  if (t >= n_tasks) return;
+  const TaskTail k = tails[t];
+  scan_items_body(item_size + k.first_item, k.n_items, item_off + k.first_item + t, part_first + k.first_pp, k.n_parts,
+                  index + k.first_pp);
+}
+
 constexpr int kGatherThreads = 256;
 
 // n bytes global -> global; 16-byte stores on the destination's alignment.
@@ -71,12 +99,11 @@ __device__ __forceinline__ void copy_bytes(uint8_t* __restrict__ dst, const uint
   if (tid < n - done) dst[done + tid] = src[done + tid];
 }
 
-__global__ __launch_bounds__(kGatherThreads) void gather_items_kernel(
+__device__ __forceinline__ void gather_item_body(
     const uint8_t* __restrict__ src, const Item* __restrict__ items, int32_t n_items,
     const uint8_t* __restrict__ slots, int64_t slot_stride, const uint32_t* __restrict__ item_size,
     const int64_t* __restrict__ item_off, uint8_t* __restrict__ dst, int64_t dst_capacity,
-    int32_t* __restrict__ status) {
-  const int it = blockIdx.x;
+    int32_t* __restrict__ status, int it) {
   if (it >= n_items) return;
   const Item item = items[it];
   const uint32_t sz = item_size[it];
@@ -123,7 +150,43 @@ __global__ __launch_bounds__(kGatherThreads) void gather_items_kernel(
   }
 }
 
+__global__ __launch_bounds__(kGatherThreads) void gather_items_kernel(
+    const uint8_t* __restrict__ src, const Item* __restrict__ items, int32_t n_items,
+    const uint8_t* __restrict__ slots, int64_t slot_stride, const uint32_t* __restrict__ item_size,
+    const int64_t* __restrict__ item_off, uint8_t* __restrict__ dst, int64_t dst_capacity,
+    int32_t* __restrict__ status) {
+  gather_item_body(src, items, n_items, slots, slot_stride, item_size, item_off, dst, dst_capacity, status, (int)blockIdx.x);
+}
+
+// one workgroup per item of EVERY task of a batched call
+__global__ __launch_bounds__(kGatherThreads) void gather_items_batch_kernel(
+    const TaskTail* __restrict__ tails, int32_t n_tasks, int32_t n_items_total, const uint8_t* __restrict__ src,
+    const Item* __restrict__ items, const uint8_t* __restrict__ slots, int64_t slot_stride,
+    const uint32_t* __restrict__ item_size, const int64_t* __restrict__ item_off, int32_t* __restrict__ status) {
+  const int g = blockIdx.x;
+  if (g >= n_items_total) return;
+  const int t = owner_task(n_tasks, g, [&](int m) { return tails[m].first_item; });
+  const TaskTail k = tails[t];
+  gather_item_body(src, items + k.first_item, k.n_items, slots, slot_stride, item_size + k.first_item,
+                   item_off + k.first_item + t, k.dst, k.dst_capacity, status + t, g - k.first_item);
+}
+
 }  // namespace
+
+void launch_scan_items_batch(const TaskTail* d_tails, int32_t n_tasks, const uint32_t* d_item_size, int64_t* d_item_off,
+                             const int32_t* d_part_first, int64_t* d_index, hipStream_t st) {
+  if (n_tasks <= 0) return;
+  hipLaunchKernelGGL(scan_items_batch_kernel, dim3((unsigned)n_tasks), dim3(kWave), 0, st, d_tails, n_tasks, d_item_size, d_item_off,
+                     d_part_first, d_index);
+}
+
+void launch_gather_items_batch(const TaskTail* d_tails, int32_t n_tasks, int32_t n_items_total, const uint8_t* d_src, const Item* d_items,
+                               const uint8_t* d_slots, int64_t slot_stride, const uint32_t* d_item_size, const int64_t* d_item_off,
+                               int32_t* d_status, hipStream_t st) {
+  if (n_items_total <= 0) return;
+  hipLaunchKernelGGL(gather_items_batch_kernel, dim3((unsigned)n_items_total), dim3(kGatherThreads), 0, st, d_tails, n_tasks,
+                     n_items_total, d_src, d_items, d_slots, slot_stride, d_item_size, d_item_off, d_status);
+}
 
 void launch_scan_items(const Item*, const uint32_t* d_item_size, int32_t n_items,
                        int64_t* d_item_off, const int32_t* d_part_first, int32_t n_parts,

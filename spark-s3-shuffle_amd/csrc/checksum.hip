@@ -114,11 +114,11 @@ __device__ __forceinline__ uint32_t crc_byte(const NibbleTabs& n, uint32_t c, ui
 
 // partial[seg] = { A|crc, B, seg_len, 0 }
 template <int ALGO>
-__global__ __launch_bounds__(kThreads) void checksum_segments_kernel(
+__device__ __forceinline__ void checksum_segment_body(
     const uint8_t* __restrict__ data, const int64_t* __restrict__ offsets, int32_t n,
     const int32_t* __restrict__ seg_start, const Tables* __restrict__ tabs,
-    uint32_t* __restrict__ partial, int64_t data_len) {
-  const int b = blockIdx.x, tid = threadIdx.x;
+    uint32_t* __restrict__ partial, int64_t data_len, const int b) {
+  const int tid = threadIdx.x;
   // which range owns worst-case segment slot b
   int lo = 0, hi = n;  // seg_start[lo] <= b < seg_start[hi]
   while (hi - lo > 1) {
@@ -244,11 +244,43 @@ __global__ __launch_bounds__(kThreads) void checksum_segments_kernel(
 // unit = bytes one partial stands for (all but a range's last): kChecksumSegBytes, or — behind checksum_fold_kernel —
 // fold_groups x kChecksumSegBytes with the partials of range p at partial + 4 * p * max_groups
 template <int ALGO>
-__global__ __launch_bounds__(kThreads) void checksum_combine_kernel(
+__global__ __launch_bounds__(kThreads) void checksum_segments_kernel(
+    const uint8_t* __restrict__ data, const int64_t* __restrict__ offsets, int32_t n,
+    const int32_t* __restrict__ seg_start, const Tables* __restrict__ tabs,
+    uint32_t* __restrict__ partial, int64_t data_len) {
+  checksum_segment_body<ALGO>(data, offsets, n, seg_start, tabs, partial, data_len, (int)blockIdx.x);
+}
+
+// the last t with first(t) <= i (wave-uniform: scalar loads; see assemble.hip)
+template <typename F>
+__device__ __forceinline__ int owner_task(int32_t n_tasks, int32_t i, F first) {
+  int lo = 0, hi = n_tasks;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (first(mid) <= i) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// the segments of EVERY task / fetched range of a batched call in one launch (TaskTail, s3s_internal.h)
+template <int ALGO>
+__global__ __launch_bounds__(kThreads) void checksum_segments_batch_kernel(
+    const TaskTail* __restrict__ tails, int32_t n_tasks, const int64_t* __restrict__ offsets,
+    const int32_t* __restrict__ seg_start, const Tables* __restrict__ tabs, uint32_t* __restrict__ partial) {
+  const int g = blockIdx.x;
+  const int t = owner_task(n_tasks, g, [&](int m) { return tails[m].first_seg; });
+  const TaskTail k = tails[t];
+  if (g - k.first_seg >= k.n_segs || k.n_parts <= 0) return;
+  checksum_segment_body<ALGO>(k.data, offsets + k.first_pp, k.n_parts, seg_start + k.first_pp, tabs, partial + 4 * (size_t)k.first_seg,
+                              k.data_len, g - k.first_seg);
+}
+
+template <int ALGO>
+__device__ __forceinline__ void checksum_combine_body(
     const int64_t* __restrict__ offsets, int32_t n, const int32_t* __restrict__ seg_start,
     const Tables* __restrict__ tabs, const uint32_t* __restrict__ partial,
-    int64_t* __restrict__ out, int64_t unit, int32_t max_groups) {
-  const int p = blockIdx.x, tid = threadIdx.x;
+    int64_t* __restrict__ out, int64_t unit, int32_t max_groups, const int p) {
+  const int tid = threadIdx.x;
   if (p >= n) return;
   const int64_t plen = offsets[p + 1] - offsets[p];
   const int64_t nseg = (plen + unit - 1) / unit;
@@ -295,6 +327,30 @@ __global__ __launch_bounds__(kThreads) void checksum_combine_kernel(
     for (int d = 32; d >= 1; d >>= 1) c ^= __shfl_xor(c, d);
     if (tid == 0) out[p] = (int64_t)(uint64_t)c;
   }
+}
+
+
+template <int ALGO>
+__global__ __launch_bounds__(kThreads) void checksum_combine_kernel(
+    const int64_t* __restrict__ offsets, int32_t n, const int32_t* __restrict__ seg_start,
+    const Tables* __restrict__ tabs, const uint32_t* __restrict__ partial,
+    int64_t* __restrict__ out, int64_t unit, int32_t max_groups) {
+  checksum_combine_body<ALGO>(offsets, n, seg_start, tabs, partial, out, unit, max_groups, (int)blockIdx.x);
+}
+
+// one wavefront per partition of EVERY task of a batched call
+template <int ALGO>
+__global__ __launch_bounds__(kWave) void checksum_combine_batch_kernel(
+    const TaskTail* __restrict__ tails, int32_t n_tasks, int32_t total_parts, const int64_t* __restrict__ offsets,
+    const int32_t* __restrict__ seg_start, const Tables* __restrict__ tabs, const uint32_t* __restrict__ partial,
+    int64_t* __restrict__ out) {
+  const int g = blockIdx.x;
+  if (g >= total_parts) return;
+  const int t = owner_task(n_tasks, g, [&](int m) { return tails[m].first_part; });
+  const TaskTail k = tails[t];
+  if (g - k.first_part >= k.n_parts) return;
+  checksum_combine_body<ALGO>(offsets + k.first_pp, k.n_parts, seg_start + k.first_pp, tabs, partial + 4 * (size_t)k.first_seg,
+                              out + k.first_part, (int64_t)kChecksumSegBytes, 0, g - k.first_part);
 }
 
 
@@ -431,6 +487,27 @@ void launch_checksum_with_tables(int algo, const uint8_t* d_data, const int64_t*
                          d_offsets, n, d_seg_start, tabs, d_partial, d_partial2, kChecksumFoldGroup, max_groups);
     hipLaunchKernelGGL(checksum_combine_kernel<S3S_CHECKSUM_CRC32>, dim3((unsigned)n),
                        dim3(kWave), 0, st, d_offsets, n, d_seg_start, tabs, comb_in, d_out, unit, max_groups);
+  }
+}
+
+void launch_checksum_batch(int algo, const TaskTail* d_tails, int32_t n_tasks, int32_t total_segs, int32_t total_parts,
+                           const int64_t* d_offsets, const int32_t* d_seg_start, const void* d_tables, uint32_t* d_partial,
+                           int64_t* d_out, hipStream_t st) {
+  if (n_tasks <= 0 || total_parts <= 0) return;
+  const Tables* tabs = static_cast<const Tables*>(d_tables) + (algo == S3S_CHECKSUM_CRC32C ? 1 : 0);
+  if (total_segs > 0) (void)hipMemsetAsync(d_partial, 0, 16 * (size_t)total_segs, st);
+  if (algo == S3S_CHECKSUM_ADLER32) {
+    if (total_segs > 0)
+      hipLaunchKernelGGL(checksum_segments_batch_kernel<S3S_CHECKSUM_ADLER32>, dim3((unsigned)total_segs), dim3(kThreads), 0, st,
+                         d_tails, n_tasks, d_offsets, d_seg_start, tabs, d_partial);
+    hipLaunchKernelGGL(checksum_combine_batch_kernel<S3S_CHECKSUM_ADLER32>, dim3((unsigned)total_parts), dim3(kWave), 0, st, d_tails,
+                       n_tasks, total_parts, d_offsets, d_seg_start, tabs, d_partial, d_out);
+  } else {
+    if (total_segs > 0)
+      hipLaunchKernelGGL(checksum_segments_batch_kernel<S3S_CHECKSUM_CRC32>, dim3((unsigned)total_segs), dim3(kThreads), 0, st,
+                         d_tails, n_tasks, d_offsets, d_seg_start, tabs, d_partial);
+    hipLaunchKernelGGL(checksum_combine_batch_kernel<S3S_CHECKSUM_CRC32>, dim3((unsigned)total_parts), dim3(kWave), 0, st, d_tails,
+                       n_tasks, total_parts, d_offsets, d_seg_start, tabs, d_partial, d_out);
   }
 }
 

@@ -546,7 +546,7 @@ int s3s_compress_map_outputs_batch_device(s3s_ctx* ctx, int codec, int checksum_
   auto al = [](size_t x) { return (x + 15) & ~size_t(15); };
   const size_t o_items = 0, o_pf = al(o_items + items_bytes), o_seg = al(o_pf + 4 * np1), o_idx = al(o_seg + 4 * np1),
                o_sums = al(o_idx + 8 * np1), o_status = al(o_sums + 8 * ((size_t)n_parts64 + 1)),
-               stage_total = o_status + 4 * (size_t)n_tasks + 16;
+               o_tails = al(o_status + 4 * (size_t)n_tasks + 16), stage_total = o_tails + sizeof(TaskTail) * (size_t)n_tasks + 16;
   int rc;
   if ((rc = ensure_stage(ctx, stage_total))) return rc;
   uint8_t* hs = static_cast<uint8_t*>(ctx->h_stage);
@@ -556,6 +556,7 @@ int s3s_compress_map_outputs_batch_device(s3s_ctx* ctx, int codec, int checksum_
   int64_t* h_idx = reinterpret_cast<int64_t*>(hs + o_idx);
   int64_t* h_sums = reinterpret_cast<int64_t*>(hs + o_sums);
   int32_t* h_status = reinterpret_cast<int32_t*>(hs + o_status);
+  TaskTail* h_tails = reinterpret_cast<TaskTail*>(hs + o_tails);
   std::vector<int32_t> first_item((size_t)n_tasks + 1), first_part((size_t)n_tasks + 1), first_seg((size_t)n_tasks + 1);
   const uint8_t* base = tasks[0].d_src;  // item sources are offsets from one base pointer (signed 64-bit)
   {
@@ -608,7 +609,25 @@ int s3s_compress_map_outputs_batch_device(s3s_ctx* ctx, int codec, int checksum_
   if ((rc = ensure(ctx, B_ITEM_OFF, sizeof(int64_t) * ((size_t)n_items + (size_t)n_tasks + 1)))) return rc;
   if ((rc = ensure(ctx, B_ITEM_CHECK, sizeof(uint32_t) * (size_t)(n_items + 1)))) return rc;
   if ((rc = ensure(ctx, B_WORK, 64))) return rc;
+  if ((rc = ensure(ctx, B_TAILS, sizeof(TaskTail) * (size_t)n_tasks + 16))) return rc;
+  for (int32_t t = 0; t < n_tasks; t++) {  // what the once-per-call tail kernels need to know about each task
+    const s3s_map_task& k = tasks[t];
+    TaskTail& d = h_tails[t];
+    d.first_item = first_item[(size_t)t];
+    d.n_items = first_item[(size_t)t + 1] - first_item[(size_t)t];
+    d.first_pp = first_part[(size_t)t] + t;
+    d.n_parts = k.num_partitions;
+    d.first_part = first_part[(size_t)t];
+    d.first_seg = first_seg[(size_t)t];
+    d.n_segs = first_seg[(size_t)t + 1] - first_seg[(size_t)t];
+    d.pad = 0;
+    d.data = k.d_dst;
+    d.data_len = k.dst_capacity;
+    d.dst = k.d_dst;
+    d.dst_capacity = k.dst_capacity;
+  }
   HIP_TRY(ctx, hipMemsetAsync(ctx->buf[B_STATUS].p, 0, 4 * (size_t)n_tasks + 16, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_TAILS].p, h_tails, sizeof(TaskTail) * (size_t)n_tasks, hipMemcpyHostToDevice, ctx->stream));
   // one upload: items | part_first | seg_start are consecutive in the staging buffer but live in separate
   // device buffers
   if (n_items > 0)
@@ -631,31 +650,20 @@ int s3s_compress_map_outputs_batch_device(s3s_ctx* ctx, int codec, int checksum_
   HIP_TRY(ctx, hipGetLastError());
   dbg_sync(ctx, "batch codec");
   record(ctx, 1);
-  // ---- per task: offsets, .data image, checksums ------------------------------------------------------------
-  for (int32_t t = 0; t < n_tasks; t++) {
-    const s3s_map_task& k = tasks[t];
-    const int32_t fi = first_item[(size_t)t], ni = first_item[(size_t)t + 1] - fi, pp = first_part[(size_t)t] + t;
-    launch_scan_items(dev<Item>(ctx, B_ITEMS) + fi, dev<uint32_t>(ctx, B_ITEM_SIZE) + fi, ni,
-                      dev<int64_t>(ctx, B_ITEM_OFF) + fi + t, dev<int32_t>(ctx, B_PART_FIRST) + pp, k.num_partitions,
-                      dev<int64_t>(ctx, B_INDEX) + pp, ctx->stream);
-    dbg_sync(ctx, "batch scan");
-    launch_gather_items(base, dev<Item>(ctx, B_ITEMS) + fi, ni, dev<uint8_t>(ctx, B_SLOTS), slot_stride,
-                        dev<uint32_t>(ctx, B_ITEM_SIZE) + fi, dev<int64_t>(ctx, B_ITEM_OFF) + fi + t, k.d_dst,
-                        k.dst_capacity, dev<int32_t>(ctx, B_STATUS) + t, ctx->stream);
-    dbg_sync(ctx, "batch gather");
-  }
+  // ---- offsets, .data images, checksums of every task: one launch each (TaskTail, s3s_internal.h) ---------------------
+  launch_scan_items_batch(dev<TaskTail>(ctx, B_TAILS), n_tasks, dev<uint32_t>(ctx, B_ITEM_SIZE), dev<int64_t>(ctx, B_ITEM_OFF),
+                          dev<int32_t>(ctx, B_PART_FIRST), dev<int64_t>(ctx, B_INDEX), ctx->stream);
+  dbg_sync(ctx, "batch scan");
+  launch_gather_items_batch(dev<TaskTail>(ctx, B_TAILS), n_tasks, n_items, base, dev<Item>(ctx, B_ITEMS), dev<uint8_t>(ctx, B_SLOTS),
+                            slot_stride, dev<uint32_t>(ctx, B_ITEM_SIZE), dev<int64_t>(ctx, B_ITEM_OFF), dev<int32_t>(ctx, B_STATUS),
+                            ctx->stream);
+  dbg_sync(ctx, "batch gather");
   HIP_TRY(ctx, hipGetLastError());
   record(ctx, 2);
   if (checksum_algo != S3S_CHECKSUM_NONE) {
-    for (int32_t t = 0; t < n_tasks; t++) {
-      const s3s_map_task& k = tasks[t];
-      if (k.num_partitions <= 0) continue;
-      const int32_t pp = first_part[(size_t)t] + t;
-      launch_checksum_with_tables(checksum_algo, k.d_dst, dev<int64_t>(ctx, B_INDEX) + pp, k.num_partitions,
-                                  dev<int32_t>(ctx, B_SEG_START) + pp, first_seg[(size_t)t + 1] - first_seg[(size_t)t],
-                                  ctx->buf[B_TABLES].p, dev<uint32_t>(ctx, B_PARTIAL) + 4 * (size_t)first_seg[(size_t)t],
-                                  dev<int64_t>(ctx, B_SUMS) + first_part[(size_t)t], k.dst_capacity, ctx->stream);
-    }
+    launch_checksum_batch(checksum_algo, dev<TaskTail>(ctx, B_TAILS), n_tasks, total_segs, (int32_t)n_parts64, dev<int64_t>(ctx, B_INDEX),
+                          dev<int32_t>(ctx, B_SEG_START), ctx->buf[B_TABLES].p, dev<uint32_t>(ctx, B_PARTIAL), dev<int64_t>(ctx, B_SUMS),
+                          ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
   }
   record(ctx, 3);

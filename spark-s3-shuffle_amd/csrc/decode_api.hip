@@ -501,7 +501,8 @@ extern "C" int s3s_decompress_ranges_batch_device(s3s_ctx* ctx, int codec, int c
   const size_t o_off = 0, o_seg = al(o_off + 8 * np1), o_sums = al(o_seg + 4 * np1), o_nf = al(o_sums + 8 * ((size_t)n_parts + 1)),
                o_tot = al(o_nf + 8 * (size_t)n_ranges), o_st = al(o_tot + 8 * (size_t)n_ranges),
                o_desc = al(o_st + 4 * ((size_t)n_ranges + 1)), o_map = al(o_desc + sizeof(LzRange) * (size_t)n_ranges),
-               o_res = al(o_map + 4 * ((size_t)total_tiles + 1)), stage_total = o_res + 16 * (size_t)n_ranges + 16;
+               o_res = al(o_map + 4 * ((size_t)total_tiles + 1)), o_tails = al(o_res + 16 * (size_t)n_ranges + 16),
+               stage_total = o_tails + sizeof(TaskTail) * (size_t)n_ranges + 16;
   int rc;
   if ((rc = ensure_stage(ctx, stage_total))) return rc;
   uint8_t* hs = static_cast<uint8_t*>(ctx->h_stage);
@@ -560,14 +561,25 @@ extern "C" int s3s_decompress_ranges_batch_device(s3s_ctx* ctx, int codec, int c
   record(ctx, 0);
   int32_t* d_status = dev<int32_t>(ctx, B_STATUS);
   // ---- phase 1: checksums + frame discovery of every range, one wait ---------------------------------------------
-  for (int32_t r = 0; r < n_ranges; r++) {
-    const s3s_fetch_range& k = R[r];
-    const size_t pp = first_part[(size_t)r] + (size_t)r;
-    if (do_sum && k.num_partitions > 0)
-      launch_checksum_with_tables(checksum_algo, k.d_comp, dev<int64_t>(ctx, B_OFFSETS) + pp, k.num_partitions,
-                                  dev<int32_t>(ctx, B_SEG_START) + pp, (int32_t)(first_seg[(size_t)r + 1] - first_seg[(size_t)r]),
-                                  ctx->buf[B_TABLES].p, dev<uint32_t>(ctx, B_PARTIAL) + 4 * first_seg[(size_t)r],
-                                  dev<int64_t>(ctx, B_SUMS) + first_part[(size_t)r], k.comp_len, ctx->stream);
+  if (do_sum && n_parts > 0) {  // the checksums of every range: one segments launch + one combine launch (TaskTail, s3s_internal.h)
+    if ((rc = ensure(ctx, B_TAILS, sizeof(TaskTail) * (size_t)n_ranges + 16))) return rc;
+    TaskTail* h_tails = reinterpret_cast<TaskTail*>(hs + o_tails);
+    for (int32_t r = 0; r < n_ranges; r++) {
+      const s3s_fetch_range& k = R[r];
+      TaskTail& d = h_tails[r];
+      memset(&d, 0, sizeof(d));
+      d.first_pp = (int32_t)(first_part[(size_t)r] + (size_t)r);
+      d.n_parts = k.num_partitions;
+      d.first_part = (int32_t)first_part[(size_t)r];
+      d.first_seg = (int32_t)first_seg[(size_t)r];
+      d.n_segs = (int32_t)(first_seg[(size_t)r + 1] - first_seg[(size_t)r]);
+      d.data = k.d_comp;
+      d.data_len = k.comp_len;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[B_TAILS].p, h_tails, sizeof(TaskTail) * (size_t)n_ranges, hipMemcpyHostToDevice, ctx->stream));
+    launch_checksum_batch(checksum_algo, dev<TaskTail>(ctx, B_TAILS), n_ranges, (int32_t)first_seg[(size_t)n_ranges], (int32_t)n_parts,
+                          dev<int64_t>(ctx, B_OFFSETS), dev<int32_t>(ctx, B_SEG_START), ctx->buf[B_TABLES].p,
+                          dev<uint32_t>(ctx, B_PARTIAL), dev<int64_t>(ctx, B_SUMS), ctx->stream);
   }
   record(ctx, 1);
   if (codec == S3S_CODEC_LZ4) {

@@ -550,8 +550,8 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
         const bool pieces = in && npc > 0 && (near || far);
         // wave-uniform facts about [s0, s1), taken once instead of in every round (round 6): is any source in front of the
         // window (those lanes read L2), is any match a period-1 / 2 / 4 splat
-        const bool any_far = ballot64(pieces & !near) != 0ull;
-        const bool any_pat = (ballot64(pieces) & ballot64(off < ml)) != 0ull;
+        const int any_far = ballot64(pieces & !near) != 0ull ? 1 : 0;
+        const int any_pat = (ballot64(pieces) & ballot64(off < ml)) != 0ull ? 1 : 0;
         if (need_drain && any_far) {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           need_drain = false;
@@ -563,7 +563,8 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
         while (cur < s1) {
           const int lp0 = __builtin_amdgcn_readlane(lpx, cur);  // pieces in front of sequence cur
           const uint64_t am = (ballot64(dep <= cur) & ballot64(lpe64 <= lp0) & PM) >> cur;
-          const int run = (~am == 0ull) ? kWave - cur : __builtin_ctzll(~am);
+          int run;  // the first zero bit of am, or all that is left (s_ff0 answers -1 when there is no zero bit)
+          asm("s_ff0_i32_b64 %0, %1\n\ts_min_u32 %0, %0, %2" : "=&s"(run) : "s"(am), "s"(kWave - cur) : "scc");
           if (run == 0) {
             const int m0 = __builtin_amdgcn_readlane(ml, cur), o0 = __builtin_amdgcn_readlane(off, cur);
             const int ms0 = __builtin_amdgcn_readlane(mstart, cur);

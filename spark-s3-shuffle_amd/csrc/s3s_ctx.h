@@ -27,6 +27,7 @@ enum BufId {
   B_WORK,  // block counter of the persistent codec grid
   B_PARTIAL2,  // checksum partials of folded segment groups (ranges of more than kChecksumFoldFrom segments)
   B_ZSCRATCH, B_ZPIECES,  // zstd single pass: decoded partitions at guessed capacities, and the compaction's piece list
+  B_TAILS,  // batched calls: one TaskTail per map task / fetched range (s3s_internal.h)
   B_COUNT
 };
 

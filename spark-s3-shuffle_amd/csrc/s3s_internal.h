@@ -84,6 +84,31 @@ void launch_checksum_with_tables(int algo, const uint8_t* d_data, const int64_t*
                                  const void* d_tables, uint32_t* d_partial, int64_t* d_out,
                                  int64_t data_len /* bytes readable at d_data */, hipStream_t st,
                                  int32_t max_segs_per_range = 0, uint32_t* d_partial2 = nullptr);
+// ---- batched tails (round 6) --------------------------------------------------------------------------------------------
+// A batched call used to launch its small kernels PER TASK (scan, gather, memset + segments + combine of the checksums: six
+// launches per map task, 2 - 5 us each plus the gap between them): 32 blocks of 8 MiB in one call spent 2.2 of its 5.6 ms
+// there (profiles/r06e_*).  One descriptor per task / fetched range, uploaded with the plan; every tail kernel is launched
+// ONCE per call and finds its task by a binary search over the descriptors (a handful of scalar loads).
+struct TaskTail {
+  int32_t first_item, n_items;   // compress: the task's plan records (scan / gather)
+  int32_t first_pp, n_parts;     // its partitions in the packed arrays that hold n + 1 entries per task (index, part_first, seg_start)
+  int32_t first_part;            // ... and in the arrays that hold n entries per task (checksums out)
+  int32_t first_seg;             // its first checksum segment slot in the call's partial array (seg_start is task-relative)
+  int32_t n_segs, pad;
+  const uint8_t* data;           // what the checksums run over: the task's .data image / the fetched range
+  int64_t data_len;              // bytes readable there
+  uint8_t* dst;                  // compress: the .data image the gather writes
+  int64_t dst_capacity;
+};
+void launch_scan_items_batch(const TaskTail* d_tails, int32_t n_tasks, const uint32_t* d_item_size, int64_t* d_item_off,
+                             const int32_t* d_part_first, int64_t* d_index, hipStream_t st);
+void launch_gather_items_batch(const TaskTail* d_tails, int32_t n_tasks, int32_t n_items_total, const uint8_t* d_src, const Item* d_items,
+                               const uint8_t* d_slots, int64_t slot_stride, const uint32_t* d_item_size, const int64_t* d_item_off,
+                               int32_t* d_status, hipStream_t st);
+// checksums of every task's ranges: offsets / seg_start packed (n + 1 per task), partial zeroed here, out packed (n per task)
+void launch_checksum_batch(int algo, const TaskTail* d_tails, int32_t n_tasks, int32_t total_segs, int32_t total_parts,
+                           const int64_t* d_offsets, const int32_t* d_seg_start, const void* d_tables, uint32_t* d_partial,
+                           int64_t* d_out, hipStream_t st);
 constexpr int kChecksumSegBytes = 16384;
 constexpr int kChecksumFoldGroup = 256;   // segments per folded group (4 MiB)
 constexpr int kChecksumFoldFrom = 2048;   // a range with more segments than this (32 MiB) is folded in two levels

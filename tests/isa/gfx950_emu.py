@@ -1210,6 +1210,9 @@ class Program:
     def x_s_ff1_i32_b64(self, w, i):
         w.ws32(i.ops[0], _ff1(_lit64(i.ops[1], w), 64))
 
+    def x_s_ff0_i32_b64(self, w, i):  # position of the first ZERO bit, -1 if there is none (SCC untouched)
+        w.ws32(i.ops[0], _ff1(~_lit64(i.ops[1], w) & ((1 << 64) - 1), 64))
+
     def x_s_flbit_i32_b32(self, w, i):
         w.ws32(i.ops[0], _flbit(w.rs32(i.ops[1]), 32))
 
