@@ -257,8 +257,8 @@ def parse_args():
                     help="concurrent task threads per GPU, one s3s_ctx (HIP stream) each — an executor runs "
                          "several tasks at once (spark.executor.cores = 4 in the reference's examples); 0 = 4 for compress "
                          "(measured 78.6 GB/s against 76.8 with two and 75.9 with one: the hash / assemble / checksum "
-                         "stages of one call overlap the other calls' codec kernels), 1 for decompress (one batched "
-                         "call over all fetched ranges measured fastest: 305 vs 294 GB/s with two)")
+                         "stages of one call overlap the other calls' codec kernels), 2 for decompress (round 6: 464 vs 416 GB/s "
+                         "with one, 428 with four)")
     ap.add_argument("--batch", type=int, default=-1,
                     help="map tasks per library call (s3s_compress_map_outputs_batch_device: one codec launch over the "
                          "chunks of all of them, one stream sync); -1 = all of a task thread's map tasks, 0 = one call "
@@ -525,7 +525,10 @@ def run_workload(args, rank: int, local_rank: int, world: int, dist):
 
     dev = torch.device("cuda", local_rank)
     tasks = []
-    task_threads = args.task_threads if args.task_threads > 0 else (1 if args.direction == "decompress" else 4)
+    # defaults: compress 4 task threads (spark.executor.cores of the reference's examples); decompress 2 — each a batched call over
+    # half of the step's fetched ranges, so one call's frame checks / discovery / checksums overlap the other's decode kernel
+    # (round 6, profiles/r06b_*: 8 TeraSort tasks 416 GB/s with one thread, 464 with two, 428 with four)
+    task_threads = args.task_threads if args.task_threads > 0 else (2 if args.direction == "decompress" else 4)
     if args.task_threads <= 0 and world > 1:
         # one process per GPU on ONE host: the ranks share its cores; with fewer than four usable cores per rank the task threads of
         # the ranks would queue for them (two threads x four map tasks per call measured 107.8 against 109 GB/s with four x two: r05q)
@@ -886,15 +889,15 @@ SECONDARY = [
     ("tpcds-wide-snappy:compress", "tpcds-wide-100g-200p-snappy", "compress", 128, 4),
     ("tpcds-wide-lz4:compress", "tpcds-wide-100g-200p-lz4", "compress", 128, 4),
     ("terasort-2000p-lz4-crc32:compress", "terasort-100g-2000p-lz4-crc32", "compress", 128, 4),
-    ("terasort-200p-lz4:decompress", "terasort-10g-200p-lz4", "decompress", 128, 4),
-    ("tpcds-wide-snappy:decompress", "tpcds-wide-100g-200p-snappy", "decompress", 128, 4),
+    ("terasort-200p-lz4:decompress", "terasort-10g-200p-lz4", "decompress", 128, 8),  # (round 6: the headline's 8 map outputs, two task threads x 4)
+    ("tpcds-wide-snappy:decompress", "tpcds-wide-100g-200p-snappy", "decompress", 128, 8),
     ("skew-1gib-lz4:compress", "skew-1part-lz4", "compress", 1024, 1),
-    ("skew-1gib-lz4:decompress", "skew-1part-lz4", "decompress", 1024, 1),
+    ("skew-1gib-lz4:decompress", "skew-1part-lz4", "decompress", 1024, 2),  # two fetched 1 GiB blocks in flight, one per task thread
     ("terasort-200p-zstd:decompress", "terasort-10g-200p-zstd", "decompress", 128, 8),  # frames in flight are its throughput
     ("tpcds-wide-zstd:decompress", "tpcds-wide-100g-200p-zstd", "decompress", 128, 8),  # 3.3 x the sequences per byte: the decoder's weak side, reported
-    ("terasort-200p-lz4-256k-blocks:decompress", "terasort-10g-200p-lz4-256k", "decompress", 128, 4),  # round 4: frames above 32 KiB, batch decoder
+    ("terasort-200p-lz4-256k-blocks:decompress", "terasort-10g-200p-lz4-256k", "decompress", 128, 8),  # round 4: frames above 32 KiB, batch decoder
     ("terasort-2000p-zstd:decompress", "terasort-100g-2000p-zstd", "decompress", 128, 4),  # 64 KiB frames, one zstd block each
-    ("terasort-200p-lzf:decompress", "terasort-10g-200p-lzf", "decompress", 128, 4),  # LZFOutputStream chunks written by liblzf
+    ("terasort-200p-lzf:decompress", "terasort-10g-200p-lzf", "decompress", 128, 8),  # LZFOutputStream chunks written by liblzf
 ]
 
 
@@ -1053,13 +1056,15 @@ def run_block_size_sweep(args, rank: int, local_rank: int, have: dict):
     for mib, maps in SWEEP:
         point = {"block_MiB": mib, "blocks_per_step": maps}
         for direction in ("compress", "decompress"):
-            prior = have.get(f"skew-1gib-lz4:{direction}") if mib == 1024 else None
+            prior = have.get(f"skew-1gib-lz4:{direction}") if (mib == 1024 and direction == "compress") else None
             if prior and "value" in prior:
                 point[direction], point[direction + "_ms_per_step"] = prior["value"], prior["ms_per_step"]
                 continue
             a = copy.copy(args)
             a.workload, a.direction, a.map_mib, a.maps_per_gpu = "skew-1part-lz4", direction, mib, maps
             a.steps, a.warmup, a.task_threads, a.batch, a.verify, a.no_cpu_baseline = 6, 2, 0, -1, False, True
+            if direction == "decompress" and mib * maps <= 64:
+                a.task_threads = 1  # (a small step is one batched call: 108.7 GB/s against 97.4 with two, profiles/r06h_*)
             if direction == "compress" and mib * maps <= 64:
                 # small blocks: two task threads, each with ONE batched call over half of the step's blocks (what the shim's commit
                 # queue does with the commits of concurrent tasks, S3GpuCommitQueue).  8 x 8 MiB are 2 048 block chains for a chip
