@@ -893,8 +893,11 @@ SECONDARY = [
     ("tpcds-wide-snappy:decompress", "tpcds-wide-100g-200p-snappy", "decompress", 128, 8),
     ("skew-1gib-lz4:compress", "skew-1part-lz4", "compress", 1024, 1),
     ("skew-1gib-lz4:decompress", "skew-1part-lz4", "decompress", 1024, 2),  # two fetched 1 GiB blocks in flight, one per task thread
-    ("terasort-200p-zstd:decompress", "terasort-10g-200p-zstd", "decompress", 128, 8),  # frames in flight are its throughput
-    ("tpcds-wide-zstd:decompress", "tpcds-wide-100g-200p-zstd", "decompress", 128, 8),  # 3.3 x the sequences per byte: the decoder's weak side, reported
+    # zstd: 16 map outputs, two task threads x 8 (round 6, profiles/r06j_*: the kernel is saturated from 1 600 frames on — four
+    # workgroups per CU by LDS and VGPRs — so more frames per call add nothing (8 / 16 / 32 per call: 60.3 / 60.4 / 63.0 GB/s kernel),
+    # but a second call's size pass and compaction overlap the first's decode: 49.3 -> 55.3 and 17.2 -> 22.8 GB/s)
+    ("terasort-200p-zstd:decompress", "terasort-10g-200p-zstd", "decompress", 128, 16),
+    ("tpcds-wide-zstd:decompress", "tpcds-wide-100g-200p-zstd", "decompress", 128, 16),  # 3.3 x the sequences per byte: the decoder's weak side, reported
     ("terasort-200p-lz4-256k-blocks:decompress", "terasort-10g-200p-lz4-256k", "decompress", 128, 8),  # round 4: frames above 32 KiB, batch decoder
     ("terasort-2000p-zstd:decompress", "terasort-100g-2000p-zstd", "decompress", 128, 4),  # 64 KiB frames, one zstd block each
     ("terasort-200p-lzf:decompress", "terasort-10g-200p-lzf", "decompress", 128, 8),  # LZFOutputStream chunks written by liblzf

@@ -1,0 +1,11 @@
+#!/bin/bash
+# (GPU) round 6: Zstandard reduce side by frames in flight (map outputs per batched call) and task threads
+cd $GRAFT_REPO_ROOT; O=gpurun_out/${1:-r06j}; mkdir -p $O
+run() { python bench.py --direction decompress --steps 6 --warmup 2 --no-cpu-baseline --no-secondary "$@" 2>/dev/null | tail -n 1 | python -c "
+import sys,json,os; d=json.loads(sys.stdin.read()); print('$*:', d['value'], 'GB/s ms/step', d['ms_per_step'], 'kernel GB/s', d['roofline']['achieved'], 'stages', d['stages_ms_per_library_call'], 'ok', d.get('bytes_verified'))" | tee -a $O/bench.txt; }
+for w in terasort-10g-200p-zstd tpcds-wide-100g-200p-zstd terasort-100g-2000p-zstd; do
+  run --workload $w --maps-per-gpu 8 --task-threads 1
+  run --workload $w --maps-per-gpu 16 --task-threads 1
+  run --workload $w --maps-per-gpu 16 --task-threads 2
+  run --workload $w --maps-per-gpu 32 --task-threads 1
+done
