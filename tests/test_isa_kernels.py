@@ -561,6 +561,40 @@ def test_whole_map_side_call_through_the_compiled_kernels(oracle):
     assert st == 0 and got == img.tobytes() and gs == [int(sums[0])]
 
 
+def test_batched_map_side_call_runs_its_tail_kernels_once(oracle):
+    """round 6: a batched call launches scan / gather / checksum segments / checksum combine ONCE, every kernel finding its task
+    through a TaskTail descriptor (tests/isa/map_side.py::compress_map_outputs_batch).  Three tasks of different shapes — one
+    with empty partitions and a multi-block partition, one of a single tiny partition, one with no bytes at all — must each
+    come out as the oracle's image, index and checksums in its OWN exactly-sized destination; a destination one byte short
+    fails that task alone."""
+    import map_side as ms
+    from s3shuffle import datagen
+
+    rng = np.random.default_rng(606)
+    d, offs = datagen.terasort_map_output(150_000, 5, seed=2, map_id=3)
+    t0 = [bytes(d[offs[p]:offs[p + 1]]) for p in range(5)]
+    t0[1] = b""
+    t0.append(bytes(corpus.chunk_corpus(2, 70_000, rng)))
+    t1 = [bytes(rng.integers(0, 4, 37, dtype=np.uint8))]
+    t2 = [b"", b""]
+    tasks = [t0, t1, t2]
+    for algo in (1, 2):
+        want = []
+        for parts in tasks:
+            data = np.frombuffer(b"".join(parts), np.uint8)
+            o = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int64)
+            want.append(oracle.compress_map_output(oracle.CODEC_LZ4, algo, data, o))
+        res = ms.compress_map_outputs_batch(tasks, algo, [w[0].size for w in want])
+        for (st, img, idx, sums), (wimg, widx, wsums) in zip(res, want):
+            assert st == 0 and img == wimg.tobytes() and idx == [int(x) for x in widx]
+            assert sums == [int(x) for x in wsums]
+    caps = [w[0].size for w in want]
+    caps[0] -= 1
+    res = ms.compress_map_outputs_batch(tasks, 0, caps)
+    assert res[0][0] == -2 and res[1][0] == 0 and res[2][0] == 0
+    assert res[1][1] == want[1][0].tobytes()
+
+
 def test_lz4_blocks_up_to_64k_on_the_map_side(oracle):
     """Round 4: spark.io.compression.lz4.blockSize up to 64k.  liblz4 parses every input below 65 547 bytes with the same
     8192 x u16 table (byU16), so the compiled window engine and the general parse take 64 KiB blocks as they are - positions
