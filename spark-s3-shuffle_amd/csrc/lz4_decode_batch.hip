@@ -981,17 +981,24 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
         // many short tokens (Snappy elements are 2-3 bytes long on match-dense data, 25 and more per window): the chain
         // is followed by pointer doubling — six rounds of "lanes on the chain mark the lane 2^k tokens behind them"
         // through 64 bytes of LDS (the window's pad), whatever the number of tokens.
-        uint8_t* mark = win + kBWin;  // (only ever over-read otherwise)
+        // The marks are how LANES talk to each other (lane i marks lane jmp[i]): to the compiler a plain store / load pair of one
+        // thread — it forwards "my own mark is still 0" into lanes that did not store (seen in round 6 when the read stopped being
+        // conditional; the interpreter's wait-count check caught it).  So the LDS accesses are asm: opaque, in program order.
+        const uint32_t mark = lds_addr(win + kBWin);  // (the window's pad: only ever over-read otherwise)
         int jmp = cx ? kWave : (nrel < kWave ? nrel : kWave);
-        bool reach = lane == 0;
-        mark[lane] = 0;
+        uint64_t RCH = 1ull;  // lanes known to be on the chain
+        asm volatile("ds_write_b8 %0, %1" : : "v"(mark + (uint32_t)lane), "v"(0) : "memory");
 #pragma unroll
         for (int k = 0; k < 6; k++) {
-          if (reach && jmp < kWave) mark[jmp] = 1;
-          reach = reach || mark[lane] != 0;
+          const bool put = ((RCH >> lane) & 1ull) != 0ull && jmp < kWave;
+          if (put) asm volatile("ds_write_b8 %0, %1" : : "v"(mark + (uint32_t)jmp), "v"(1) : "memory");
+          uint32_t m;
+          asm volatile("ds_read_u8 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(m) : "v"(mark + (uint32_t)lane) : "memory");
+          RCH |= ballot64(m != 0u);
           const int j2 = __shfl(jmp, jmp & 63);
           jmp = jmp < kWave ? j2 : kWave;
         }
+        const bool reach = ((RCH >> lane) & 1ull) != 0ull;
         const uint64_t RM = ballot64(reach);
         const uint64_t CXR = ballot64(reach && cx);  // the (at most one) complex token the chain runs into
         mask = RM & ~CXR;

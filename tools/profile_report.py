@@ -28,14 +28,15 @@ P = os.path.join(ROOT, "profiles")
 
 # name: (dominant kernel, traffic key, map tasks per launch of that kernel under the profiled command)
 #   compress: --maps-per-gpu 8, four task threads -> two map tasks per launch (the headline's shape);
-#   the others: --maps-per-gpu 4: compress side four threads -> one task per launch, reduce side one thread -> all four in one launch
+#   the others: compress side --maps-per-gpu 4, four threads -> one task per launch; reduce side (round 6) --maps-per-gpu 8, two task
+#   threads -> four per launch
 SETS = {
     "compress": ("lz4_compress_l2_kernel<true>", "terasort-10g-200p-lz4:compress", 2),
     "snappy_compress": ("snappy_compress_kernel<true>", "tpcds-wide-100g-200p-snappy:compress", 1),
-    "decompress": ("batch_decode_kernel<0>", "terasort-10g-200p-lz4:decompress", 4),
+    "decompress": ("batch_decode_kernel<0>", "terasort-10g-200p-lz4:decompress", 4),   # --maps-per-gpu 8, two task threads x 4 (round 6)
     "crc2000": ("lz4_compress_l2_kernel<true>", "terasort-100g-2000p-lz4-crc32:compress", 1),
     "snappy_decompress": ("batch_decode_kernel<1>", "tpcds-wide-100g-200p-snappy:decompress", 4),
-    "zstd": ("zstd_partitions_kernel", "terasort-10g-200p-zstd:decompress", 8),
+    "zstd": ("zstd_partitions_kernel", "terasort-10g-200p-zstd:decompress", 4),
 }
 # round 5: the HBM-bound stage lines (bench.py --hbm-stages-only): traffic per launch of each kernel, keyed for run_hbm_stages
 HBM_KERNELS = {"checksum_segments_kernel<1>": "hbm-stages:adler32", "checksum_segments_kernel<2>": "hbm-stages:crc32",
@@ -122,8 +123,6 @@ if os.path.exists(hsrc):
                     f"{c.get('SQ_INSTS_LDS', 0):.0f} | {c.get('SQ_WAIT_ANY', 0) / max(c.get('SQ_WAVE_CYCLES', 1), 1):.3f} |\n")
     print("hbm", {k: traffic[k]["hbm_bytes_per_launch"] for k in traffic if k.startswith("hbm-stages")})
 json.dump(traffic, open(traffic_file, "w"), indent=1)
-for f in sorted(os.listdir(G)):
+for f in sorted(os.listdir(G)):  # the closing call's bench files (tools/closing_call.sh): headline line, summary line, full record
     if f.startswith("bench") and f.endswith(".json"):
-        lines = [l for l in open(os.path.join(G, f)) if l.startswith("{")]
-        if lines:
-            open(os.path.join(P, f"{tag}_{f}"), "w").write(lines[-1])
+        open(os.path.join(P, f"{tag}_{f}"), "w").write(open(os.path.join(G, f)).read())

@@ -32,9 +32,9 @@ for s in $SETS; do
   case $s in
     compress) prof compress ;;
     snappy_compress) prof snappy_compress --workload tpcds-wide-100g-200p-snappy --maps-per-gpu 4 ;;
-    decompress) prof decompress --direction decompress --maps-per-gpu 4 ;;
+    decompress) prof decompress --direction decompress --maps-per-gpu 8 ;;
     crc2000) prof crc2000 --workload terasort-100g-2000p-lz4-crc32 --maps-per-gpu 4 ;;
-    snappy_decompress) prof snappy_decompress --workload tpcds-wide-100g-200p-snappy --direction decompress --maps-per-gpu 4 ;;
+    snappy_decompress) prof snappy_decompress --workload tpcds-wide-100g-200p-snappy --direction decompress --maps-per-gpu 8 ;;
     zstd) prof zstd --workload terasort-10g-200p-zstd --direction decompress ;;
     hbm) prof hbm --hbm-stages-only ;;  # round 5: checksum-only / xxHash32 lines on a 1 GiB range
   esac
