@@ -194,6 +194,84 @@ enum { kFmtLz4 = 0, kFmtSnappy = 1, kFmtLzf = 2 };  // kFmtLzf (round 4): liblzf
 constexpr int kParallelWalkTokens = S3S_PWALK_TOKENS;
 constexpr int kSnappyWalkTokens = S3S_SWALK_TOKENS;
 
+// ---- element front ends of the Snappy / LZF parse block (operands of that asm statement) ------------------------------------
+// in: d0 = the dword at the lane's stream position cpos.  out: isl (lanes whose element is a literal run), cx (byte-wise path),
+// r0 / r1 (the record halves of the generic front end), nxt (stream position of the element behind), islv (isl as 0 / 1).
+// Snappy: literal with its length in the tag (n6 + 1) or in one / two bytes behind it (n6 = 60 / 61; longer forms, a literal
+// past the block or above 32 KiB: byte-wise), copy with a 1-byte offset (length 4 + (n6 & 7), offset (tag >> 5) << 8 | next byte)
+// or a 2-byte offset (length n6 + 1); a 4-byte offset: byte-wise.
+// LZF: ctrl < 32: ctrl + 1 literals; else a back reference of (ctrl >> 5 [7: + next byte]) + 2 bytes, ((ctrl & 31) << 8 | last
+// byte) + 1 back.
+#define S3S_EL_FRONT_SNAPPY \
+  "v_and_b32_e32 %[ty], 3, %[d0]\n\t" \
+  "v_bfe_u32 %[n6], %[d0], 2, 6\n\t" \
+  "v_bfe_u32 %[b1], %[d0], 8, 8\n\t" \
+  "v_bfe_u32 %[w16], %[d0], 8, 16\n\t" \
+  "v_cmp_eq_u32_e32 vcc, 60, %[n6]\n\t" \
+  "v_add_u32_e32 %[len], 1, %[n6]\n\t" \
+  "v_add_u32_e32 %[vt], 1, %[b1]\n\t" \
+  "v_cmp_eq_u32_e64 %[t1], 61, %[n6]\n\t" \
+  "v_cndmask_b32_e32 %[len], %[len], %[vt], vcc\n\t" \
+  "v_cndmask_b32_e64 %[hdr], 1, 2, vcc\n\t" \
+  "v_add_u32_e32 %[vt], 1, %[w16]\n\t" \
+  "v_cmp_lt_u32_e64 %[cx], 61, %[n6]\n\t" \
+  "v_cndmask_b32_e64 %[len], %[len], %[vt], %[t1]\n\t" \
+  "v_cndmask_b32_e64 %[hdr], %[hdr], 3, %[t1]\n\t" \
+  "v_cmp_eq_u32_e64 %[isl], 0, %[ty]\n\t" \
+  "v_add3_u32 %[nxt], %[cpos], %[hdr], %[len]\n\t" \
+  "v_cmp_lt_u32_e32 vcc, 0x8000, %[len]\n\t" \
+  "v_add_u32_e32 %[vt2], %[lane], %[hdr]\n\t" \
+  "s_or_b64 %[cx], %[cx], vcc\n\t" \
+  "v_cmp_lt_i32_e32 vcc, %[clen], %[nxt]\n\t" \
+  "v_lshlrev_b32_e32 %[vt2], 16, %[vt2]\n\t" \
+  "s_or_b64 %[cx], %[cx], vcc\n\t" \
+  "s_and_b64 %[cx], %[cx], %[isl]\n\t" \
+  "v_cmp_eq_u32_e32 vcc, 3, %[ty]\n\t" \
+  "v_and_b32_e32 %[vt], 7, %[n6]\n\t" \
+  "s_or_b64 %[cx], %[cx], vcc\n\t" \
+  "v_cmp_eq_u32_e32 vcc, 1, %[ty]\n\t" \
+  "v_add_u32_e32 %[vt], 4, %[vt]\n\t" \
+  "v_add_u32_e32 %[m], 1, %[n6]\n\t" \
+  "v_bfe_u32 %[jmp], %[d0], 5, 3\n\t" \
+  "v_cndmask_b32_e32 %[vt], %[m], %[vt], vcc\n\t" \
+  "v_lshl_or_b32 %[jmp], %[jmp], 8, %[b1]\n\t" \
+  "v_lshlrev_b32_e32 %[vt], 16, %[vt]\n\t" \
+  "v_cndmask_b32_e32 %[jmp], %[w16], %[jmp], vcc\n\t" \
+  "v_cndmask_b32_e64 %[m], 3, 2, vcc\n\t" \
+  "v_cndmask_b32_e64 %[r0], %[vt], %[len], %[isl]\n\t" \
+  "v_add_u32_e32 %[m], %[cpos], %[m]\n\t" \
+  "v_cndmask_b32_e64 %[r1], %[jmp], %[vt2], %[isl]\n\t" \
+  "v_cndmask_b32_e64 %[nxt], %[m], %[nxt], %[isl]\n\t" \
+  "v_cndmask_b32_e64 %[islv], 0, 1, %[isl]\n\t"
+
+#define S3S_EL_FRONT_LZF \
+  "v_and_b32_e32 %[ty], 0xff, %[d0]\n\t" \
+  "v_bfe_u32 %[b1], %[d0], 8, 8\n\t" \
+  "v_bfe_u32 %[w16], %[d0], 16, 8\n\t" \
+  "v_cmp_gt_u32_e64 %[isl], 32, %[ty]\n\t" \
+  "v_add_u32_e32 %[len], 1, %[ty]\n\t" \
+  "v_lshrrev_b32_e32 %[n6], 5, %[ty]\n\t" \
+  "v_add3_u32 %[nxt], %[cpos], %[len], 1\n\t" \
+  "v_cmp_lt_i32_e32 vcc, %[clen], %[nxt]\n\t" \
+  "v_cmp_eq_u32_e64 %[t1], 7, %[n6]\n\t" \
+  "s_and_b64 %[cx], %[isl], vcc\n\t" \
+  "v_add_u32_e32 %[vt], 7, %[b1]\n\t" \
+  "v_add_u32_e32 %[vt2], 1, %[lane]\n\t" \
+  "v_cndmask_b32_e64 %[vt], %[n6], %[vt], %[t1]\n\t" \
+  "v_lshlrev_b32_e32 %[vt2], 16, %[vt2]\n\t" \
+  "v_add_u32_e32 %[vt], 2, %[vt]\n\t" \
+  "v_and_b32_e32 %[m], 0x1f, %[ty]\n\t" \
+  "v_cndmask_b32_e64 %[jmp], %[b1], %[w16], %[t1]\n\t" \
+  "v_lshlrev_b32_e32 %[vt], 16, %[vt]\n\t" \
+  "v_lshl_or_b32 %[jmp], %[m], 8, %[jmp]\n\t" \
+  "v_cndmask_b32_e64 %[m], 2, 3, %[t1]\n\t" \
+  "v_add_u32_e32 %[jmp], 1, %[jmp]\n\t" \
+  "v_add_u32_e32 %[m], %[cpos], %[m]\n\t" \
+  "v_cndmask_b32_e64 %[r0], %[vt], %[len], %[isl]\n\t" \
+  "v_cndmask_b32_e64 %[r1], %[jmp], %[vt2], %[isl]\n\t" \
+  "v_cndmask_b32_e64 %[nxt], %[m], %[nxt], %[isl]\n\t" \
+  "v_cndmask_b32_e64 %[islv], 0, 1, %[isl]\n\t"
+
 // one round of the pointer-doubling walk inside the Snappy parse block (operands of that asm statement; written out six times:
 // the interpreter of tests/isa reads the compiler's text, where an assembler loop would still be a directive)
 #define S3S_SNAPPY_DBL_ROUND \
@@ -210,6 +288,132 @@ constexpr int kSnappyWalkTokens = S3S_SWALK_TOKENS;
   "v_cmp_ne_u32_e64 %[t1], 0, %[m]\n\t" \
   "v_cndmask_b32_e32 %[jmp], %[c64], %[vt], vcc\n\t" \
   "s_or_b64 %[rch], %[rch], %[t1]\n\t"
+
+// ---- the Snappy / LZF parse block: ONE asm statement (front end FRONT + walk + join + stores), see its use in the kernel ----
+#define S3S_EL_PARSE_BLOCK(FRONT) \
+          asm volatile( \
+              "v_mov_b32_e32 %[one], 1\n\t" \
+              "v_mov_b32_e32 %[c64], 64\n\t" \
+              "v_add_u32_e32 %[lma], %[mark], %[lane]\n\t" \
+              ".Ls_loop%=:\n\t" \
+              "v_add_u32_e32 %[cpos], %[ip], %[lane]\n\t" \
+              "global_load_dword %[d0], %[cpos], %[c]\n\t" \
+              "s_waitcnt vmcnt(0)\n\t" \
+              FRONT \
+              "v_subrev_u32_e32 %[nxt], %[ip], %[nxt]\n\t"  /* next token, window-relative */ \
+              "s_mov_b64 %[m64], 0\n\t" \
+              "s_cmp_lt_u32 %[lt], 12\n\t" \
+              "v_cndmask_b32_e64 %[nrel], %[nxt], -1, %[cx]\n\t" \
+              "s_cbranch_scc1 .Ls_swalk%=\n\t" \
+              /* ---- pointer doubling: six rounds of "lanes on the chain mark the lane 2^k tokens behind them" ---- */ \
+              "v_min_i32_e32 %[jmp], 64, %[nxt]\n\t" \
+              "v_mov_b32_e32 %[vt], 0\n\t" \
+              "v_cndmask_b32_e64 %[jmp], %[jmp], %[c64], %[cx]\n\t" \
+              "ds_write_b8 %[lma], %[vt]\n\t" \
+              "s_mov_b64 %[rch], 1\n\t" \
+              S3S_SNAPPY_DBL_ROUND S3S_SNAPPY_DBL_ROUND S3S_SNAPPY_DBL_ROUND S3S_SNAPPY_DBL_ROUND S3S_SNAPPY_DBL_ROUND S3S_SNAPPY_DBL_ROUND \
+              "s_and_b64 %[t1], %[rch], %[cx]\n\t"  /* the (at most one) byte-wise token the chain runs into */ \
+              "s_andn2_b64 %[m64], %[rch], %[t1]\n\t" \
+              "s_cmp_lg_u64 %[t1], 0\n\t" \
+              "s_cbranch_scc0 .Ls_dnocx%=\n\t" \
+              "s_ff1_i32_b64 %[rel], %[t1]\n\t" \
+              "s_branch .Ls_wdone%=\n\t" \
+              ".Ls_dnocx%=:\n\t" \
+              "s_flbit_i32_b64 %[n], %[m64]\n\t"  /* (lane 0 is on the chain: mask != 0) */ \
+              "s_sub_i32 %[n], 63, %[n]\n\t" \
+              "v_readlane_b32 %[rel], %[nrel], %[n]\n\t" \
+              "s_branch .Ls_wdone%=\n\t" \
+              /* ---- the scalar walk (few tokens) ---- */ \
+              ".Ls_swalk%=:\n\t" \
+              "s_mov_b32 %[rel], 0\n\t" \
+              "v_readlane_b32 %[n], %[nrel], %[rel]\n\t" \
+              "s_cmp_lt_u32 %[n], 64\n\t" \
+              "s_cbranch_scc0 .Ls_wout%=\n\t" \
+              ".Ls_wnext%=:\n\t" \
+              "s_bitset1_b64 %[m64], %[rel]\n\t" \
+              "s_mov_b32 %[rel], %[n]\n\t" \
+              "v_readlane_b32 %[n], %[nrel], %[rel]\n\t" \
+              "s_cmp_lt_u32 %[n], 64\n\t" \
+              "s_cbranch_scc1 .Ls_wnext%=\n\t" \
+              ".Ls_wout%=:\n\t" \
+              "s_cmp_gt_i32 %[n], -1\n\t" \
+              "s_cbranch_scc0 .Ls_wdone%=\n\t" \
+              "s_bitset1_b64 %[m64], %[rel]\n\t" \
+              "s_mov_b32 %[rel], %[n]\n\t" \
+              ".Ls_wdone%=:\n\t" \
+              "s_bcnt1_i32_b64 %[lt], %[m64]\n\t"  /* tokens of this window (scc = any); picks the next walk */ \
+              "s_mov_b32 %[code], 1\n\t" \
+              "s_cbranch_scc0 .Ls_exit%=\n\t" \
+              /* ---- which copies join the literal in front of them: literal tokens mark their successor ---- */ \
+              "s_and_b64 %[lm], %[isl], %[m64]\n\t" \
+              "v_mov_b32_e32 %[vt], 0\n\t" \
+              "v_cmp_gt_u32_e32 vcc, 64, %[nxt]\n\t"  /* successor inside the window */ \
+              "ds_write_b8 %[lma], %[vt]\n\t" \
+              "s_and_b64 %[t1], %[lm], vcc\n\t" \
+              "s_and_saveexec_b64 %[sv], %[t1]\n\t" \
+              "v_add_u32_e32 %[vt], %[mark], %[nxt]\n\t" \
+              "ds_write_b8 %[vt], %[one]\n\t" \
+              "s_mov_b64 exec, %[sv]\n\t" \
+              "ds_read_u8 %[m], %[lma]\n\t" \
+              "s_andn2_b64 %[J], %[m64], %[isl]\n\t"  /* copy tokens ... */ \
+              "s_waitcnt lgkmcnt(0)\n\t" \
+              "v_cmp_ne_u32_e64 %[t1], 0, %[m]\n\t" \
+              "s_nop 0\n\t" \
+              "s_or_b32 %[n], %[open], 0\n\t"  /* (the first token's predecessor is the batch's last record) */ \
+              "s_mov_b32 %[cnt], 0\n\t" \
+              "s_mov_b64 %[S], 0\n\t" \
+              "s_cmp_lg_u32 %[open], 0\n\t" \
+              "s_cbranch_scc0 .Ls_noopen%=\n\t" \
+              "s_bitset1_b64 %[t1], %[cnt]\n\t"  /* ... lane 0 (always a token) counts as marked */ \
+              ".Ls_noopen%=:\n\t" \
+              "s_and_b64 %[J], %[J], %[t1]\n\t"  /* ... behind a literal: joined */ \
+              "s_andn2_b64 %[S], %[m64], %[J]\n\t"  /* tokens that start a record */ \
+              "s_bcnt1_i32_b64 %[cnt], %[S]\n\t" \
+              "s_add_i32 %[t], %[nseq], %[cnt]\n\t" \
+              "s_mov_b32 %[code], 2\n\t" \
+              "s_cmp_gt_i32 %[t], 64\n\t" \
+              "s_cbranch_scc1 .Ls_exit%=\n\t" \
+              /* ---- stores: a record per S lane; a joined copy writes its length and offset into the record in front ---- */ \
+              "s_cmp_eq_u32 %[nseq], 0\n\t" \
+              "s_cselect_b32 %[sbase], %[ip], %[sbase]\n\t" \
+              "s_sub_i32 %[cnt], %[ip], %[sbase]\n\t" \
+              "s_lshl_b32 %[cnt], %[cnt], 16\n\t" \
+              "s_mov_b64 vcc, %[S]\n\t" \
+              "v_mbcnt_lo_u32_b32 %[vt], vcc_lo, 0\n\t" \
+              "v_mbcnt_hi_u32_b32 %[vt], vcc_hi, %[vt]\n\t" \
+              "v_add_u32_e32 %[vt2], %[cnt], %[r1]\n\t" \
+              "v_add_lshl_u32 %[vt], %[vt], %[nseq], 3\n\t" \
+              "v_add_u32_e32 %[vt], %[rec], %[vt]\n\t" \
+              "v_lshrrev_b32_e32 %[m], 16, %[r0]\n\t" \
+              "s_mov_b64 exec, %[S]\n\t" \
+              "ds_write_b32 %[vt], %[r0]\n\t" \
+              "ds_write_b32 %[vt], %[vt2] offset:4\n\t" \
+              "s_mov_b64 exec, %[J]\n\t" \
+              "v_add_u32_e32 %[vt], -8, %[vt]\n\t" \
+              "ds_write_b16 %[vt], %[m] offset:2\n\t" \
+              "ds_write_b16 %[vt], %[r1] offset:4\n\t" \
+              "s_mov_b64 exec, -1\n\t" \
+              /* the window's last token is a literal: the next window's first copy may join it */ \
+              "s_flbit_i32_b64 %[n], %[m64]\n\t" \
+              "s_sub_i32 %[n], 63, %[n]\n\t" \
+              "s_bitcmp1_b64 %[lm], %[n]\n\t" \
+              "s_cselect_b32 %[open], 1, 0\n\t" \
+              "s_mov_b32 %[nseq], %[t]\n\t" \
+              "s_add_i32 %[ip], %[ip], %[rel]\n\t" \
+              "s_add_i32 %[t], %[ip], 67\n\t" \
+              "s_mov_b32 %[code], 0\n\t" \
+              "s_cmp_le_i32 %[t], %[clen]\n\t" \
+              "s_cbranch_scc1 .Ls_loop%=\n\t" \
+              ".Ls_exit%=:" \
+              : [code] "=&s"(code), [m64] "=&s"(mask), [rel] "=&s"(rel), [r0] "=&v"(r0), [r1] "=&v"(r1), [islv] "=&v"(v_isl), \
+                [ip] "+s"(ip), [nseq] "+s"(nseq), [sbase] "+s"(sbase), [lt] "+s"(lt_), [open] "+s"(open_), \
+                [n] "=&s"(n_), [cnt] "=&s"(cnt_), [t] "=&s"(t_), [cx] "=&s"(cx_), [sv] "=&s"(sv_), [isl] "=&s"(isl_), \
+                [t1] "=&s"(t1_), [lm] "=&s"(lm_), [S] "=&s"(S_), [J] "=&s"(J_), [rch] "=&s"(rch_), \
+                [cpos] "=&v"(v_cpos), [d0] "=&v"(v_d0), [ty] "=&v"(v_ty), [n6] "=&v"(v_n6), [b1] "=&v"(v_b1), [w16] "=&v"(v_w16), \
+                [len] "=&v"(v_len), [hdr] "=&v"(v_hdr), [vt] "=&v"(v_t), [vt2] "=&v"(v_t2), [nxt] "=&v"(v_nxt), [nrel] "=&v"(v_nrel), \
+                [jmp] "=&v"(v_jmp), [m] "=&v"(v_m), [one] "=&v"(n_one), [c64] "=&v"(n_c64), [lma] "=&v"(n_lma) \
+              : [c] "s"(c), [clen] "s"(clen), [lane] "v"(lane), [rec] "s"(lds_addr(rec)), [mark] "s"(markb) \
+              : "vcc", "scc", "memory");
 
 // kFmt selects the front end (token parse + byte-wise path); batches, rounds and the output window are the same:
 // a Snappy element is a sequence with either literals only (ml = 0) or a copy only (lit = 0).
@@ -902,8 +1106,8 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
           parsed = true;
         }
       }
-      if constexpr (kFmt == kFmtSnappy) {
-        // ---- Snappy, interior windows: the hand-written parse block (round 6, second half) -------------------------------
+      if constexpr (kFmt != kFmtLz4) {
+        // ---- Snappy / LZF, interior windows: the hand-written parse block (round 6, second half) -------------------------------
         // The LZ4 block's recipe for Snappy's elements: tag decode without a branch (one dword per lane: literal with its
         // length in the tag or in 1 - 2 bytes behind it, copy with a 1- or 2-byte offset; anything else = byte-wise path),
         // the walk — pointer doubling when the previous window held 12 tokens or more, the five-instruction scalar loop
@@ -918,169 +1122,11 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
           uint64_t cx_, sv_, isl_, t1_, lm_, S_, J_, rch_;
           uint32_t v_cpos, v_d0, v_ty, v_n6, v_b1, v_w16, v_len, v_hdr, v_t, v_t2, v_nxt, v_nrel, v_jmp, v_m, v_isl, n_one, n_c64, n_lma;
           const uint32_t markb = lds_addr(win + kBWin);
-          asm volatile(
-              "v_mov_b32_e32 %[one], 1\n\t"
-              "v_mov_b32_e32 %[c64], 64\n\t"
-              "v_add_u32_e32 %[lma], %[mark], %[lane]\n\t"
-              ".Ls_loop%=:\n\t"
-              "v_add_u32_e32 %[cpos], %[ip], %[lane]\n\t"
-              "global_load_dword %[d0], %[cpos], %[c]\n\t"
-              "s_waitcnt vmcnt(0)\n\t"
-              "v_and_b32_e32 %[ty], 3, %[d0]\n\t"
-              "v_bfe_u32 %[n6], %[d0], 2, 6\n\t"
-              "v_bfe_u32 %[b1], %[d0], 8, 8\n\t"
-              "v_bfe_u32 %[w16], %[d0], 8, 16\n\t"
-              // literal: length in the tag (n6 + 1) or in one / two bytes behind it
-              "v_cmp_eq_u32_e32 vcc, 60, %[n6]\n\t"
-              "v_add_u32_e32 %[len], 1, %[n6]\n\t"
-              "v_add_u32_e32 %[vt], 1, %[b1]\n\t"
-              "v_cmp_eq_u32_e64 %[t1], 61, %[n6]\n\t"
-              "v_cndmask_b32_e32 %[len], %[len], %[vt], vcc\n\t"
-              "v_cndmask_b32_e64 %[hdr], 1, 2, vcc\n\t"
-              "v_add_u32_e32 %[vt], 1, %[w16]\n\t"
-              "v_cmp_lt_u32_e64 %[cx], 61, %[n6]\n\t"            // length in 3 / 4 bytes: byte-wise path
-              "v_cndmask_b32_e64 %[len], %[len], %[vt], %[t1]\n\t"
-              "v_cndmask_b32_e64 %[hdr], %[hdr], 3, %[t1]\n\t"
-              "v_cmp_eq_u32_e64 %[isl], 0, %[ty]\n\t"
-              "v_add3_u32 %[nxt], %[cpos], %[hdr], %[len]\n\t"    // behind the literal
-              "v_cmp_lt_u32_e32 vcc, 0x8000, %[len]\n\t"          // longer than a block
-              "v_add_u32_e32 %[vt2], %[lane], %[hdr]\n\t"
-              "s_or_b64 %[cx], %[cx], vcc\n\t"
-              "v_cmp_lt_i32_e32 vcc, %[clen], %[nxt]\n\t"         // runs past the block
-              "v_lshlrev_b32_e32 %[vt2], 16, %[vt2]\n\t"          // literal: r1 = (lane + hdr) << 16
-              "s_or_b64 %[cx], %[cx], vcc\n\t"
-              "s_and_b64 %[cx], %[cx], %[isl]\n\t"                // (those three only concern literals)
-              "v_cmp_eq_u32_e32 vcc, 3, %[ty]\n\t"                // copy with a 4-byte offset: byte-wise path
-              "v_and_b32_e32 %[vt], 7, %[n6]\n\t"
-              "s_or_b64 %[cx], %[cx], vcc\n\t"
-              "v_cmp_eq_u32_e32 vcc, 1, %[ty]\n\t"                // copy with a 1-byte offset
-              "v_add_u32_e32 %[vt], 4, %[vt]\n\t"                 // its length 4 + (n6 & 7)
-              "v_add_u32_e32 %[m], 1, %[n6]\n\t"                  // 2-byte offset: length n6 + 1
-              "v_bfe_u32 %[jmp], %[d0], 5, 3\n\t"
-              "v_cndmask_b32_e32 %[vt], %[m], %[vt], vcc\n\t"     // match length of a copy
-              "v_lshl_or_b32 %[jmp], %[jmp], 8, %[b1]\n\t"        // 1-byte form: (tag >> 5) << 8 | next byte
-              "v_lshlrev_b32_e32 %[vt], 16, %[vt]\n\t"
-              "v_cndmask_b32_e32 %[jmp], %[w16], %[jmp], vcc\n\t" // offset of a copy
-              "v_cndmask_b32_e64 %[m], 3, 2, vcc\n\t"             // bytes of a copy element
-              "v_cndmask_b32_e64 %[r0], %[vt], %[len], %[isl]\n\t"
-              "v_add_u32_e32 %[m], %[cpos], %[m]\n\t"
-              "v_cndmask_b32_e64 %[r1], %[jmp], %[vt2], %[isl]\n\t"
-              "v_cndmask_b32_e64 %[nxt], %[m], %[nxt], %[isl]\n\t"
-              "v_cndmask_b32_e64 %[islv], 0, 1, %[isl]\n\t"
-              "v_subrev_u32_e32 %[nxt], %[ip], %[nxt]\n\t"        // next token, window-relative
-              "s_mov_b64 %[m64], 0\n\t"
-              "s_cmp_lt_u32 %[lt], 12\n\t"
-              "v_cndmask_b32_e64 %[nrel], %[nxt], -1, %[cx]\n\t"
-              "s_cbranch_scc1 .Ls_swalk%=\n\t"
-              // ---- pointer doubling: six rounds of "lanes on the chain mark the lane 2^k tokens behind them" ----
-              "v_min_i32_e32 %[jmp], 64, %[nxt]\n\t"
-              "v_mov_b32_e32 %[vt], 0\n\t"
-              "v_cndmask_b32_e64 %[jmp], %[jmp], %[c64], %[cx]\n\t"
-              "ds_write_b8 %[lma], %[vt]\n\t"
-              "s_mov_b64 %[rch], 1\n\t"
-              S3S_SNAPPY_DBL_ROUND S3S_SNAPPY_DBL_ROUND S3S_SNAPPY_DBL_ROUND S3S_SNAPPY_DBL_ROUND S3S_SNAPPY_DBL_ROUND S3S_SNAPPY_DBL_ROUND
-              "s_and_b64 %[t1], %[rch], %[cx]\n\t"                 // the (at most one) byte-wise token the chain runs into
-              "s_andn2_b64 %[m64], %[rch], %[t1]\n\t"
-              "s_cmp_lg_u64 %[t1], 0\n\t"
-              "s_cbranch_scc0 .Ls_dnocx%=\n\t"
-              "s_ff1_i32_b64 %[rel], %[t1]\n\t"
-              "s_branch .Ls_wdone%=\n\t"
-              ".Ls_dnocx%=:\n\t"
-              "s_flbit_i32_b64 %[n], %[m64]\n\t"                   // (lane 0 is on the chain: mask != 0)
-              "s_sub_i32 %[n], 63, %[n]\n\t"
-              "v_readlane_b32 %[rel], %[nrel], %[n]\n\t"
-              "s_branch .Ls_wdone%=\n\t"
-              // ---- the scalar walk (few tokens) ----
-              ".Ls_swalk%=:\n\t"
-              "s_mov_b32 %[rel], 0\n\t"
-              "v_readlane_b32 %[n], %[nrel], %[rel]\n\t"
-              "s_cmp_lt_u32 %[n], 64\n\t"
-              "s_cbranch_scc0 .Ls_wout%=\n\t"
-              ".Ls_wnext%=:\n\t"
-              "s_bitset1_b64 %[m64], %[rel]\n\t"
-              "s_mov_b32 %[rel], %[n]\n\t"
-              "v_readlane_b32 %[n], %[nrel], %[rel]\n\t"
-              "s_cmp_lt_u32 %[n], 64\n\t"
-              "s_cbranch_scc1 .Ls_wnext%=\n\t"
-              ".Ls_wout%=:\n\t"
-              "s_cmp_gt_i32 %[n], -1\n\t"
-              "s_cbranch_scc0 .Ls_wdone%=\n\t"
-              "s_bitset1_b64 %[m64], %[rel]\n\t"
-              "s_mov_b32 %[rel], %[n]\n\t"
-              ".Ls_wdone%=:\n\t"
-              "s_bcnt1_i32_b64 %[lt], %[m64]\n\t"                  // tokens of this window (scc = any); picks the next walk
-              "s_mov_b32 %[code], 1\n\t"
-              "s_cbranch_scc0 .Ls_exit%=\n\t"
-              // ---- which copies join the literal in front of them: literal tokens mark their successor ----
-              "s_and_b64 %[lm], %[isl], %[m64]\n\t"
-              "v_mov_b32_e32 %[vt], 0\n\t"
-              "v_cmp_gt_u32_e32 vcc, 64, %[nxt]\n\t"               // successor inside the window
-              "ds_write_b8 %[lma], %[vt]\n\t"
-              "s_and_b64 %[t1], %[lm], vcc\n\t"
-              "s_and_saveexec_b64 %[sv], %[t1]\n\t"
-              "v_add_u32_e32 %[vt], %[mark], %[nxt]\n\t"
-              "ds_write_b8 %[vt], %[one]\n\t"
-              "s_mov_b64 exec, %[sv]\n\t"
-              "ds_read_u8 %[m], %[lma]\n\t"
-              "s_andn2_b64 %[J], %[m64], %[isl]\n\t"               // copy tokens ...
-              "s_waitcnt lgkmcnt(0)\n\t"
-              "v_cmp_ne_u32_e64 %[t1], 0, %[m]\n\t"
-              "s_nop 0\n\t"
-              "s_or_b32 %[n], %[open], 0\n\t"                      // (the first token's predecessor is the batch's last record)
-              "s_mov_b32 %[cnt], 0\n\t"
-              "s_mov_b64 %[S], 0\n\t"
-              "s_cmp_lg_u32 %[open], 0\n\t"
-              "s_cbranch_scc0 .Ls_noopen%=\n\t"
-              "s_bitset1_b64 %[t1], %[cnt]\n\t"                    // ... lane 0 (always a token) counts as marked
-              ".Ls_noopen%=:\n\t"
-              "s_and_b64 %[J], %[J], %[t1]\n\t"                    // ... behind a literal: joined
-              "s_andn2_b64 %[S], %[m64], %[J]\n\t"                 // tokens that start a record
-              "s_bcnt1_i32_b64 %[cnt], %[S]\n\t"
-              "s_add_i32 %[t], %[nseq], %[cnt]\n\t"
-              "s_mov_b32 %[code], 2\n\t"
-              "s_cmp_gt_i32 %[t], 64\n\t"
-              "s_cbranch_scc1 .Ls_exit%=\n\t"
-              // ---- stores: a record per S lane; a joined copy writes its length and offset into the record in front ----
-              "s_cmp_eq_u32 %[nseq], 0\n\t"
-              "s_cselect_b32 %[sbase], %[ip], %[sbase]\n\t"
-              "s_sub_i32 %[cnt], %[ip], %[sbase]\n\t"
-              "s_lshl_b32 %[cnt], %[cnt], 16\n\t"
-              "s_mov_b64 vcc, %[S]\n\t"
-              "v_mbcnt_lo_u32_b32 %[vt], vcc_lo, 0\n\t"
-              "v_mbcnt_hi_u32_b32 %[vt], vcc_hi, %[vt]\n\t"
-              "v_add_u32_e32 %[vt2], %[cnt], %[r1]\n\t"
-              "v_add_lshl_u32 %[vt], %[vt], %[nseq], 3\n\t"
-              "v_add_u32_e32 %[vt], %[rec], %[vt]\n\t"
-              "v_lshrrev_b32_e32 %[m], 16, %[r0]\n\t"
-              "s_mov_b64 exec, %[S]\n\t"
-              "ds_write_b32 %[vt], %[r0]\n\t"
-              "ds_write_b32 %[vt], %[vt2] offset:4\n\t"
-              "s_mov_b64 exec, %[J]\n\t"
-              "v_add_u32_e32 %[vt], -8, %[vt]\n\t"
-              "ds_write_b16 %[vt], %[m] offset:2\n\t"
-              "ds_write_b16 %[vt], %[r1] offset:4\n\t"
-              "s_mov_b64 exec, -1\n\t"
-              // the window's last token is a literal: the next window's first copy may join it
-              "s_flbit_i32_b64 %[n], %[m64]\n\t"
-              "s_sub_i32 %[n], 63, %[n]\n\t"
-              "s_bitcmp1_b64 %[lm], %[n]\n\t"
-              "s_cselect_b32 %[open], 1, 0\n\t"
-              "s_mov_b32 %[nseq], %[t]\n\t"
-              "s_add_i32 %[ip], %[ip], %[rel]\n\t"
-              "s_add_i32 %[t], %[ip], 67\n\t"
-              "s_mov_b32 %[code], 0\n\t"
-              "s_cmp_le_i32 %[t], %[clen]\n\t"
-              "s_cbranch_scc1 .Ls_loop%=\n\t"
-              ".Ls_exit%=:"
-              : [code] "=&s"(code), [m64] "=&s"(mask), [rel] "=&s"(rel), [r0] "=&v"(r0), [r1] "=&v"(r1), [islv] "=&v"(v_isl),
-                [ip] "+s"(ip), [nseq] "+s"(nseq), [sbase] "+s"(sbase), [lt] "+s"(lt_), [open] "+s"(open_),
-                [n] "=&s"(n_), [cnt] "=&s"(cnt_), [t] "=&s"(t_), [cx] "=&s"(cx_), [sv] "=&s"(sv_), [isl] "=&s"(isl_),
-                [t1] "=&s"(t1_), [lm] "=&s"(lm_), [S] "=&s"(S_), [J] "=&s"(J_), [rch] "=&s"(rch_),
-                [cpos] "=&v"(v_cpos), [d0] "=&v"(v_d0), [ty] "=&v"(v_ty), [n6] "=&v"(v_n6), [b1] "=&v"(v_b1), [w16] "=&v"(v_w16),
-                [len] "=&v"(v_len), [hdr] "=&v"(v_hdr), [vt] "=&v"(v_t), [vt2] "=&v"(v_t2), [nxt] "=&v"(v_nxt), [nrel] "=&v"(v_nrel),
-                [jmp] "=&v"(v_jmp), [m] "=&v"(v_m), [one] "=&v"(n_one), [c64] "=&v"(n_c64), [lma] "=&v"(n_lma)
-              : [c] "s"(c), [clen] "s"(clen), [lane] "v"(lane), [rec] "s"(lds_addr(rec)), [mark] "s"(markb)
-              : "vcc", "scc", "memory");
+          if constexpr (kFmt == kFmtSnappy) {
+            S3S_EL_PARSE_BLOCK(S3S_EL_FRONT_SNAPPY)
+          } else {
+            S3S_EL_PARSE_BLOCK(S3S_EL_FRONT_LZF)
+          }
           last_tokens = lt_;
           open_lit = open_ != 0;
           if (code == 0) continue;

@@ -354,6 +354,27 @@ def test_compiled_lz4_parse_block_takes_the_interior_windows(oracle):
     assert walk > 4000 and walk > 20 * generic, (walk, generic)
 
 
+@pytest.mark.parametrize("fmt", [1, 2], ids=["snappy", "lzf"])
+def test_compiled_element_parse_block_takes_the_interior_windows(oracle, fmt):
+    """the Snappy / LZF parse block (one asm statement per format: branch-free element decode, doubling or scalar walk, the
+    literal-copy join through LDS marks, record stores) must be where ordinary blocks are parsed — match-dense wide rows
+    (25 elements per window: the doubling walk) and TeraSort records (the scalar walk) — and the result must be the source"""
+    import decode_kernel as dk
+    from s3shuffle import datagen
+
+    for gen, seed in ((datagen.tpcds_wide_map_output, 3), (datagen.terasort_map_output, 2)):
+        d, _ = gen(1 << 19, 1, seed=seed, map_id=1)
+        blk = d[32768 * 4:32768 * 5]
+        c = bytes(oracle.snappy_compress_block(blk) if fmt == 1 else oracle.lzf_compress_block(blk))
+        prof = {}
+        res, st, _ = dk.decode_blocks([(c, 32768)], fmt=fmt, profile=prof)
+        assert st == 0 and res[0] == bytes(blk)
+        in_block = sum(v[0] for k, v in prof.items() if k.startswith(".Ls_"))
+        generic_walk = sum(v[0] for k, v in prof.items() if k.startswith(".Lwalk_next"))
+        total = sum(v[0] for v in prof.values())
+        assert in_block > 0.25 * total and generic_walk < 0.01 * total, (in_block, generic_walk, total)
+
+
 def test_compiled_decoder_on_chained_sources(oracle):
     """hand-made sequence lists whose matches copy from inside earlier matches, from literal runs and from periodic
     patterns (the generator of tests/test_batch_decode_model.py): what the decoder's source redirection, its 16-byte
