@@ -1,6 +1,6 @@
 """Fuzz of the COMPILED batch decoder in the gfx950 interpreter (TEST INFRASTRUCTURE).
 
-    python tests/tools/isa_decode_fuzz.py --seed 5 --minutes 20 [--fmt lz4|snappy|both] [--kernel batch|ring]
+    python tests/tools/isa_decode_fuzz.py --seed 5 --minutes 20 [--fmt lz4|snappy|lzf|both] [--kernel batch|ring]
 
 Valid blocks (sequence lists with chained / periodic / literal sources, oracle-compressed corpora) must decode to the
 reference decoder's bytes; mutated blocks must be refused or decode to exactly what the reference decoder produces — and the
@@ -43,13 +43,17 @@ def main():
                     help="ring = lz4_decompress_valu_kernel / snappy_decompress_valu_kernel (decode variant 3, the fallback for big frames)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
-    fmts = [0, 1] if args.fmt == "both" else [0 if args.fmt == "lz4" else 1]
+    fmts = [0, 1] if args.fmt == "both" else [{"lz4": 0, "snappy": 1, "lzf": 2}[args.fmt]]
     t0, n_valid, n_mut, bad = time.time(), 0, 0, 0
     while time.time() - t0 < args.minutes * 60:
         for fmt in fmts:
             cases = []
             for _ in range(6):
-                if rng.integers(0, 3) == 0:
+                if fmt == 2:  # LZF (round 6: its front end is a hand-written block too): the oracle's encoder over the corpora, liblzf-pinned decoder as reference
+                    c = corpus.chunk_corpus(int(rng.integers(0, corpus.N_KINDS)), int(rng.integers(20, 9000)), rng)
+                    blk = bytes(oracle.lzf_compress_block(c))
+                    want = c.tobytes()
+                elif rng.integers(0, 3) == 0:
                     c = corpus.chunk_corpus(int(rng.integers(0, corpus.N_KINDS)), int(rng.integers(20, 6000)), rng)
                     blk = bytes(oracle.lz4_compress_block(c) if fmt == 0 else oracle.snappy_compress_block(c))
                     want = c.tobytes()
@@ -89,7 +93,11 @@ def main():
                 p = bytearray(blk)
                 for _ in range(int(rng.integers(1, 4))):
                     p[int(rng.integers(0, len(p)))] = int(rng.integers(0, 256))
-                ref = (framing.lz4_decode_py if fmt == 0 else framing.snappy_decode_py)(bytes(p))
+                if fmt == 2:  # (the block does not carry its decoded length: the frame record's length is the source's)
+                    r = oracle.lzf_decompress_block(np.frombuffer(bytes(p), np.uint8), len(want))
+                    ref = None if isinstance(r, int) or len(r) != len(want) else r.tobytes()
+                else:
+                    ref = (framing.lz4_decode_py if fmt == 0 else framing.snappy_decode_py)(bytes(p))
                 olen = len(ref) if ref is not None and 0 < len(ref) <= 32768 else len(want)
                 if fmt == 1:  # a Snappy block declares its length: the frame record must agree or the kernel refuses
                     pass
