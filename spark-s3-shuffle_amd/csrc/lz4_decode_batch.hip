@@ -19,7 +19,7 @@
 //            source shifted (chains resolved by pointer doubling), a source inside the batch's literals
 //            is final from the start, periods 1 / 2 / 4 are splats; a match above 64 bytes, an odd
 //            period or a source that straddles the window base is copied by the whole wave
-//   output   is staged in a sliding LDS window (5.4 KiB, 4 KiB of history survive a slide): match
+//   output   is staged in a sliding LDS window (4.4 KiB, 2 KiB of history survive a slide): match
 //            sources are LDS reads, the block leaves in 16-byte coalesced stores; a source older than
 //            the window is read back from L2 (after the flush that wrote it has drained)
 //   tokens the fast parse does not take (lengths with a 255 chain, the block's last sequence) go
@@ -37,13 +37,17 @@ namespace s3s {
 namespace {
 
 #ifndef S3S_BWIN
-#define S3S_BWIN 5568
+#define S3S_BWIN 4544
 #endif
 #ifndef S3S_BHIST
-#define S3S_BHIST 4096
+#define S3S_BHIST 2048
 #endif
-constexpr int kBWin = S3S_BWIN;    // staged output bytes (multiple of 16); with pad + records = 6 KiB -> 26 wavefronts / CU
-                                   // (measured: 7616 / 4096 = 20 per CU 278 GB/s, 5568 / 4096 298, 4544 / 3072 284, 3520 / 2048 292)
+constexpr int kBWin = S3S_BWIN;    // staged output bytes (multiple of 16); with pad + records = 5 KiB -> 32 wavefronts / CU
+                                   // (round 2, compiled kernel: 7616 / 4096 = 20 per CU 278 GB/s, 5568 / 4096 298, 4544 / 3072 284, 3520 / 2048 292;
+                                   //  round 6, after the instruction diet (profiles/r06p_*, TeraSort / wide rows LZ4 / Snappy / 1 GiB blocks):
+                                   //  7616 / 4096 480 / 223 / 211 / 466, 5568 / 4096 492 - 503 / 247 / 226 / 478, 4544 / 3072 494 / 257 / 226 / 497,
+                                   //  4544 / 2048 501 / 261 / 226 / 505, 3520 / 2048 493 / 257 / 224 / 489 — with fewer instructions per frame the
+                                   //  kernel follows its residency again)
 constexpr int kBHist = S3S_BHIST;  // history a slide keeps
 static_assert(kBWin % 16 == 0 && kBHist % 16 == 0 && kBWin >= kBHist + 1024, "window geometry");
 constexpr int kBPad = 64;
@@ -1005,7 +1009,7 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
         //   code 2: the window at ip is parsed (mask, rel, r0, r1) but the batch is full,
         // and the code below carries on from there (flush, byte-wise path, store) exactly as after its own front end.
         // Why by hand: the compiler's form of this loop is ~90 scalar instructions per window (flag registers for every
-        // break / continue, re-materialised bools) and the CU's ONE scalar port is what its 26 decoder wavefronts queue for
+        // break / continue, re-materialised bools) and the CU's ONE scalar port is what its 28 decoder wavefronts queue for
         // (profiles/r06_experiments.md §2); this block has ~62, and 33 vector instructions instead of ~48.
         if (ip + 67 <= clen) {
           int code, n_, cnt_, t_;
@@ -1257,7 +1261,7 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
       } else {
         // for (;;) { n = nrel[rel]; if (n < 0) break; mask |= 1 << rel; rel = n; if (rel >= 64) break; } — five
         // instructions per token, both ends of the chain in one unsigned compare (the compiler's loop has thirteen,
-        // and the CU's one scalar issue per cycle is what its 26 decoder waves wait for)
+        // and the CU's one scalar issue per cycle is what its 28 decoder waves wait for)
         int n;
         asm volatile(
             "v_readlane_b32 %[n], %[v], %[rel]\n"

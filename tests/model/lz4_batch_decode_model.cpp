@@ -18,8 +18,8 @@
 namespace {
 
 constexpr int W = 64;
-constexpr int kWin = 5568;    // bytes of output held in the staging window (= kBWin of the kernel)
-constexpr int kHist = 4096;   // history kept by a slide
+constexpr int kWin = 4544;    // bytes of output held in the staging window (= kBWin of the kernel)
+constexpr int kHist = 2048;   // history kept by a slide
 constexpr int kPad = 64;
 constexpr int kSmallMl = 16;  // per-lane match copies up to this length, longer ones cooperatively
 constexpr int kSmallLit = 32; // per-lane literal copies up to this length
