@@ -422,7 +422,7 @@ constexpr int kSnappyWalkTokens = S3S_SWALK_TOKENS;
 // kFmt selects the front end (token parse + byte-wise path); batches, rounds and the output window are the same:
 // a Snappy element is a sequence with either literals only (ml = 0) or a copy only (lit = 0).
 template <int kFmt>
-__global__ __launch_bounds__(kWave) void batch_decode_kernel(
+__global__ __launch_bounds__(kWave, 8) void batch_decode_kernel(
     const uint8_t* __restrict__ comp, const Frame* __restrict__ frames, int32_t n_frames,
     const int64_t* __restrict__ frame_out, uint8_t* dst, int32_t* __restrict__ status
 ) {
@@ -1009,7 +1009,7 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
         //   code 2: the window at ip is parsed (mask, rel, r0, r1) but the batch is full,
         // and the code below carries on from there (flush, byte-wise path, store) exactly as after its own front end.
         // Why by hand: the compiler's form of this loop is ~90 scalar instructions per window (flag registers for every
-        // break / continue, re-materialised bools) and the CU's ONE scalar port is what its 28 decoder wavefronts queue for
+        // break / continue, re-materialised bools) and the CU's ONE scalar port is what its 32 decoder wavefronts queue for
         // (profiles/r06_experiments.md §2); this block has ~62, and 33 vector instructions instead of ~48.
         if (ip + 67 <= clen) {
           int code, n_, cnt_, t_;
@@ -1261,7 +1261,7 @@ __global__ __launch_bounds__(kWave) void batch_decode_kernel(
       } else {
         // for (;;) { n = nrel[rel]; if (n < 0) break; mask |= 1 << rel; rel = n; if (rel >= 64) break; } — five
         // instructions per token, both ends of the chain in one unsigned compare (the compiler's loop has thirteen,
-        // and the CU's one scalar issue per cycle is what its 28 decoder waves wait for)
+        // and the CU's one scalar issue per cycle is what its 32 decoder waves wait for)
         int n;
         asm volatile(
             "v_readlane_b32 %[n], %[v], %[rel]\n"
