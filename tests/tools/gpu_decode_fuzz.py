@@ -53,6 +53,17 @@ def main():
     ap.add_argument("--parts", type=int, default=48)
     ap.add_argument("--codec", default="all")
     a = ap.parse_args()
+    rounds, mb, refused, bad = run(a.seed, a.seconds, a.parts, a.codec)
+    print("DONE seed %d: %d rounds, %.1f MB per codec, %d damaged images refused, %d failures" % (a.seed, rounds, mb, refused, bad), flush=True)
+    sys.exit(1 if bad else 0)
+
+
+def run(seed, seconds, parts_n=48, codec_sel="all"):
+    """-> (rounds, MB per codec, damaged images refused, failures)"""
+    class A:
+        pass
+    a = A()
+    a.seed, a.seconds, a.parts, a.codec = seed, seconds, parts_n, codec_sel
     import corpus
     import isa_fuzz as F
     import s3shuffle
@@ -109,8 +120,8 @@ def main():
                 refused += 1
             n_bytes += data.size
         rounds += 1
-    print("DONE seed %d: %d rounds, %.1f MB per codec, %d damaged images refused, %d failures" % (a.seed, rounds, n_bytes / len(codecs) / 1e6, refused, bad), flush=True)
-    sys.exit(1 if bad else 0)
+    c.close()
+    return rounds, n_bytes / len(codecs) / 1e6, refused, bad
 
 
 if __name__ == "__main__":
